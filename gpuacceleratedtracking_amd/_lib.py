@@ -1,0 +1,123 @@
+"""ctypes binding of libgat.so -- the only way the Python host layer reaches the GPU.
+
+There is NO fallback: if the HIP library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+GAT_OK = 0
+GAT_FLAG_ATOMIC = 1
+GAT_LAYOUT_PLANAR = 0
+GAT_LAYOUT_INTERLEAVED = 1
+GAT_MAX_TAPS = 32
+
+EXPORTS = [
+    "gat_create", "gat_destroy", "gat_set_stream", "gat_sync", "gat_last_error", "gat_version",
+    "gat_device_info", "gat_set_codes", "gat_gen_codes", "gat_sample_shifts",
+    "gat_downconvert_and_correlate", "gat_downconvert_and_correlate_dev", "gat_gen_code_replica",
+    "gat_gen_signal", "gat_reduce_cplx_multi", "gat_malloc", "gat_free", "gat_memcpy_h2d",
+    "gat_memcpy_d2h", "gat_memset", "gat_timer_start", "gat_timer_stop", "gat_last_launch_info",
+]
+
+
+class GatError(RuntimeError):
+    """A libgat call returned a non-zero status."""
+
+    def __init__(self, status: int, where: str, message: str = ""):
+        self.status = status
+        kind = {1: "GAT_ERR_ARG", 2: "GAT_ERR_RANGE", 3: "GAT_ERR_STATE", 4: "GAT_ERR_UNSUPPORTED",
+                5: "GAT_ERR_NOMEM"}.get(status, f"hipError {-status}" if status < 0 else str(status))
+        super().__init__(f"{where}: {kind}" + (f" ({message})" if message else ""))
+
+
+class ChannelParams(C.Structure):
+    """gat_channel_params (include/gat.h)."""
+
+    _fields_ = [("prn", C.c_int32), ("reserved", C.c_int32), ("code_freq_hz", C.c_double),
+                ("carrier_freq_hz", C.c_double), ("code_phase_chips", C.c_double),
+                ("carrier_phase_cycles", C.c_double)]
+
+
+PARAMS_DTYPE = np.dtype([("prn", "<i4"), ("reserved", "<i4"), ("code_freq_hz", "<f8"),
+                         ("carrier_freq_hz", "<f8"), ("code_phase_chips", "<f8"),
+                         ("carrier_phase_cycles", "<f8")])
+assert PARAMS_DTYPE.itemsize == C.sizeof(ChannelParams) == 40
+
+
+class SignalDesc(C.Structure):
+    """gat_signal_desc (include/gat.h)."""
+
+    _fields_ = [("re", C.c_void_p), ("im", C.c_void_p), ("layout", C.c_int32),
+                ("num_ants", C.c_int32), ("num_samples", C.c_int64), ("ant_stride", C.c_int64),
+                ("block_stride", C.c_int64), ("chan_stride", C.c_int64)]
+
+
+class LaunchInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("workgroups", "threads", "splits", "ant_tile", "vec",
+                                          "lds_bytes", "finalize_launched", "reserved")]
+
+
+_LIB = None
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True):
+    """Load libgat.so (building it with hipcc when absent/stale and hipcc is available)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if build_if_missing and _build.is_stale():
+        try:
+            _build.build_libgat()
+        except Exception as exc:  # no hipcc on this machine
+            if not os.path.exists(path):
+                raise ImportError(f"libgat.so is not built and hipcc failed: {exc}") from exc
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: run `python -m gpuacceleratedtracking_amd.build`")
+    lib = C.CDLL(path)
+    vp, i32, i64, u32, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_double
+    pp = C.POINTER(ChannelParams)
+    sp = C.POINTER(SignalDesc)
+    i32p = C.POINTER(C.c_int32)
+    sigs = {
+        "gat_create": (i32, [i32, vp, C.POINTER(vp)]),
+        "gat_destroy": (i32, [vp]),
+        "gat_set_stream": (i32, [vp, vp]),
+        "gat_sync": (i32, [vp]),
+        "gat_last_error": (C.c_char_p, [vp]),
+        "gat_version": (C.c_char_p, []),
+        "gat_device_info": (i32, [vp, C.c_char_p, C.c_size_t, i32p, i32p]),
+        "gat_set_codes": (i32, [vp, C.POINTER(C.c_int8), i32, i32]),
+        "gat_gen_codes": (i32, [C.c_char_p, i32, C.POINTER(C.c_int8), i32p, C.POINTER(dbl)]),
+        "gat_sample_shifts": (i32, [i32, dbl, dbl, dbl, i32p]),
+        "gat_downconvert_and_correlate": (i32, [vp, sp, pp, i32, i32, i32, i32p, dbl, vp, vp, u32]),
+        "gat_downconvert_and_correlate_dev": (i32, [vp, sp, vp, i32, i32, i32, i32p, dbl, vp, vp, u32]),
+        "gat_gen_code_replica": (i32, [vp, vp, i64, i32, dbl, dbl, dbl, i64]),
+        "gat_gen_signal": (i32, [vp, vp, vp, i32, i64, i32, i64, i64, i32, i32, vp, dbl]),
+        "gat_reduce_cplx_multi": (i32, [vp, vp, vp, i64, i32, vp, vp]),
+        "gat_malloc": (i32, [vp, C.c_size_t, C.POINTER(vp)]),
+        "gat_free": (i32, [vp, vp]),
+        "gat_memcpy_h2d": (i32, [vp, vp, vp, C.c_size_t]),
+        "gat_memcpy_d2h": (i32, [vp, vp, vp, C.c_size_t]),
+        "gat_memset": (i32, [vp, vp, i32, C.c_size_t]),
+        "gat_timer_start": (i32, [vp]),
+        "gat_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
+        "gat_last_launch_info": (i32, [vp, C.POINTER(LaunchInfo)]),
+    }
+    assert sorted(sigs) == sorted(EXPORTS)
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib

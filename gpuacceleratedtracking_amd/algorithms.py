@@ -1,0 +1,184 @@
+"""Selector types and the ``kernel_algorithm`` launch-sequencing surface of the reference
+(src/GPUAcceleratedTracking.jl:24-91, src/algorithms.jl:869-1545).
+
+The reference has nine ``kernel_algorithm`` methods, each sequencing 1-4 CUDA launches
+(replica -> downconvert -> reduce -> reduce).  Here EVERY algorithm id maps onto the one fused
+HIP kernel family of libgat; the id only selects the second-stage flavour the reference's ladder
+distinguishes: ids 4xxx/5xxx ("atomic reduction", src/algorithms.jl:625-632) use
+``GAT_FLAG_ATOMIC``, all others the deterministic two-stage sum.  The positional argument lists
+are kept exactly (three forms, see ``kernel_algorithm``) so that the reference's tests and
+``_run_kernel_benchmark`` bodies read the same; launch-shape arguments (threads, blocks, shmem)
+and scratch buffers are accepted and ignored.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from .context import get_context
+from .correlator import _as_int
+from .gen_signal import make_params
+from .signals import GNSSSystem
+from .tracking import _signal_desc
+
+
+class _Selector:
+    __slots__ = ("id",)
+
+    def __init__(self, x):
+        self.id = x
+
+    def __eq__(self, other):
+        return type(self) is type(other) and self.id == other.id
+
+    def __hash__(self):
+        return hash((type(self).__name__, self.id))
+
+    def __repr__(self):
+        return f"{type(self).__name__}({self.id})"
+
+
+class KernelAlgorithm(_Selector):
+    """``KernelAlgorithm{x}`` (src/GPUAcceleratedTracking.jl:24-27)."""
+
+
+class ReductionAlgorithm(_Selector):
+    """``ReductionAlgorithm{x}`` (src/GPUAcceleratedTracking.jl:29-32)."""
+
+
+class ReplicaAlgorithm(_Selector):
+    """``ReplicaAlgorithm{x}`` (src/GPUAcceleratedTracking.jl:34-37)."""
+
+
+# src/GPUAcceleratedTracking.jl:44-61
+ALGODICT = {
+    "1_3_cplx_multi": 1330,
+    "1_3_cplx_multi_textmem": 1331,
+    "1_4_cplx_multi_textmem": 1431,
+    "2_3_cplx_multi": 2330,
+    "2_3_cplx_multi_textmem": 2331,
+    "2_4_cplx_multi": 2430,
+    "2_4_cplx_multi_textmem": 2431,
+    "3_4_cplx_multi": 3430,
+    "3_4_cplx_multi_textmem": 3431,
+    "4_4_cplx_multi_textmem": 4431,
+    "5_4_cplx_multi_textmem": 5431,
+    # this build's own entry: the fused HIP path under its own name
+    "hip_fused": 9000,
+    "hip_fused_atomic": 9001,
+}
+# src/GPUAcceleratedTracking.jl:63-72
+REDDICT = {"pure": ReductionAlgorithm(1), "cplx": ReductionAlgorithm(2), "cplx_multi": ReductionAlgorithm(3)}
+MEMDICT = {"gmem": ReplicaAlgorithm(1), "textmem": ReplicaAlgorithm(2)}
+# src/GPUAcceleratedTracking.jl:74-91 (the duplicate 1331 key of the reference resolves to the
+# later entry, as a Julia Dict literal does)
+ALGODICTINV = {
+    1300: "1_3_pure", 1301: "1_3_pure_textmem", 1320: "1_3_cplx", 1330: "1_3_cplx_multi",
+    1331: "1_3_cplx_multi_textmem", 1430: "1_4_cplx_multi", 1431: "1_4_cplx_multi_textmem",
+    2330: "2_3_cplx_multi", 2331: "2_3_cplx_multi_textmem", 2430: "2_4_cplx_multi",
+    2431: "2_4_cplx_multi_textmem", 3430: "3_4_cplx_multi", 3431: "3_4_cplx_multi_textmem",
+    4431: "4_4_cplx_multi_textmem", 5431: "5_4_cplx_multi_textmem",
+    9000: "hip_fused", 9001: "hip_fused_atomic",
+}
+
+_FORM_A = {1330, 1331, 1431}                     # ..., partial_sum, carrier.., 25 positional
+_FORM_B = {2330, 2331, 2430, 2431}               # ..., accum_re, accum_im, phi_re, phi_im, .. 28
+_FORM_C = {3430, 3431, 4431, 5431, 9000, 9001}   # ..., accum_re, accum_im, carrier.., 26
+_ATOMIC = {4431, 5431, 9001}
+
+
+def algorithm_flags(algorithm: KernelAlgorithm) -> int:
+    return _lib.GAT_FLAG_ATOMIC if algorithm.id in _ATOMIC else 0
+
+
+def _codes_of(codes) -> np.ndarray:
+    if isinstance(codes, GNSSSystem):
+        return codes.codes
+    if isinstance(codes, torch.Tensor):
+        codes = codes.cpu().numpy()
+    return np.ascontiguousarray(codes, dtype=np.int8)
+
+
+def _store(dst_re: torch.Tensor, dst_im: torch.Tensor, res_re: torch.Tensor, res_im: torch.Tensor):
+    """Write the [L, M] result where the reference's tests read it: ``Array(buf)[1, :, :]`` of a
+    column-major [blocks x M x L] buffer == ``buf[:, :, 0]`` of the C-order [L, M, blocks] tensor;
+    a plain [L, M] accumulator (alg. 4/5, ``accum[m, l]``) is overwritten whole."""
+    L, M = res_re.shape
+    for dst, res in ((dst_re, res_re), (dst_im, res_im)):
+        if dst.shape == (L, M):
+            dst.copy_(res)
+        elif dst.dim() == 3 and dst.shape[:2] == (L, M):
+            dst[:, :, 0].copy_(res)
+        else:
+            raise ValueError(f"result buffer shape {tuple(dst.shape)} does not hold an [{L}, {M}] result")
+
+
+def kernel_algorithm(*args):
+    """``kernel_algorithm(threads_per_block, blocks_per_grid, shmem_size, code_replica, codes,
+    code_frequency, sampling_frequency, start_code_phase, prn, num_samples, num_of_shifts,
+    code_length, <result buffers>, carrier_replica_re, carrier_replica_im,
+    downconverted_signal_re, downconverted_signal_im, signal_re, signal_im,
+    correlator_sample_shifts, carrier_frequency, carrier_phase, num_ants, num_corrs, algorithm)``
+
+    ``<result buffers>`` is ``partial_sum`` (object with .re/.im) for 1330/1331/1431
+    (src/algorithms.jl:869-895), ``accum_re, accum_im, phi_re, phi_im`` for 2xxx (:1050-1079,
+    result read from ``phi``), ``accum_re, accum_im`` for 3431/4431 (:1410-1437, :1485-1512).
+    ``prn`` is 1-based; ``carrier_phase`` in cycles."""
+    algorithm = args[-1]
+    if not isinstance(algorithm, KernelAlgorithm):
+        raise TypeError("last argument must be a KernelAlgorithm")
+    aid = algorithm.id
+    head = args[:12]
+    (_tpb, _bpg, _shmem, _code_replica, codes, code_frequency, sampling_frequency, start_code_phase, prn,
+     num_samples, _num_of_shifts, code_length) = head
+    if aid in _FORM_A:
+        if len(args) != 25:
+            raise TypeError(f"KernelAlgorithm({aid}) takes 25 positional arguments, got {len(args)}")
+        partial_sum = args[12]
+        res_re, res_im = partial_sum.re, partial_sum.im
+        rest = args[13:]
+    elif aid in _FORM_B:
+        if len(args) != 28:
+            raise TypeError(f"KernelAlgorithm({aid}) takes 28 positional arguments, got {len(args)}")
+        res_re, res_im = args[14], args[15]  # phi_re, phi_im hold the reduced result
+        rest = args[16:]
+    elif aid in _FORM_C:
+        if len(args) != 26:
+            raise TypeError(f"KernelAlgorithm({aid}) takes 26 positional arguments, got {len(args)}")
+        res_re, res_im = args[12], args[13]
+        rest = args[14:]
+    else:
+        raise NotImplementedError(f"no kernel_algorithm method for id {aid} (the reference has none either)")
+    (_car_re, _car_im, _dw_re, _dw_im, signal_re, signal_im, shifts, carrier_frequency, carrier_phase,
+     num_ants, _num_corrs, _alg) = rest
+    table = _codes_of(codes)
+    if table.shape[1] != int(code_length):
+        raise ValueError("code_length does not match the code table")
+    ctx = get_context(signal_re.device)
+    ctx.set_codes(table)
+    M = _as_int(num_ants)
+    sh = np.ascontiguousarray(shifts, dtype=np.int32)
+    desc = _signal_desc(signal_re, signal_im, int(num_samples))
+    if desc.num_ants != M:
+        raise ValueError("num_ants does not match the signal")
+    prm = make_params(int(prn) - 1, code_frequency, carrier_frequency, start_code_phase, carrier_phase, shape=(1, 1))
+    out_re = torch.empty((sh.size, M), dtype=torch.float32, device=ctx.device)
+    out_im = torch.empty_like(out_re)
+    ctx.downconvert_and_correlate(desc, prm, 1, 1, sh, float(sampling_frequency), out_re, out_im,
+                                  algorithm_flags(algorithm))
+    _store(res_re, res_im, out_re, out_im)
+    return None
+
+
+def cpu_reduce_partial_sum(partial_re: torch.Tensor, partial_im: torch.Tensor):
+    """``cpu_reduce_partial_sum`` (src/algorithms.jl:1-5): copy the per-block partials to the
+    host and sum them there.  [..., blocks] -> complex64 numpy [...]."""
+    return (partial_re.cpu().numpy().sum(axis=-1) + 1j * partial_im.cpu().numpy().sum(axis=-1)).astype(np.complex64)
+
+
+def cuda_reduce_partial_sum(partial_re: torch.Tensor, partial_im: torch.Tensor):
+    """``cuda_reduce_partial_sum`` (src/algorithms.jl:7-11): device-side second stage; here the
+    HIP two-pass column sum of libgat (``gat_reduce_cplx_multi``)."""
+    from .tracking import reduce_cplx_multi
+    return reduce_cplx_multi(partial_re.contiguous(), partial_im.contiguous())

@@ -1,0 +1,165 @@
+"""Device context: one libgat ctx per (device, HIP stream).
+
+PyTorch is plumbing here: it owns device memory (tensors) and streams; every compute call goes
+through the C ABI with raw device pointers.  Mirrors the implicit CUDA.jl device/stream state of
+the reference (``CUDA.@sync`` at src/benchmarks.jl:120).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GatError
+
+
+def _ptr(t) -> int:
+    return 0 if t is None else int(t.data_ptr())
+
+
+class Context:
+    """Owns a ``gat_ctx``.  Not thread-safe (as the C ABI states); distinct contexts are."""
+
+    def __init__(self, device: int | torch.device | None = None, stream: torch.cuda.Stream | None = None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("gpuacceleratedtracking_amd needs a HIP device (no CPU fallback exists)")
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else (device.index or 0))
+        with torch.cuda.device(self.device):
+            self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._h = C.c_void_p()
+        rc = self.lib.gat_create(self.device.index, C.c_void_p(self.stream.cuda_stream), C.byref(self._h))
+        if rc != 0:
+            raise GatError(rc, "gat_create")
+        self._codes_key = None
+
+    # -- plumbing -----------------------------------------------------------------------
+    def check(self, rc: int, where: str):
+        if rc != 0:
+            msg = self.lib.gat_last_error(self._h)
+            raise GatError(rc, where, msg.decode() if msg else "")
+
+    def close(self):
+        if self._h:
+            self.lib.gat_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self.check(self.lib.gat_sync(self._h), "gat_sync")
+
+    def device_info(self) -> dict:
+        buf = C.create_string_buffer(256)
+        ver, cus = C.c_int32(), C.c_int32()
+        self.check(self.lib.gat_device_info(self._h, buf, 256, C.byref(ver), C.byref(cus)), "gat_device_info")
+        return {"name": buf.value.decode(), "hip_runtime": ver.value, "num_cus": cus.value}
+
+    def last_launch_info(self) -> dict:
+        info = _lib.LaunchInfo()
+        self.check(self.lib.gat_last_launch_info(self._h, C.byref(info)), "gat_last_launch_info")
+        return {n: getattr(info, n) for n, _ in info._fields_ if n != "reserved"}
+
+    def timer_start(self):
+        self.check(self.lib.gat_timer_start(self._h), "gat_timer_start")
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self.check(self.lib.gat_timer_stop(self._h, C.byref(ms)), "gat_timer_stop")
+        return float(ms.value)
+
+    # -- code tables --------------------------------------------------------------------
+    def set_codes(self, codes: np.ndarray):
+        """codes: int8 [num_prns, code_length] (C-order == reference's column-major [Lc x P])."""
+        codes = np.ascontiguousarray(codes, dtype=np.int8)
+        key = (codes.shape, hash(codes.tobytes()))
+        if key == self._codes_key:
+            return
+        p, lc = codes.shape
+        self.check(self.lib.gat_set_codes(self._h, codes.ctypes.data_as(C.POINTER(C.c_int8)), lc, p),
+                   "gat_set_codes")
+        self._codes_key = key
+
+    # -- operators ----------------------------------------------------------------------
+    def downconvert_and_correlate(self, desc: _lib.SignalDesc, params, num_blocks: int, num_channels: int,
+                                  shifts, sampling_frequency: float, out_re: torch.Tensor,
+                                  out_im: torch.Tensor, flags: int = 0):
+        """params: numpy structured array (host path) or a torch uint8/int tensor holding
+        gat_channel_params on the device (device path)."""
+        sh = np.ascontiguousarray(shifts, dtype=np.int32)
+        shp = sh.ctypes.data_as(C.POINTER(C.c_int32))
+        need = num_blocks * num_channels * sh.size * desc.num_ants
+        if out_re.numel() < need or out_im.numel() < need or out_re.dtype != torch.float32:
+            raise ValueError("output tensors too small or not float32")
+        if isinstance(params, torch.Tensor):
+            if params.numel() * params.element_size() < num_blocks * num_channels * 40:
+                raise ValueError("device params tensor too small")
+            rc = self.lib.gat_downconvert_and_correlate_dev(
+                self._h, C.byref(desc), C.c_void_p(_ptr(params)), num_blocks, num_channels, sh.size, shp,
+                float(sampling_frequency), C.c_void_p(_ptr(out_re)), C.c_void_p(_ptr(out_im)), flags)
+            self.check(rc, "gat_downconvert_and_correlate_dev")
+        else:
+            prm = np.ascontiguousarray(params, dtype=_lib.PARAMS_DTYPE)
+            if prm.size != num_blocks * num_channels:
+                raise ValueError("params must hold num_blocks * num_channels entries")
+            rc = self.lib.gat_downconvert_and_correlate(
+                self._h, C.byref(desc), prm.ctypes.data_as(C.POINTER(_lib.ChannelParams)), num_blocks,
+                num_channels, sh.size, shp, float(sampling_frequency), C.c_void_p(_ptr(out_re)),
+                C.c_void_p(_ptr(out_im)), flags)
+            self.check(rc, "gat_downconvert_and_correlate")
+
+    def gen_code_replica(self, out: torch.Tensor, count: int, prn: int, code_frequency: float,
+                         sampling_frequency: float, code_phase: float, first_shift: int):
+        if out.numel() < count or out.dtype != torch.float32:
+            raise ValueError("replica tensor too small or not float32")
+        rc = self.lib.gat_gen_code_replica(self._h, C.c_void_p(_ptr(out)), count, prn, float(code_frequency),
+                                           float(sampling_frequency), float(code_phase), int(first_shift))
+        self.check(rc, "gat_gen_code_replica")
+
+    def gen_signal(self, re: torch.Tensor, im: torch.Tensor | None, layout: int, num_samples: int,
+                   num_ants: int, ant_stride: int, block_stride: int, num_blocks: int, num_channels: int,
+                   params_dev: torch.Tensor, sampling_frequency: float):
+        rc = self.lib.gat_gen_signal(self._h, C.c_void_p(_ptr(re)), C.c_void_p(_ptr(im)), layout, num_samples,
+                                     num_ants, ant_stride, block_stride, num_blocks, num_channels,
+                                     C.c_void_p(_ptr(params_dev)), float(sampling_frequency))
+        self.check(rc, "gat_gen_signal")
+
+    def reduce_cplx_multi(self, in_re: torch.Tensor, in_im: torch.Tensor, n: int, cols: int,
+                          out_re: torch.Tensor, out_im: torch.Tensor):
+        rc = self.lib.gat_reduce_cplx_multi(self._h, C.c_void_p(_ptr(in_re)), C.c_void_p(_ptr(in_im)), n, cols,
+                                            C.c_void_p(_ptr(out_re)), C.c_void_p(_ptr(out_im)))
+        self.check(rc, "gat_reduce_cplx_multi")
+
+    def params_to_device(self, params: np.ndarray) -> torch.Tensor:
+        prm = np.ascontiguousarray(params, dtype=_lib.PARAMS_DTYPE)
+        return torch.from_numpy(prm.view(np.uint8).reshape(-1).copy()).to(self.device)
+
+
+_CONTEXTS: dict = {}
+
+
+def get_context(device=None) -> Context:
+    """Context for ``device`` bound to PyTorch's CURRENT stream on it (cached)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("gpuacceleratedtracking_amd needs a HIP device (no CPU fallback exists)")
+    if device is None:
+        idx = torch.cuda.current_device()
+    elif isinstance(device, int):
+        idx = device
+    else:
+        idx = torch.device(device).index or 0
+    stream = torch.cuda.current_stream(idx)
+    key = (idx, stream.cuda_stream)
+    ctx = _CONTEXTS.get(key)
+    if ctx is None:
+        ctx = Context(idx, stream)
+        _CONTEXTS[key] = ctx
+    return ctx

@@ -1,0 +1,487 @@
+// gat_api.cpp -- the C ABI declared in include/gat.h: context, validation, launch planning.
+//
+// Launch planning for the fused correlator (DESIGN.md "Kernels"):
+//   ant_tile MT = largest of {4,3,2,1} dividing M          (register accumulators 2*MT*L <= 64)
+//   vec      = 4 when every plane base/stride is 16-byte aligned, else 1
+//   splits   = workgroups per (block, channel, antenna tile): 1 once B*K*M/MT already fills the
+//              chip (>= 8 workgroups per CU), otherwise the block's samples are split and a
+//              finalize launch sums the per-split partials in fixed order.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "gat_internal.h"
+
+using namespace gat;
+
+struct gat_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int8_t *d_codes = nullptr;
+    int Lc = 0, P = 0;
+    float *d_partial = nullptr;
+    size_t partial_bytes = 0;
+    gat_channel_params *d_params = nullptr;
+    size_t params_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timer_running = false;
+    int num_cus = 256;
+    std::string err;
+    gat_launch_info last{};
+};
+
+namespace {
+
+int32_t fail(gat_ctx *c, int32_t code, const char *msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+int32_t hipfail(gat_ctx *c, hipError_t e, const char *where)
+{
+    if (c) {
+        c->err = std::string(where) + ": " + hipGetErrorString(e);
+    }
+    return -(int32_t)e;
+}
+
+#define GAT_HIP(c, call)                                      \
+    do {                                                      \
+        hipError_t e_ = (call);                               \
+        if (e_ != hipSuccess) return hipfail((c), e_, #call); \
+    } while (0)
+
+bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int32_t ensure_partial(gat_ctx *c, size_t bytes)
+{
+    if (bytes <= c->partial_bytes) return GAT_OK;
+    if (c->d_partial) {
+        GAT_HIP(c, hipStreamSynchronize(c->stream)); // previous launches may still read it
+        GAT_HIP(c, hipFree(c->d_partial));
+        c->d_partial = nullptr;
+        c->partial_bytes = 0;
+    }
+    GAT_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->d_partial), bytes));
+    c->partial_bytes = bytes;
+    return GAT_OK;
+}
+
+int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel_params *params_dev,
+                       int32_t B, int32_t K, int32_t L, const int32_t *shifts, double fs,
+                       float *out_re, float *out_im, uint32_t flags)
+{
+    if (!sig || !params_dev || !shifts || !out_re || !out_im) return fail(c, GAT_ERR_ARG, "null argument");
+    if (!c->d_codes) return fail(c, GAT_ERR_STATE, "gat_set_codes has not been called");
+    if (sig->layout != GAT_LAYOUT_PLANAR && sig->layout != GAT_LAYOUT_INTERLEAVED)
+        return fail(c, GAT_ERR_ARG, "unknown signal layout");
+    const bool il = sig->layout == GAT_LAYOUT_INTERLEAVED;
+    if (!sig->re || (!il && !sig->im) || (il && sig->im))
+        return fail(c, GAT_ERR_ARG, "signal pointers do not match the layout");
+    if (B < 1 || K < 1 || sig->num_ants < 1 || sig->num_samples < 1)
+        return fail(c, GAT_ERR_ARG, "sizes must be positive");
+    if (L < 1 || L > GAT_MAX_TAPS) return fail(c, GAT_ERR_RANGE, "num_taps outside 1..GAT_MAX_TAPS");
+    if (!(fs > 0.0) || !std::isfinite(fs)) return fail(c, GAT_ERR_ARG, "sampling frequency must be positive");
+    if (flags & ~GAT_FLAG_ATOMIC) return fail(c, GAT_ERR_ARG, "unknown flag bits");
+    long long max_shift = 0;
+    for (int l = 0; l < L; ++l) max_shift = std::max<long long>(max_shift, std::llabs((long long)shifts[l]));
+    if (sig->num_samples + max_shift >= (1ll << 30))
+        return fail(c, GAT_ERR_RANGE, "num_samples + |shift| must stay below 2^30");
+    if (sig->ant_stride < 0 || sig->block_stride < 0 || sig->chan_stride < 0)
+        return fail(c, GAT_ERR_ARG, "negative stride");
+
+    const int M = sig->num_ants;
+    int MT = 1;
+    for (int mt = kMaxAntTile; mt >= 1; --mt)
+        if (M % mt == 0) {
+            MT = mt;
+            break;
+        }
+    const int AT = M / MT;
+
+    int vec = 1;
+    if (!il) {
+        if (aligned16(sig->re) && aligned16(sig->im) && sig->ant_stride % 4 == 0 &&
+            sig->block_stride % 4 == 0 && sig->chan_stride % 4 == 0)
+            vec = 4;
+    } else {
+        if (aligned16(sig->re) && sig->ant_stride % 2 == 0 && sig->block_stride % 2 == 0 &&
+            sig->chan_stride % 2 == 0)
+            vec = 4;
+    }
+
+    const long long N = sig->num_samples;
+    const long long chunk = (long long)kThreads * vec;
+    const long long chunks = (N + chunk - 1) / chunk;
+    const long long groups = (long long)B * K * AT;
+    const long long target = 8ll * c->num_cus;
+    long long splits = std::max<long long>(1, (target + groups - 1) / groups);
+    splits = std::min(splits, chunks);
+    const long long cps = (chunks + splits - 1) / splits;
+    splits = (chunks + cps - 1) / cps;
+    if (groups * splits >= (1ll << 31)) return fail(c, GAT_ERR_RANGE, "grid too large");
+
+    const bool atomic = (flags & GAT_FLAG_ATOMIC) != 0;
+    const size_t out_elems = (size_t)B * K * L * M;
+    if (atomic) {
+        GAT_HIP(c, hipMemsetAsync(out_re, 0, out_elems * sizeof(float), c->stream));
+        GAT_HIP(c, hipMemsetAsync(out_im, 0, out_elems * sizeof(float), c->stream));
+    } else if (splits > 1) {
+        const int32_t rc = ensure_partial(c, (size_t)B * K * splits * L * M * 2 * sizeof(float));
+        if (rc != GAT_OK) return rc;
+    }
+
+    DcArgs a{};
+    a.re = sig->re;
+    a.im = sig->im;
+    a.params = params_dev;
+    a.codes = c->d_codes;
+    a.out_re = out_re;
+    a.out_im = out_im;
+    a.partial = c->d_partial;
+    a.N = N;
+    a.ant_stride = sig->ant_stride;
+    a.block_stride = sig->block_stride;
+    a.chan_stride = sig->chan_stride;
+    a.fs = fs;
+    a.M = M;
+    a.K = K;
+    a.B = B;
+    a.Lc = c->Lc;
+    a.num_prns = c->P;
+    a.splits = (int)splits;
+    a.chunks_per_split = (int)cps;
+    a.total_chunks = (int)chunks;
+    a.ant_tiles = AT;
+    a.Ltot = L;
+    a.flags = flags;
+
+    DcLaunch cfg{};
+    cfg.ant_tile = MT;
+    cfg.vec = vec;
+    cfg.interleaved = il ? 1 : 0;
+    cfg.grid = (unsigned)(groups * splits);
+    cfg.lds_bytes = (unsigned)(((c->Lc + 15) & ~15) + 4 * 64 * sizeof(float));
+
+    for (int t0 = 0; t0 < L; t0 += kMaxTapsPerLaunch) {
+        cfg.taps = std::min(kMaxTapsPerLaunch, L - t0);
+        a.tap_off = t0;
+        for (int l = 0; l < kMaxTapsPerLaunch; ++l) a.shifts[l] = l < cfg.taps ? shifts[t0 + l] : 0;
+        GAT_HIP(c, launch_dc(a, cfg, c->stream));
+    }
+    const bool fin = !atomic && splits > 1;
+    if (fin)
+        GAT_HIP(c, launch_finalize(c->d_partial, out_re, out_im, (int)splits, L * M * 2, (long long)B * K,
+                                   c->stream));
+
+    c->last.workgroups = (int32_t)cfg.grid;
+    c->last.threads = kThreads;
+    c->last.splits = (int32_t)splits;
+    c->last.ant_tile = MT;
+    c->last.vec = vec;
+    c->last.lds_bytes = (int32_t)cfg.lds_bytes;
+    c->last.finalize_launched = fin ? 1 : 0;
+    return GAT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+GAT_API const char *gat_version(void) { return "libgat 0.1.0 (gfx950)"; }
+
+GAT_API int32_t gat_create(int32_t device, void *hip_stream, gat_ctx **out_ctx)
+{
+    if (!out_ctx) return GAT_ERR_ARG;
+    *out_ctx = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess) return -(int32_t)e;
+    if (device < 0 || device >= ndev) return GAT_ERR_RANGE;
+    gat_ctx *c = new (std::nothrow) gat_ctx();
+    if (!c) return GAT_ERR_NOMEM;
+    c->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        delete c;
+        return -(int32_t)e;
+    }
+    if (hip_stream != GAT_OWN_STREAM) {
+        c->stream = reinterpret_cast<hipStream_t>(hip_stream); // NULL == the default stream
+    } else {
+        if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+            delete c;
+            return -(int32_t)e;
+        }
+        c->own_stream = true;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        delete c;
+        return -(int32_t)e;
+    }
+    *out_ctx = c;
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_destroy(gat_ctx *c)
+{
+    if (!c) return GAT_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->d_codes) (void)hipFree(c->d_codes);
+    if (c->d_partial) (void)hipFree(c->d_partial);
+    if (c->d_params) (void)hipFree(c->d_params);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_set_stream(gat_ctx *c, void *hip_stream)
+{
+    if (!c) return GAT_ERR_ARG;
+    GAT_HIP(c, hipSetDevice(c->device));
+    GAT_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream) {
+        GAT_HIP(c, hipStreamDestroy(c->stream));
+        c->own_stream = false;
+    }
+    if (hip_stream != GAT_OWN_STREAM) {
+        c->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    } else {
+        GAT_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_sync(gat_ctx *c)
+{
+    if (!c) return GAT_ERR_ARG;
+    GAT_HIP(c, hipSetDevice(c->device));
+    GAT_HIP(c, hipStreamSynchronize(c->stream));
+    return GAT_OK;
+}
+
+GAT_API const char *gat_last_error(const gat_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+GAT_API int32_t gat_device_info(gat_ctx *c, char *name_buf, size_t name_len, int32_t *runtime_version,
+                                int32_t *num_cus)
+{
+    if (!c) return GAT_ERR_ARG;
+    hipDeviceProp_t prop;
+    GAT_HIP(c, hipGetDeviceProperties(&prop, c->device));
+    if (name_buf && name_len) {
+        std::snprintf(name_buf, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (runtime_version) {
+        int v = 0;
+        GAT_HIP(c, hipRuntimeGetVersion(&v));
+        *runtime_version = v;
+    }
+    if (num_cus) *num_cus = prop.multiProcessorCount;
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_set_codes(gat_ctx *c, const int8_t *codes_host, int32_t code_length, int32_t num_prns)
+{
+    if (!c || !codes_host) return fail(c, GAT_ERR_ARG, "null argument");
+    if (code_length < 1 || num_prns < 1) return fail(c, GAT_ERR_ARG, "sizes must be positive");
+    if (code_length > 150000) return fail(c, GAT_ERR_RANGE, "code table does not fit in LDS (max 150000 chips)");
+    GAT_HIP(c, hipSetDevice(c->device));
+    GAT_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->d_codes) {
+        GAT_HIP(c, hipFree(c->d_codes));
+        c->d_codes = nullptr;
+    }
+    const size_t bytes = (size_t)code_length * num_prns;
+    GAT_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->d_codes), bytes));
+    GAT_HIP(c, hipMemcpy(c->d_codes, codes_host, bytes, hipMemcpyHostToDevice));
+    c->Lc = code_length;
+    c->P = num_prns;
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_sample_shifts(int32_t L, double fs, double fc, double spacing, int32_t *shifts)
+{
+    if (!shifts || L < 1 || !(fs > 0.0) || !(fc > 0.0)) return GAT_ERR_ARG;
+    long long s = (long long)std::nearbyint(spacing * fs / fc); // round-half-even like Julia round(Int, x)
+    if (s < 1) s = 1;
+    for (int l = 0; l < L; ++l) shifts[l] = (int32_t)((l - L / 2) * s);
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_downconvert_and_correlate_dev(gat_ctx *c, const gat_signal_desc *sig,
+                                                  const gat_channel_params *params_dev, int32_t B,
+                                                  int32_t K, int32_t L, const int32_t *shifts, double fs,
+                                                  float *out_re, float *out_im, uint32_t flags)
+{
+    if (!c) return GAT_ERR_ARG;
+    GAT_HIP(c, hipSetDevice(c->device));
+    return correlate_impl(c, sig, params_dev, B, K, L, shifts, fs, out_re, out_im, flags);
+}
+
+GAT_API int32_t gat_downconvert_and_correlate(gat_ctx *c, const gat_signal_desc *sig,
+                                              const gat_channel_params *params_host, int32_t B, int32_t K,
+                                              int32_t L, const int32_t *shifts, double fs, float *out_re,
+                                              float *out_im, uint32_t flags)
+{
+    if (!c) return GAT_ERR_ARG;
+    if (!params_host || !sig || !shifts) return fail(c, GAT_ERR_ARG, "null argument");
+    if (B < 1 || K < 1) return fail(c, GAT_ERR_ARG, "sizes must be positive");
+    GAT_HIP(c, hipSetDevice(c->device));
+    // host-side validation the device-params variant cannot do
+    long long max_shift = 0;
+    for (int l = 0; l < L && l < GAT_MAX_TAPS; ++l)
+        max_shift = std::max<long long>(max_shift, std::llabs((long long)shifts[l]));
+    const size_t n = (size_t)B * K;
+    for (size_t i = 0; i < n; ++i) {
+        const gat_channel_params &p = params_host[i];
+        if (p.prn < 0 || p.prn >= c->P) return fail(c, GAT_ERR_RANGE, "prn outside the code table");
+        if (!std::isfinite(p.code_freq_hz) || !std::isfinite(p.carrier_freq_hz) ||
+            !std::isfinite(p.code_phase_chips) || !std::isfinite(p.carrier_phase_cycles))
+            return fail(c, GAT_ERR_ARG, "non-finite channel parameter");
+        const double span = std::fabs(p.code_phase_chips) +
+                            std::fabs(p.code_freq_hz / fs) * (double)(sig->num_samples + max_shift) + 1.0;
+        if (span >= 1073741824.0 || (c->Lc > 0 && span / c->Lc >= 2097152.0))
+            return fail(c, GAT_ERR_RANGE, "code phase span too large");
+    }
+    if (n > c->params_cap) {
+        if (c->d_params) {
+            GAT_HIP(c, hipStreamSynchronize(c->stream));
+            GAT_HIP(c, hipFree(c->d_params));
+            c->d_params = nullptr;
+            c->params_cap = 0;
+        }
+        GAT_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->d_params), n * sizeof(gat_channel_params)));
+        c->params_cap = n;
+    }
+    GAT_HIP(c, hipMemcpyAsync(c->d_params, params_host, n * sizeof(gat_channel_params),
+                              hipMemcpyHostToDevice, c->stream));
+    return correlate_impl(c, sig, c->d_params, B, K, L, shifts, fs, out_re, out_im, flags);
+}
+
+GAT_API int32_t gat_gen_code_replica(gat_ctx *c, float *rep, int64_t count, int32_t prn, double fc,
+                                     double fs, double tau, int64_t first_shift)
+{
+    if (!c || !rep) return fail(c, GAT_ERR_ARG, "null argument");
+    if (!c->d_codes) return fail(c, GAT_ERR_STATE, "gat_set_codes has not been called");
+    if (count < 1) return fail(c, GAT_ERR_ARG, "count must be positive");
+    if (prn < 0 || prn >= c->P) return fail(c, GAT_ERR_RANGE, "prn outside the code table");
+    if (!(fs > 0.0) || !std::isfinite(fc) || !std::isfinite(tau)) return fail(c, GAT_ERR_ARG, "bad frequency / phase");
+    if (count + std::llabs((long long)first_shift) >= (1ll << 30)) return fail(c, GAT_ERR_RANGE, "replica too long");
+    GAT_HIP(c, hipSetDevice(c->device));
+    GAT_HIP(c, launch_gen_code_replica(rep, count, c->d_codes + (size_t)prn * c->Lc, c->Lc, fc, fs, tau,
+                                       first_shift, c->stream));
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_gen_signal(gat_ctx *c, float *re, float *im, int32_t layout, int64_t N, int32_t M,
+                               int64_t ant_stride, int64_t block_stride, int32_t B, int32_t K,
+                               const gat_channel_params *params_dev, double fs)
+{
+    if (!c || !re || !params_dev) return fail(c, GAT_ERR_ARG, "null argument");
+    if (!c->d_codes) return fail(c, GAT_ERR_STATE, "gat_set_codes has not been called");
+    if (layout != GAT_LAYOUT_PLANAR && layout != GAT_LAYOUT_INTERLEAVED) return fail(c, GAT_ERR_ARG, "unknown layout");
+    if ((layout == GAT_LAYOUT_PLANAR) != (im != nullptr)) return fail(c, GAT_ERR_ARG, "signal pointers do not match the layout");
+    if (N < 1 || N >= (1ll << 30) || M < 1 || B < 1 || B > 65535 || K < 1) return fail(c, GAT_ERR_RANGE, "size out of range");
+    if (!(fs > 0.0)) return fail(c, GAT_ERR_ARG, "sampling frequency must be positive");
+    GAT_HIP(c, hipSetDevice(c->device));
+    GAT_HIP(c, launch_gen_signal(re, im, layout == GAT_LAYOUT_INTERLEAVED, N, M, ant_stride, block_stride, B, K,
+                                 params_dev, c->d_codes, c->Lc, c->P, fs, c->stream));
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_reduce_cplx_multi(gat_ctx *c, const float *in_re, const float *in_im, int64_t n,
+                                      int32_t cols, float *out_re, float *out_im)
+{
+    if (!c || !in_re || !in_im || !out_re || !out_im) return fail(c, GAT_ERR_ARG, "null argument");
+    if (n < 1 || cols < 1 || cols > 65535) return fail(c, GAT_ERR_ARG, "sizes must be positive");
+    GAT_HIP(c, hipSetDevice(c->device));
+    long long chunks = (n + 4 * kThreads - 1) / (4 * kThreads);
+    const long long want = std::max<long long>(1, (4ll * c->num_cus + cols - 1) / cols);
+    chunks = std::max<long long>(1, std::min(chunks, want));
+    const int32_t rc = ensure_partial(c, (size_t)chunks * cols * 2 * sizeof(float));
+    if (rc != GAT_OK) return rc;
+    GAT_HIP(c, launch_reduce_stage1(in_re, in_im, n, cols, (int)chunks, c->d_partial, c->stream));
+    GAT_HIP(c, launch_finalize(c->d_partial, out_re, out_im, (int)chunks, cols * 2, 1, c->stream));
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_malloc(gat_ctx *c, size_t bytes, void **out)
+{
+    if (!c || !out || bytes == 0) return fail(c, GAT_ERR_ARG, "bad argument");
+    GAT_HIP(c, hipSetDevice(c->device));
+    GAT_HIP(c, hipMalloc(out, bytes));
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_free(gat_ctx *c, void *p)
+{
+    if (!c) return GAT_ERR_ARG;
+    GAT_HIP(c, hipSetDevice(c->device));
+    GAT_HIP(c, hipFree(p));
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_memcpy_h2d(gat_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c || !dst || !src) return fail(c, GAT_ERR_ARG, "null argument");
+    GAT_HIP(c, hipSetDevice(c->device));
+    GAT_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    GAT_HIP(c, hipStreamSynchronize(c->stream));
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_memcpy_d2h(gat_ctx *c, void *dst, const void *src, size_t bytes)
+{
+    if (!c || !dst || !src) return fail(c, GAT_ERR_ARG, "null argument");
+    GAT_HIP(c, hipSetDevice(c->device));
+    GAT_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    GAT_HIP(c, hipStreamSynchronize(c->stream));
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_memset(gat_ctx *c, void *dst, int32_t value, size_t bytes)
+{
+    if (!c || !dst) return fail(c, GAT_ERR_ARG, "null argument");
+    GAT_HIP(c, hipSetDevice(c->device));
+    GAT_HIP(c, hipMemsetAsync(dst, value, bytes, c->stream));
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_timer_start(gat_ctx *c)
+{
+    if (!c) return GAT_ERR_ARG;
+    GAT_HIP(c, hipSetDevice(c->device));
+    GAT_HIP(c, hipEventRecord(c->ev0, c->stream));
+    c->timer_running = true;
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_timer_stop(gat_ctx *c, float *ms)
+{
+    if (!c || !ms) return fail(c, GAT_ERR_ARG, "null argument");
+    if (!c->timer_running) return fail(c, GAT_ERR_STATE, "timer not started");
+    GAT_HIP(c, hipSetDevice(c->device));
+    GAT_HIP(c, hipEventRecord(c->ev1, c->stream));
+    GAT_HIP(c, hipEventSynchronize(c->ev1));
+    GAT_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    c->timer_running = false;
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_last_launch_info(const gat_ctx *c, gat_launch_info *out)
+{
+    if (!c || !out) return GAT_ERR_ARG;
+    *out = c->last;
+    return GAT_OK;
+}
+
+} // extern "C"

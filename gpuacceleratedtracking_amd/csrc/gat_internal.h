@@ -1,0 +1,57 @@
+// gat_internal.h -- shared between the C-ABI layer (gat_api.cpp) and the kernels (gat_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gat.h"
+
+namespace gat {
+
+constexpr int kThreads = 256;       // 4 wave64 per workgroup
+constexpr int kMaxTapsPerLaunch = 8; // taps handled by one launch (register accumulators)
+constexpr int kMaxAntTile = 4;       // antennas handled by one workgroup
+
+// Arguments of the fused correlator kernel (passed by value in the kernarg segment).
+struct DcArgs {
+    const float *re;
+    const float *im;
+    const gat_channel_params *params; // dev, [B*K], channel fastest
+    const int8_t *codes;              // dev, [P][Lc]
+    float *out_re;                    // dev, [B][K][Ltot][M]
+    float *out_im;
+    float *partial;                   // dev, [B*K][splits][Ltot*M*2] (splits > 1 only)
+    long long N, ant_stride, block_stride, chan_stride;
+    double fs;
+    int M, K, B, Lc, num_prns;
+    int splits, chunks_per_split, total_chunks, ant_tiles;
+    int Ltot, tap_off;
+    unsigned flags;
+    int shifts[kMaxTapsPerLaunch];
+};
+
+struct DcLaunch {
+    int ant_tile; // MT
+    int taps;     // L of this launch
+    int vec;      // 4 or 1
+    int interleaved;
+    unsigned grid;
+    unsigned lds_bytes;
+};
+
+// Launchers implemented in gat_kernels.hip.  All return hipError_t of the launch.
+hipError_t launch_dc(const DcArgs &a, const DcLaunch &cfg, hipStream_t s);
+hipError_t launch_finalize(const float *partial, float *out_re, float *out_im, int splits, int elems,
+                           long long groups, hipStream_t s);
+hipError_t launch_gen_code_replica(float *rep, long long count, const int8_t *code_row, int Lc,
+                                   double fc, double fs, double tau, long long first_shift,
+                                   hipStream_t s);
+hipError_t launch_gen_signal(float *re, float *im, int interleaved, long long N, int M,
+                             long long ant_stride, long long block_stride, int B, int K,
+                             const gat_channel_params *params, const int8_t *codes, int Lc,
+                             int num_prns, double fs, hipStream_t s);
+hipError_t launch_reduce_stage1(const float *in_re, const float *in_im, long long n, int cols,
+                                int chunks, float *partial, hipStream_t s);
+bool dc_supported(int ant_tile, int taps);
+
+} // namespace gat

@@ -1,0 +1,488 @@
+// gat_kernels.hip -- gfx950 (MI355X, wave64) kernels of the downconvert + correlate path.
+//
+// What is computed (reference: downconvert_and_correlate_kernel_1330!, src/algorithms.jl:170-187;
+// replica convention of kernel 5431, src/algorithms.jl:752-758; equation paper/paper.tex:48-52):
+//
+//   R[m,l,k,b] = sum_n x[n,m,b] * conj(exp(j2pi(n*f/fs + phi))) * c_k[floor(fc/fs*(n+shift_l)+tau) mod Lc]
+//
+// How (CDNA4-first, not the reference's shared-memory tree per sample):
+//   * one workgroup (4 waves) streams a contiguous run of one integration block; every lane
+//     owns VEC consecutive samples per step and loads them as 16-byte vectors per antenna
+//     plane (planar) or 2 x 16 B (interleaved ComplexF32) -- 1 KiB per wave-instruction;
+//   * the +-1 chip table of the workgroup's PRN lives in LDS as int8 (1 KB for C/A, 10 KB L5);
+//   * carrier: one double-precision phase anchor per lane and step, reduced to an octant in
+//     double, float polynomial sincos, then VEC-1 complex rotations -- no per-(antenna,tap)
+//     redundant FP64 sincos as in the reference (src/algorithms.jl:172);
+//   * code phase: the reference's exact double-precision expression, unfused (this file is
+//     built with -ffp-contract=off) so chip edges fall on the same sample as on the CPU;
+//   * MT x L complex accumulators stay in registers for the whole run; ONE reduction per
+//     workgroup: a butterfly that halves the value count at each of the 6 wave64 shuffle
+//     steps (2*MT*L -> 1 value per lane), then 4 waves through LDS;
+//   * the result is written once (deterministic).  When a block is split over several
+//     workgroups (small batch), per-split partials are summed by finalize_kernel in fixed
+//     order; GAT_FLAG_ATOMIC uses float atomics instead (reference alg. 4/5).
+#include "gat_internal.h"
+
+namespace gat {
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+
+// exp(j*2*pi*theta) for theta in cycles (double).  Octant reduction in double (exact), float
+// Taylor polynomials on |a| <= pi/4 (|err| < 3e-8), quadrant fix-up.
+__device__ __forceinline__ void sincos_cycles(double theta, float &c, float &s)
+{
+    const double q = __builtin_rint(theta * 4.0);
+    const double r = __builtin_fma(q, -0.25, theta); // exact: |r| <= 0.125 cycles
+    const float a = (float)r * 6.283185307179586f;
+    const float a2 = a * a;
+    float sp = __builtin_fmaf(a2, 2.7557319e-6f, -1.9841270e-4f);
+    sp = __builtin_fmaf(a2, sp, 8.3333333e-3f);
+    sp = __builtin_fmaf(a2, sp, -1.6666667e-1f);
+    sp = __builtin_fmaf(a2 * a, sp, a);
+    float cp = __builtin_fmaf(a2, 2.4801587e-5f, -1.3888889e-3f);
+    cp = __builtin_fmaf(a2, cp, 4.1666667e-2f);
+    cp = __builtin_fmaf(a2, cp, -0.5f);
+    cp = __builtin_fmaf(a2, cp, 1.0f);
+    const int qi = (int)(long long)q & 3;
+    const float cs = (qi & 1) ? sp : cp;
+    const float sn = (qi & 1) ? cp : sp;
+    c = (qi == 1 || qi == 2) ? -cs : cs;
+    s = (qi >= 2) ? -sn : sn;
+}
+
+// floor(p) mod Lc with floored (Julia) semantics; valid for |ip| / Lc < 2^21 (host-checked).
+__device__ __forceinline__ int floormod_fast(int ip, int Lc, float inv_lc)
+{
+    const float q = __builtin_floorf((float)ip * inv_lc);
+    int r = ip - (int)q * Lc;
+    r += (r < 0) ? Lc : 0;
+    r -= (r >= Lc) ? Lc : 0;
+    if ((unsigned)r >= (unsigned)Lc) { // estimate off by more than one: huge |ip| (never on checked inputs)
+        r = ip % Lc;
+        r += (r < 0) ? Lc : 0;
+    }
+    return r;
+}
+
+// chip index of sample x = n + shift: the reference's expression, src/algorithms.jl:179-182.
+// One double multiply and one double add, NOT fused (bit-identical to the CPU oracle).
+__device__ __forceinline__ int chip_index(double ratio, double tau, int x, int Lc, float inv_lc)
+{
+    const double p = __dadd_rn(__dmul_rn(ratio, (double)x), tau);
+    const int ip = (int)__builtin_floor(p);
+    return floormod_fast(ip, Lc, inv_lc);
+}
+
+// Butterfly reduce-scatter over one wave64: NV per-lane values -> after 6 steps each lane
+// holds the full wave sum of ONE value (id[0]); 25 shuffles for NV = 24 instead of 144.
+template <int NV, int OFF>
+struct Butterfly {
+    static __device__ __forceinline__ void run(float *v, int *id, int lane)
+    {
+        constexpr int H = NV / 2;
+        const bool up = (lane & OFF) != 0;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            // load both operands unconditionally: a ternary on the array elements themselves is
+            // turned into a dynamically indexed (scratch) access by the compiler
+            const float lo = v[2 * i], hi = v[2 * i + 1];
+            const int ilo = id[2 * i], ihi = id[2 * i + 1];
+            const float keep = up ? hi : lo;
+            const float send = up ? lo : hi;
+            const float recv = __shfl_xor(send, OFF, 64);
+            v[i] = keep + recv;
+            id[i] = up ? ihi : ilo;
+        }
+        if constexpr (NV & 1) {
+            v[H] = v[NV - 1] + __shfl_xor(v[NV - 1], OFF, 64);
+            id[H] = id[NV - 1];
+        }
+        Butterfly<(NV + 1) / 2, OFF / 2>::run(v, id, lane);
+    }
+};
+template <int NV>
+struct Butterfly<NV, 0> {
+    static __device__ __forceinline__ void run(float *, int *, int) {}
+};
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// fused downconvert + correlate
+// ------------------------------------------------------------------------------------------
+template <int MT, int L, int VEC, bool IL>
+__global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int8_t *s_code = reinterpret_cast<int8_t *>(smem);
+    float *s_part = reinterpret_cast<float *>(smem + ((a.Lc + 15) & ~15)); // [4][64]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    unsigned wg = blockIdx.x;
+    const int split = wg % a.splits;
+    wg /= a.splits;
+    const int at = wg % a.ant_tiles;
+    wg /= a.ant_tiles;
+    const int k = wg % a.K;
+    const int b = wg / a.K;
+
+    const gat_channel_params P = a.params[(size_t)b * a.K + k];
+    const bool bad_prn = P.prn < 0 || P.prn >= a.num_prns;
+    const int prn = bad_prn ? 0 : P.prn;
+    const int Lc = a.Lc;
+
+    {
+        const int8_t *g = a.codes + (size_t)prn * Lc;
+        for (int i = tid; i < Lc; i += kThreads) s_code[i] = g[i];
+    }
+    __syncthreads();
+
+    const double ratio = P.code_freq_hz / a.fs;    // src/algorithms.jl:179 (Float64 division)
+    const double step = P.carrier_freq_hz / a.fs;  // cycles per sample
+    const double tau = P.code_phase_chips;
+    const double phi = P.carrier_phase_cycles;
+    const float inv_lc = 1.0f / (float)Lc;
+
+    float wr, wi; // one-sample rotation exp(+j*2*pi*step)
+    sincos_cycles(step - __builtin_rint(step), wr, wi);
+
+    float acc_re[MT][L], acc_im[MT][L];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int l = 0; l < L; ++l) acc_re[m][l] = acc_im[m][l] = 0.f;
+
+    const int N = (int)a.N;
+    const size_t base = (size_t)b * a.block_stride + (size_t)k * a.chan_stride +
+                        (size_t)(at * MT) * a.ant_stride;
+    constexpr int CHUNK = kThreads * VEC;
+    const int c_begin = split * a.chunks_per_split;
+    const int c_end = min(c_begin + a.chunks_per_split, a.total_chunks);
+
+    // one sample: carrier (cr, ci), chips for the L taps, MT antennas
+    auto accumulate = [&](const float (&xr)[MT], const float (&xi)[MT], float cr, float ci, int n) {
+        float chip[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l)
+            chip[l] = (float)s_code[chip_index(ratio, tau, n + a.shifts[l], Lc, inv_lc)];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            // conj(carrier) wipe-off, src/algorithms.jl:175-176
+            const float dr = __builtin_fmaf(xr[m], cr, xi[m] * ci);
+            const float di = __builtin_fmaf(xi[m], cr, -(xr[m] * ci));
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                acc_re[m][l] = __builtin_fmaf(chip[l], dr, acc_re[m][l]);
+                acc_im[m][l] = __builtin_fmaf(chip[l], di, acc_im[m][l]);
+            }
+        }
+    };
+
+    for (int c = c_begin; c < c_end; ++c) {
+        const int n0 = c * CHUNK + tid * VEC;
+        if (n0 + VEC <= N) {
+            float xr[VEC][MT], xi[VEC][MT];
+            if constexpr (VEC == 4 && !IL) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float4 vr = *reinterpret_cast<const float4 *>(a.re + base + (size_t)m * a.ant_stride + n0);
+                    const float4 vi = *reinterpret_cast<const float4 *>(a.im + base + (size_t)m * a.ant_stride + n0);
+                    xr[0][m] = vr.x; xr[1][m] = vr.y; xr[2][m] = vr.z; xr[3][m] = vr.w;
+                    xi[0][m] = vi.x; xi[1][m] = vi.y; xi[2][m] = vi.z; xi[3][m] = vi.w;
+                }
+            } else if constexpr (VEC == 4 && IL) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const float4 *p = reinterpret_cast<const float4 *>(a.re + 2 * (base + (size_t)m * a.ant_stride + n0));
+                    const float4 v0 = p[0], v1 = p[1];
+                    xr[0][m] = v0.x; xi[0][m] = v0.y; xr[1][m] = v0.z; xi[1][m] = v0.w;
+                    xr[2][m] = v1.x; xi[2][m] = v1.y; xr[3][m] = v1.z; xi[3][m] = v1.w;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const size_t e = base + (size_t)m * a.ant_stride + n0 + j;
+                        xr[j][m] = IL ? a.re[2 * e] : a.re[e];
+                        xi[j][m] = IL ? a.re[2 * e + 1] : a.im[e];
+                    }
+            }
+            float cr, ci;
+            const double th0 = __builtin_fma((double)n0, step, phi);
+            sincos_cycles(th0 - __builtin_rint(th0), cr, ci);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                accumulate(xr[j], xi[j], cr, ci, n0 + j);
+                if (j + 1 < VEC) {
+                    const float t = __builtin_fmaf(cr, wr, -(ci * wi));
+                    ci = __builtin_fmaf(cr, wi, ci * wr);
+                    cr = t;
+                }
+            }
+        } else if (VEC > 1 && n0 < N) {
+            // ragged end of the block: at most one lane, at most VEC-1 samples
+            for (int n = n0; n < N; ++n) {
+                float xr[MT], xi[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const size_t e = base + (size_t)m * a.ant_stride + n;
+                    xr[m] = IL ? a.re[2 * e] : a.re[e];
+                    xi[m] = IL ? a.re[2 * e + 1] : a.im[e];
+                }
+                const double th = __builtin_fma((double)n, step, phi);
+                float cr, ci;
+                sincos_cycles(th - __builtin_rint(th), cr, ci);
+                accumulate(xr, xi, cr, ci, n);
+            }
+        }
+    }
+
+    // ---- workgroup reduction: 2*MT*L values, id = (l*MT + m)*2 + {0: re, 1: im} ----------
+    constexpr int NV = 2 * MT * L;
+    static_assert(NV <= 64, "one value per lane after the butterfly");
+    float v[NV];
+    int id[NV];
+#pragma unroll
+    for (int l = 0; l < L; ++l)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            v[(l * MT + m) * 2 + 0] = acc_re[m][l];
+            v[(l * MT + m) * 2 + 1] = acc_im[m][l];
+        }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) id[i] = i;
+    Butterfly<NV, 32>::run(v, id, lane);
+    s_part[wave * 64 + id[0]] = v[0]; // lanes sharing an id hold bit-identical sums
+    __syncthreads();
+
+    if (tid < NV) {
+        float tot = (s_part[tid] + s_part[64 + tid]) + (s_part[128 + tid] + s_part[192 + tid]);
+        if (bad_prn) tot = __builtin_nanf("");
+        const int comp = tid & 1;
+        const int ml = tid >> 1;
+        const int m = at * MT + (ml % MT);
+        const int l = a.tap_off + ml / MT;
+        const size_t bk = (size_t)b * a.K + k;
+        const size_t o = (bk * a.Ltot + l) * a.M + m;
+        if (a.flags & GAT_FLAG_ATOMIC) {
+            atomicAdd((comp ? a.out_im : a.out_re) + o, tot);
+        } else if (a.splits == 1) {
+            (comp ? a.out_im : a.out_re)[o] = tot;
+        } else {
+            const size_t elems = (size_t)a.Ltot * a.M * 2;
+            a.partial[(bk * a.splits + split) * elems + ((size_t)l * a.M + m) * 2 + comp] = tot;
+        }
+    }
+}
+
+// second stage: fixed-order sum of the per-split partials (deterministic).
+// partial [groups][splits][elems], elems = cols*2 with re/im interleaved innermost.
+__global__ void __launch_bounds__(kThreads)
+finalize_kernel(const float *__restrict__ partial, float *__restrict__ out_re,
+                float *__restrict__ out_im, int splits, int elems, long long groups)
+{
+    const long long gid = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (gid >= groups * elems) return;
+    const long long g = gid / elems;
+    const int e = (int)(gid - g * elems);
+    const float *p = partial + (size_t)g * splits * elems + e;
+    float s = 0.f;
+    for (int i = 0; i < splits; ++i) s += p[(size_t)i * elems];
+    float *o = (e & 1) ? out_im : out_re;
+    o[(size_t)g * (elems / 2) + (e >> 1)] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// stand-alone operators
+// ------------------------------------------------------------------------------------------
+
+// gen_code_replica_kernel! (src/algorithms.jl:13-32), grid-stride as _strided_ (:34-54).
+__global__ void __launch_bounds__(kThreads)
+code_replica_kernel(float *__restrict__ rep, long long count, const int8_t *__restrict__ code,
+                    int Lc, double fc, double fs, double tau, long long first_shift)
+{
+    const double ratio = fc / fs;
+    const float inv_lc = 1.0f / (float)Lc;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < count;
+         i += (long long)gridDim.x * kThreads)
+        rep[i] = (float)code[chip_index(ratio, tau, (int)(i + first_shift), Lc, inv_lc)];
+}
+
+// gen_signal! (src/gen_signal.jl:64-70, :86-90): Float64 code phase, carrier phase evaluated in
+// Float64 then rounded to Float32 BEFORE cos/sin (src/gen_signal.jl:88), identical antennas.
+__global__ void __launch_bounds__(kThreads)
+gen_signal_kernel(float *__restrict__ re, float *__restrict__ im, int interleaved, long long N,
+                  int M, long long ant_stride, long long block_stride, int K,
+                  const gat_channel_params *__restrict__ params, const int8_t *__restrict__ codes,
+                  int Lc, int num_prns, double fs)
+{
+    const int b = blockIdx.y;
+    const float inv_lc = 1.0f / (float)Lc;
+    for (long long n = (long long)blockIdx.x * kThreads + threadIdx.x; n < N;
+         n += (long long)gridDim.x * kThreads) {
+        float sr = 0.f, si = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const gat_channel_params P = params[(size_t)b * K + k];
+            const int prn = (P.prn < 0 || P.prn >= num_prns) ? 0 : P.prn;
+            const double ratio = P.code_freq_hz / fs;
+            const float chip = (float)codes[(size_t)prn * Lc +
+                                            chip_index(ratio, P.code_phase_chips, (int)n, Lc, inv_lc)];
+            // 2pi * n * f / fs + phase, left to right as the reference broadcasts it
+            const double ph64 = __dadd_rn(__ddiv_rn(__dmul_rn(__dmul_rn(6.283185307179586, (double)n), P.carrier_freq_hz), fs),
+                                          P.carrier_phase_cycles /* radians here, see gat.h */);
+            const float ph = (float)ph64;
+            sr = __builtin_fmaf(cosf(ph), chip, sr);
+            si = __builtin_fmaf(sinf(ph), chip, si);
+        }
+        for (int m = 0; m < M; ++m) {
+            const size_t e = (size_t)b * block_stride + (size_t)m * ant_stride + n;
+            if (interleaved) {
+                re[2 * e] = sr;
+                re[2 * e + 1] = si;
+            } else {
+                re[e] = sr;
+                im[e] = si;
+            }
+        }
+    }
+}
+
+// reduce_cplx_multi first pass (src/reduction.jl:331-403): per (chunk, column) partial sums.
+// partial layout [chunks][cols*2] so that finalize_kernel produces the column sums.
+__global__ void __launch_bounds__(kThreads)
+reduce_stage1_kernel(const float *__restrict__ in_re, const float *__restrict__ in_im, long long n,
+                     int cols, int chunks, float *__restrict__ partial)
+{
+    __shared__ float s[2][4];
+    const int col = blockIdx.y;
+    const int chunk = blockIdx.x;
+    const long long per = (n + chunks - 1) / chunks;
+    const long long lo = (long long)chunk * per;
+    const long long hi = min(lo + per, n);
+    const float *pr = in_re + (size_t)col * n;
+    const float *pi = in_im + (size_t)col * n;
+    float ar = 0.f, ai = 0.f;
+    for (long long i = lo + threadIdx.x; i < hi; i += kThreads) {
+        ar += pr[i];
+        ai += pi[i];
+    }
+    ar = wave_sum(ar);
+    ai = wave_sum(ai);
+    if ((threadIdx.x & 63) == 0) {
+        s[0][threadIdx.x >> 6] = ar;
+        s[1][threadIdx.x >> 6] = ai;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const float t = (s[threadIdx.x][0] + s[threadIdx.x][1]) + (s[threadIdx.x][2] + s[threadIdx.x][3]);
+        partial[(size_t)chunk * cols * 2 + (size_t)col * 2 + threadIdx.x] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------
+template <int MT, int L>
+static hipError_t launch_dc_ml(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
+{
+    const dim3 grid(cfg.grid), block(kThreads);
+    if (cfg.vec == 4) {
+        if (cfg.interleaved)
+            hipLaunchKernelGGL((dc_kernel<MT, L, 4, true>), grid, block, cfg.lds_bytes, s, a);
+        else
+            hipLaunchKernelGGL((dc_kernel<MT, L, 4, false>), grid, block, cfg.lds_bytes, s, a);
+    } else {
+        if (cfg.interleaved)
+            hipLaunchKernelGGL((dc_kernel<MT, L, 1, true>), grid, block, cfg.lds_bytes, s, a);
+        else
+            hipLaunchKernelGGL((dc_kernel<MT, L, 1, false>), grid, block, cfg.lds_bytes, s, a);
+    }
+    return hipGetLastError();
+}
+
+template <int MT>
+static hipError_t launch_dc_m(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
+{
+    switch (cfg.taps) {
+    case 1: return launch_dc_ml<MT, 1>(a, cfg, s);
+    case 2: return launch_dc_ml<MT, 2>(a, cfg, s);
+    case 3: return launch_dc_ml<MT, 3>(a, cfg, s);
+    case 4: return launch_dc_ml<MT, 4>(a, cfg, s);
+    case 5: return launch_dc_ml<MT, 5>(a, cfg, s);
+    case 6: return launch_dc_ml<MT, 6>(a, cfg, s);
+    case 7: return launch_dc_ml<MT, 7>(a, cfg, s);
+    case 8: return launch_dc_ml<MT, 8>(a, cfg, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+bool dc_supported(int ant_tile, int taps)
+{
+    return ant_tile >= 1 && ant_tile <= kMaxAntTile && taps >= 1 && taps <= kMaxTapsPerLaunch;
+}
+
+hipError_t launch_dc(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
+{
+    switch (cfg.ant_tile) {
+    case 1: return launch_dc_m<1>(a, cfg, s);
+    case 2: return launch_dc_m<2>(a, cfg, s);
+    case 3: return launch_dc_m<3>(a, cfg, s);
+    case 4: return launch_dc_m<4>(a, cfg, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_finalize(const float *partial, float *out_re, float *out_im, int splits, int elems,
+                           long long groups, hipStream_t s)
+{
+    const long long total = groups * elems;
+    const unsigned grid = (unsigned)((total + kThreads - 1) / kThreads);
+    hipLaunchKernelGGL(finalize_kernel, dim3(grid), dim3(kThreads), 0, s, partial, out_re, out_im,
+                       splits, elems, groups);
+    return hipGetLastError();
+}
+
+hipError_t launch_gen_code_replica(float *rep, long long count, const int8_t *code_row, int Lc,
+                                   double fc, double fs, double tau, long long first_shift,
+                                   hipStream_t s)
+{
+    long long blocks = (count + kThreads - 1) / kThreads;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(code_replica_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, s, rep, count,
+                       code_row, Lc, fc, fs, tau, first_shift);
+    return hipGetLastError();
+}
+
+hipError_t launch_gen_signal(float *re, float *im, int interleaved, long long N, int M,
+                             long long ant_stride, long long block_stride, int B, int K,
+                             const gat_channel_params *params, const int8_t *codes, int Lc,
+                             int num_prns, double fs, hipStream_t s)
+{
+    long long bx = (N + kThreads - 1) / kThreads;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(gen_signal_kernel, dim3((unsigned)bx, (unsigned)B), dim3(kThreads), 0, s, re,
+                       im, interleaved, N, M, ant_stride, block_stride, K, params, codes, Lc,
+                       num_prns, fs);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_stage1(const float *in_re, const float *in_im, long long n, int cols,
+                                int chunks, float *partial, hipStream_t s)
+{
+    hipLaunchKernelGGL(reduce_stage1_kernel, dim3((unsigned)chunks, (unsigned)cols), dim3(kThreads), 0,
+                       s, in_re, in_im, n, cols, chunks, partial);
+    return hipGetLastError();
+}
+
+} // namespace gat

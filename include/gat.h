@@ -1,0 +1,204 @@
+/*
+ * gat.h -- C ABI of libgat, the MI355X (gfx950) GNSS tracking correlator.
+ *
+ * Drop-in boundary for ONE path of coezmaden/GPUAcceleratedTracking: downconvert + correlate
+ * (carrier wipe-off, PRN code replica, multi-tap multiply over antennas, reduction).  The
+ * reference has no FFI layer -- its boundary is Julia multiple dispatch -- so every entry point
+ * below names the reference interface it stands in for (paths relative to the reference tree).
+ * INTEGRATION.md shows the Julia `ccall` shim that binds them.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the ABI; every function returns int32 status:
+ *       0 = GAT_OK, > 0 = argument/state error (GAT_ERR_*), < 0 = -(hipError_t).
+ *     gat_last_error(ctx) returns a human-readable message for the last failure on that ctx.
+ *   - "dev" pointers are device (HBM) addresses valid on the ctx's device; "host" pointers are
+ *     ordinary host memory, read/written only during the call.
+ *   - all work is enqueued on the ctx's HIP stream; calls are asynchronous unless stated.
+ *     A ctx is not thread-safe; distinct ctxs are independent.
+ *   - arrays are column-major as in the reference: signal [N x M] (sample fastest,
+ *     src/gen_signal.jl:179), codes [Lc x P] (src/algorithms.jl:185), correlator outputs
+ *     [M x L x K x B] (antenna fastest, src/algorithms.jl:628), planar re / im
+ *     (StructArray{ComplexF32}).
+ *   - indices are 0-based here (sample n = 0 is the reference's sample_idx = 1; prn is the
+ *     0-based column of the code table, i.e. reference prn - 1).
+ */
+#ifndef GAT_H_
+#define GAT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(GAT_BUILD)
+#define GAT_API __attribute__((visibility("default")))
+#else
+#define GAT_API
+#endif
+
+/* ---- status codes ----------------------------------------------------------------------- */
+#define GAT_OK 0
+#define GAT_ERR_ARG 1         /* null pointer, non-positive size, bad enum                    */
+#define GAT_ERR_RANGE 2       /* prn / phase / size outside the supported range               */
+#define GAT_ERR_STATE 3       /* e.g. correlate before gat_set_codes                          */
+#define GAT_ERR_UNSUPPORTED 4 /* valid request this build has no kernel for                   */
+#define GAT_ERR_NOMEM 5
+
+/* ---- flags for gat_downconvert_and_correlate ------------------------------------------- */
+#define GAT_FLAG_ATOMIC 1u /* single-pass float atomics (reference alg. 4/5,                */
+                           /* src/algorithms.jl:625-632); default = deterministic two-stage */
+
+/* ---- signal layouts ---------------------------------------------------------------------- */
+#define GAT_LAYOUT_PLANAR 0      /* re[] and im[] planes (reference StructArray layout)       */
+#define GAT_LAYOUT_INTERLEAVED 1 /* ComplexF32 {re,im} pairs; .im must be NULL                */
+
+#define GAT_MAX_TAPS 32 /* correlator taps per call (L); reference uses 3 and 7           */
+
+typedef struct gat_ctx gat_ctx;
+
+/* One satellite channel in one integration block.  Replaces the scalar arguments
+ * (prn, code_frequency, carrier_frequency, start_code_phase, carrier_phase) of
+ * Tracking.downconvert_and_correlate! (call site src/benchmarks.jl:63-79) and of
+ * downconvert_and_correlate_kernel_1330! (src/algorithms.jl:142-159). */
+typedef struct gat_channel_params {
+    int32_t prn;                 /* 0-based column of the code table                         */
+    int32_t reserved;            /* must be 0                                                */
+    double code_freq_hz;         /* code_frequency (chips/s), incl. code Doppler             */
+    double carrier_freq_hz;      /* carrier_frequency = IF + Doppler (Hz)                    */
+    double code_phase_chips;     /* start_code_phase at sample 0                             */
+    double carrier_phase_cycles; /* carrier_phase at sample 0, in CYCLES (algorithms.jl:172) */
+} gat_channel_params;
+
+/* Device-resident antenna signal; replaces signal.re / signal.im (CuArray{Float32,2} or ,3)
+ * handed to kernel_algorithm (src/algorithms.jl:887-888) -- element (n, m, b, k) lives at
+ *   n + m*ant_stride + b*block_stride + k*chan_stride          (in samples). */
+typedef struct gat_signal_desc {
+    const float *re;      /* dev; planar: real plane. interleaved: ComplexF32 base            */
+    const float *im;      /* dev; planar: imaginary plane. interleaved: NULL                  */
+    int32_t layout;       /* GAT_LAYOUT_*                                                     */
+    int32_t num_ants;     /* M                                                                */
+    int64_t num_samples;  /* N per integration block                                          */
+    int64_t ant_stride;   /* samples between antennas (>= extent of one antenna's stream)     */
+    int64_t block_stride; /* samples between consecutive integration blocks (normally N)     */
+    int64_t chan_stride;  /* 0: every channel reads the same signal; != 0: one signal per     */
+                          /* channel as in _3d_4431! (src/algorithms.jl:668)                 */
+} gat_signal_desc;
+
+/* ---- context ------------------------------------------------------------------------------
+ * Replaces the implicit CUDA.jl task-local device + default stream (CUDA.@sync at
+ * src/benchmarks.jl:120).  `hip_stream` is a hipStream_t the caller keeps alive (e.g. PyTorch's
+ * current stream); NULL is the HIP default (null) stream -- which is also what PyTorch's default
+ * stream is; GAT_OWN_STREAM asks the library to create (and own) a non-blocking stream. */
+#define GAT_OWN_STREAM ((void *)(intptr_t)-1)
+GAT_API int32_t gat_create(int32_t device, void *hip_stream, gat_ctx **out_ctx);
+GAT_API int32_t gat_destroy(gat_ctx *ctx);
+GAT_API int32_t gat_set_stream(gat_ctx *ctx, void *hip_stream);
+GAT_API int32_t gat_sync(gat_ctx *ctx); /* CUDA.@sync equivalent: wait for the ctx stream  */
+GAT_API const char *gat_last_error(const gat_ctx *ctx);
+GAT_API const char *gat_version(void);
+
+/* Device properties used for metadata (add_metadata!, src/benchmarks.jl:11-32: GPU_model, CUDA
+ * version).  name_buf receives the device name; *runtime_version the HIP runtime version. */
+GAT_API int32_t gat_device_info(gat_ctx *ctx, char *name_buf, size_t name_len,
+                                int32_t *runtime_version, int32_t *num_cus);
+
+/* ---- code tables --------------------------------------------------------------------------
+ * Replaces `system.codes` (GNSSSignals.jl; src/benchmarks.jl:93, src/algorithms.jl:185):
+ * int8 +-1 chips, column-major [code_length x num_prns], copied to the device once. */
+GAT_API int32_t gat_set_codes(gat_ctx *ctx, const int8_t *codes_host, int32_t code_length,
+                              int32_t num_prns);
+
+/* Host-side PRN generators standing in for GNSSSignals.GPSL1()/GPSL5() (src/
+ * GPUAcceleratedTracking.jl:39-42).  system = "GPSL1" (1023 chips, 1.023 Mcps, PRN 1..37) or
+ * "GPSL5" (I5, 10230 chips, 10.23 Mcps, PRN 1..37).  out_codes may be NULL to query sizes. */
+GAT_API int32_t gat_gen_codes(const char *system, int32_t num_prns, int8_t *out_codes_host,
+                              int32_t *code_length, double *code_freq_hz);
+
+/* get_correlator_sample_shifts(system, correlator, fs, preferred_code_shift)
+ * (src/benchmarks.jl:105-107): s = max(1, round(spacing*fs/fc)); shifts[l] = (l - L/2)*s. */
+GAT_API int32_t gat_sample_shifts(int32_t num_taps, double sampling_freq_hz, double code_freq_hz,
+                                  double spacing_chips, int32_t *shifts_host);
+
+/* ---- the hot path -------------------------------------------------------------------------
+ * Tracking.downconvert_and_correlate!(system, signal, correlator, code_replica, code_phase,
+ *   carrier_replica, carrier_phase, downconverted_signal, code_frequency,
+ *   correlator_sample_shifts, carrier_frequency, sampling_frequency, start_sample,
+ *   num_samples, prn)                                           (src/benchmarks.jl:63-79)
+ * == kernel_algorithm(..., ::KernelAlgorithm{1330|1331|1431|2xxx|3431|4431|5431})
+ *                                                               (src/algorithms.jl:869-1545)
+ * == downconvert_and_correlate_kernel_3d_4431! for num_channels > 1 (src/algorithms.jl:637).
+ *
+ *   R[m,l,k,b] = sum_{n<N} x[n,m,b] * conj(exp(j2pi(n*f/fs + phi))) * c[floor(fc/fs*(n+shift_l)+tau) mod Lc]
+ *
+ * One fused launch (plus a tiny finalize launch when one block's samples are split over
+ * several workgroups).  Outputs are OVERWRITTEN (the reference's `+=` into stale buffers,
+ * src/algorithms.jl:207, is not reproduced).  params: [num_channels x num_blocks], channel
+ * fastest.  out_re/out_im: dev float [M x L x K x B].  The replica / carrier / downconverted
+ * scratch arguments of the reference call do not exist: nothing is materialised. */
+GAT_API int32_t gat_downconvert_and_correlate(gat_ctx *ctx, const gat_signal_desc *signal,
+                                              const gat_channel_params *params_host,
+                                              int32_t num_blocks, int32_t num_channels,
+                                              int32_t num_taps, const int32_t *shifts_host,
+                                              double sampling_freq_hz, float *out_re_dev,
+                                              float *out_im_dev, uint32_t flags);
+
+/* Same, with the per-(block, channel) parameters already resident on the device (a tracking
+ * loop that produces them on-GPU; also the form bench.py times). */
+GAT_API int32_t gat_downconvert_and_correlate_dev(gat_ctx *ctx, const gat_signal_desc *signal,
+                                                  const gat_channel_params *params_dev,
+                                                  int32_t num_blocks, int32_t num_channels,
+                                                  int32_t num_taps, const int32_t *shifts_host,
+                                                  double sampling_freq_hz, float *out_re_dev,
+                                                  float *out_im_dev, uint32_t flags);
+
+/* ---- stand-alone operators on the same path ---------------------------------------------- */
+
+/* Tracking.gen_code_replica!(code_replica, system, code_frequency, sampling_frequency,
+ *   start_code_phase, start_sample, num_samples, correlator_sample_shifts, prn)
+ *   (scripts/code_replica_experiment.jl:70) == gen_code_replica_kernel! (src/algorithms.jl:13)
+ * rep[i] = c[floor(fc/fs*(i + first_shift) + tau) mod Lc], i = 0..count-1, as float32 +-1. */
+GAT_API int32_t gat_gen_code_replica(gat_ctx *ctx, float *replica_dev, int64_t count, int32_t prn,
+                                     double code_freq_hz, double sampling_freq_hz,
+                                     double code_phase_chips, int64_t first_shift);
+
+/* gen_signal! (src/gen_signal.jl:53-175): noise-free synthetic IF signal, identical on every
+ * antenna.  Writes, for every block b, x[n,m,b] = sum_k c_k[floor(fc_k/fs*n + tau_kb) mod Lc]
+ *   * (cos, sin)(float32(2pi*n*f_kb/fs + phase_kb)).  NOTE: for THIS call the
+ * carrier_phase_cycles field is interpreted in RADIANS, as start_carrier_phase is in the
+ * reference (src/gen_signal.jl:88).  params_dev: [num_channels x num_blocks]. */
+GAT_API int32_t gat_gen_signal(gat_ctx *ctx, float *re_dev, float *im_dev, int32_t layout,
+                               int64_t num_samples, int32_t num_ants, int64_t ant_stride,
+                               int64_t block_stride, int32_t num_blocks, int32_t num_channels,
+                               const gat_channel_params *params_dev, double sampling_freq_hz);
+
+/* reduce_cplx_multi_3/4/5 two-pass sum (src/reduction.jl:93, :331, :548; launch sequence
+ * src/algorithms.jl:914-922): column sums of a planar complex [n x num_cols] array.
+ * Deterministic; no single-block second pass limit (SURVEY defect D6). */
+GAT_API int32_t gat_reduce_cplx_multi(gat_ctx *ctx, const float *in_re_dev, const float *in_im_dev,
+                                      int64_t n, int32_t num_cols, float *out_re_dev,
+                                      float *out_im_dev);
+
+/* ---- memory + timing helpers (for hosts without their own HIP array type) ---------------- */
+GAT_API int32_t gat_malloc(gat_ctx *ctx, size_t bytes, void **out_dev);
+GAT_API int32_t gat_free(gat_ctx *ctx, void *dev);
+GAT_API int32_t gat_memcpy_h2d(gat_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+GAT_API int32_t gat_memcpy_d2h(gat_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+GAT_API int32_t gat_memset(gat_ctx *ctx, void *dst_dev, int32_t value, size_t bytes);
+
+/* hipEvent pair on the ctx stream (the reference times with BenchmarkTools around CUDA.@sync,
+ * src/benchmarks.jl:120; CUDA.@elapsed in test/algorithms.jl:1242).  stop() synchronises. */
+GAT_API int32_t gat_timer_start(gat_ctx *ctx);
+GAT_API int32_t gat_timer_stop(gat_ctx *ctx, float *elapsed_ms);
+
+/* Launch geometry chosen for the last correlate call (diagnostics / DESIGN.md tables). */
+typedef struct gat_launch_info {
+    int32_t workgroups, threads, splits, ant_tile, vec, lds_bytes, finalize_launched, reserved;
+} gat_launch_info;
+GAT_API int32_t gat_last_launch_info(const gat_ctx *ctx, gat_launch_info *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAT_H_ */
