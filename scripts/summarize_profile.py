@@ -37,7 +37,8 @@ def main():
             for r in csv.DictReader(fh):
                 k = r["Kernel_Name"]
                 durs.setdefault(k, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    dom = max(durs, key=lambda k: sum(durs[k])) if durs else None
+    hot = {k: v for k, v in durs.items() if "dc_kernel" in k} or durs
+    dom = max(hot, key=lambda k: sum(hot[k])) if hot else None
     if dom:
         d = durs[dom]
         # skip warm-up dispatches (first 2 of the bench + any earlier)
