@@ -3,7 +3,7 @@
 // Stand-in for GNSSSignals.GPSL1() / GPSL5() `system.codes` (reference: src/benchmarks.jl:93,
 // src/GPUAcceleratedTracking.jl:39-42; GNSSSignals.jl itself is an un-vendored dependency).
 // Written from the public interface specifications, in a different formulation from the test
-// oracle (oracle/gat_oracle.c uses the G2 tap-selector form) so that the two cross-check:
+// oracle (which uses the G2 tap-selector form) so that the two cross-check:
 //   GPS L1 C/A (IS-GPS-200): chip_i = G1_i xor G2_{i - delay(prn)}, 10-bit Fibonacci LFSRs.
 //   GPS L5 I5  (IS-GPS-705): chip_i = XA_i xor XB_{i + advance(prn)}, 13-bit LFSRs, XA
 //                            short-cycled after 8190 chips, both restarted every 10230 chips.

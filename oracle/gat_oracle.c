@@ -277,19 +277,34 @@ GAT_ORACLE_API int gat_oracle_dc_f32_4pass(const float *re, const float *im, int
             di[n] = xi[n] * car_re[n] - xr[n] * car_im[n];
         }
     }
-    /* pass 4: correlate */
+    /* pass 4: correlate.  16 independent float partial sums per (antenna, tap) (what a SIMD
+     * loop with vector accumulators does), flushed into a double every 1024 samples: a single
+     * running float sum of ~N near-constant terms drifts by >1e-4 relative at N = 20000. */
     for (int l = 0; l < L; ++l) {
         const float *cl = code + (shifts[l] - shifts[0]);
         for (int m = 0; m < M; ++m) {
             const float *dr = dw_re + (size_t)m * N, *di = dw_im + (size_t)m * N;
-            float ar = 0.f, ai = 0.f;
-#pragma GCC ivdep
-            for (int64_t n = 0; n < N; ++n) {
-                ar += dr[n] * cl[n];
-                ai += di[n] * cl[n];
+            double tr = 0.0, ti = 0.0;
+            for (int64_t n0 = 0; n0 < N; n0 += 1024) {
+                const int len = (int)((N - n0) < 1024 ? (N - n0) : 1024);
+                float pr[16] = {0}, pi[16] = {0};
+                int n = 0;
+                for (; n + 16 <= len; n += 16)
+                    for (int j = 0; j < 16; ++j) {
+                        pr[j] += dr[n0 + n + j] * cl[n0 + n + j];
+                        pi[j] += di[n0 + n + j] * cl[n0 + n + j];
+                    }
+                for (; n < len; ++n) {
+                    pr[0] += dr[n0 + n] * cl[n0 + n];
+                    pi[0] += di[n0 + n] * cl[n0 + n];
+                }
+                float sr = 0.f, si = 0.f;
+                for (int j = 0; j < 16; ++j) { sr += pr[j]; si += pi[j]; }
+                tr += sr;
+                ti += si;
             }
-            out_re[m + l * M] = ar;
-            out_im[m + l * M] = ai;
+            out_re[m + l * M] = (float)tr;
+            out_im[m + l * M] = (float)ti;
         }
     }
     return 0;

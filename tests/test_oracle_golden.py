@@ -1,0 +1,123 @@
+"""CPU tests: pin the oracle.
+
+1. against the reference's own known-answer literals (test/algorithms.jl:85 ...; test/reduction.jl:51);
+2. against IS-GPS-200's first-10-chip octals (typed by hand in scripts/make_golden.py);
+3. the C restatement against an independent numpy restatement;
+4. the FP32 4-pass CPU baseline against the FP64 oracle (north-star tolerance 1e-5);
+5. against the committed fixtures (regression)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from tests.helpers import RTOL, check_close, make_case, oracle_result
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))
+
+
+@pytest.mark.parametrize("ka", GOLD["known_answers"], ids=lambda k: k["id"])
+def test_reference_known_answers(ka):
+    """GPS L1 PRN 1, f = 1500 Hz, phases 0, taps from get_correlator_sample_shifts(.., 0.5)."""
+    lc, fc, _ = oracle.SYSTEMS[ka["system"]]
+    codes = oracle.codes(ka["system"], 32)
+    N, M = ka["N"], ka["M"]
+    fs = N / 1e-3
+    sh = oracle.sample_shifts(3, fs, fc)
+    assert sh.tolist() == [-1, 0, 1]
+    re, im = oracle.gen_signal(codes, ka["prn"] - 1, fc, fs, ka["f"], 0.0, 0.0, N, M)
+    prm = oracle.make_params(ka["prn"] - 1, fc, ka["f"], 0.0, 0.0, shape=(1, 1))
+    R = oracle.correlate_f64(re, im, codes, prm, fs, sh)[0, 0]  # [L, M]
+    R32 = oracle.dc_f32(re, im, codes, prm, fs, sh)[0, 0]
+    for m in range(M):
+        # the reference asserts `≈` (rtol = sqrt(eps(Float32)) = 3.4e-4); we hold 1e-5
+        assert np.allclose(R[:, m], ka["expect"], rtol=RTOL, atol=0)
+        assert np.allclose(R32[:, m], ka["expect"], rtol=RTOL, atol=RTOL * N)
+    assert np.abs(R.imag).max() < 1e-3  # noise-free, phase-aligned: imaginary part ~ 0
+
+
+def test_ca_first_ten_chips_octal():
+    codes = oracle.codes("GPSL1", 32)
+    for p, want in enumerate(GOLD["ca_first10_octal"]):
+        bits = (1 - codes[p, :10].astype(int)) // 2
+        v = 0
+        for b in bits:
+            v = (v << 1) | int(b)
+        assert oct(v)[2:] == want, f"PRN {p + 1}"
+
+
+def test_code_tables_properties_and_digest():
+    for system, (lc, _, _) in oracle.SYSTEMS.items():
+        c = oracle.codes(system, 32)
+        assert c.shape == (32, lc) and set(np.unique(c)) == {-1, 1}
+        assert hashlib.sha256(c.tobytes()).hexdigest() == GOLD["code_sha256"][system]
+    ca = oracle.codes("GPSL1", 32).astype(np.int64)
+    # Gold-code properties: balance -1 (one more logic-1), 3-valued autocorrelation {-1, -65, 63}
+    assert (ca.sum(axis=1) == -1).all()
+    ac = np.array([np.dot(ca[0], np.roll(ca[0], s)) for s in range(1, 1023)])
+    assert set(np.unique(ac)) <= {-1, -65, 63}
+    for p in (1, 2, 7, 19, 32):
+        assert np.array_equal(oracle.np_code_gpsl1(p), ca[p - 1])
+
+
+def test_reduction_all_ones():
+    """test/reduction.jl:51-52, :126-127 ...: ones + 0im of (N, M, L) sums to [N N N]."""
+    for n, ml in ((2048, 3), (2500, 12), (32768, 16)):
+        out = oracle.reduce_cplx_multi(np.ones((ml, n), np.float32), np.zeros((ml, n), np.float32))
+        assert (out.real == n).all() and (out.imag == 0).all()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_c_oracle_matches_numpy_restatement(seed):
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(50, 3000))
+    M = int(rng.integers(1, 4))
+    L = int(rng.choice([1, 3, 5]))
+    case = make_case(100 + seed, N=N, M=M, L=L, K=1, B=1, if_hz=float(rng.choice([0.0, 3.1e5])))
+    ref = oracle_result(case)[0, 0]
+    p = case["prm"][0, 0]
+    alt = oracle.np_correlate(case["re"], case["im"], case["codes"][p["prn0"]], p["code_freq_hz"], case["fs"],
+                              p["carrier_freq_hz"], p["code_phase_chips"], p["carrier_phase_cycles"], case["shifts"])
+    assert np.abs(ref - alt).max() <= 1e-9 * np.abs(ref).max()
+
+
+def test_negative_shift_wraps_to_code_end():
+    """Early tap at n = 0 has a negative code phase: floored mod wraps to the code end
+    (Julia mod, src/algorithms.jl:182)."""
+    codes = oracle.codes("GPSL1", 1)
+    rep = oracle.gen_code_replica(codes, 0, 1.023e6, 2.5e6, 0.0, -3, 8)
+    want = [codes[0, (int(np.floor(0.4092 * i)) % 1023)] for i in range(-3, 5)]
+    assert rep.tolist() == [float(w) for w in want]
+    assert rep[0] == codes[0, 1021] and rep[2] == codes[0, 1022] and rep[3] == codes[0, 0]
+
+
+def test_replica_fixtures():
+    for r in GOLD["replicas"]:
+        lc, fc, _ = oracle.SYSTEMS[r["system"]]
+        got = oracle.gen_code_replica(oracle.codes(r["system"], 32), r["prn0"], fc, r["fs"], r["tau"], r["first_shift"], 40)
+        assert got.astype(int).tolist() == r["rep"]
+
+
+@pytest.mark.parametrize("g", GOLD["cases"], ids=lambda g: "seed%d" % g["config"]["seed"])
+def test_golden_cases(g):
+    case = make_case(**g["config"])
+    assert case["shifts"].tolist() == g["shifts"]
+    assert np.isclose(case["re"].astype(np.float64).sum(), g["signal_checksum"][0], rtol=0, atol=1e-3)
+    ref = np.array(g["out_re"]) + 1j * np.array(g["out_im"])
+    got = oracle_result(case)
+    assert np.abs(got - ref).max() <= 1e-9 * np.abs(ref).max()
+    # the FP32 4-pass CPU baseline (what bench.py times) holds the north-star tolerance too
+    if case["K"] >= 1:
+        f32 = oracle.dc_f32(case["re"], case["im"], case["codes"], case["prm"], case["fs"], case["shifts"], N=case["N"])
+        check_close(f32, ref, what="cpu f32 4-pass")
+
+
+def test_sample_shifts():
+    assert oracle.sample_shifts(3, 2.5e6, 1.023e6).tolist() == [-1, 0, 1]       # pinned by 1476
+    assert oracle.sample_shifts(3, 20e6, 1.023e6).tolist() == [-10, 0, 10]      # BASELINE C2
+    assert oracle.sample_shifts(5, 50e6, 10.23e6).tolist() == [-4, -2, 0, 2, 4]  # BASELINE C3
+    assert oracle.sample_shifts(3, 50e6, 1.023e6).tolist() == [-24, 0, 24]      # BASELINE C4
+    assert oracle.sample_shifts(3, 1.0e6, 1.023e6).tolist() == [-1, 0, 1]       # max(1, .)
+    assert oracle.sample_shifts(7, 20e6, 1.023e6).tolist() == [-30, -20, -10, 0, 10, 20, 30]
