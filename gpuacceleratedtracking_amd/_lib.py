@@ -67,7 +67,8 @@ _LIB = None
 
 
 def library_path() -> str:
-    return _build.LIB
+    """Path of libgat.so; GAT_LIBRARY overrides it (kernel experiments: A/B builds)."""
+    return os.environ.get("GAT_LIBRARY") or _build.LIB
 
 
 def load(build_if_missing: bool = True):
@@ -76,7 +77,7 @@ def load(build_if_missing: bool = True):
     if _LIB is not None:
         return _LIB
     path = library_path()
-    if build_if_missing and _build.is_stale():
+    if build_if_missing and not os.environ.get("GAT_LIBRARY") and _build.is_stale():
         try:
             _build.build_libgat()
         except Exception as exc:  # no hipcc on this machine

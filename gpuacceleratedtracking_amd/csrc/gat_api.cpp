@@ -8,6 +8,7 @@
 //              finalize launch sums the per-split partials in fixed order.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -29,6 +30,7 @@ struct gat_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timer_running = false;
     int num_cus = 256;
+    bool force_direct = false; // GAT_DIRECT_CHIPS=1: disable the LDS replica path (A/B experiments)
     std::string err;
     gat_launch_info last{};
 };
@@ -115,7 +117,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     }
 
     const long long N = sig->num_samples;
-    const long long chunk = (long long)kThreads * vec;
+    const long long chunk = dc_chunk(vec, il);
     const long long chunks = (N + chunk - 1) / chunk;
     const long long groups = (long long)B * K * AT;
     const long long target = 8ll * c->num_cus;
@@ -165,12 +167,22 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     cfg.vec = vec;
     cfg.interleaved = il ? 1 : 0;
     cfg.grid = (unsigned)(groups * splits);
-    cfg.lds_bytes = (unsigned)(((c->Lc + 15) & ~15) + 4 * 64 * sizeof(float));
+    a.max_abs_shift = (int)max_shift;
 
     for (int t0 = 0; t0 < L; t0 += kMaxTapsPerLaunch) {
         cfg.taps = std::min(kMaxTapsPerLaunch, L - t0);
         a.tap_off = t0;
         for (int l = 0; l < kMaxTapsPerLaunch; ++l) a.shifts[l] = l < cfg.taps ? shifts[t0 + l] : 0;
+        // LDS replica segment: needs ascending taps (shifts[0] is the earliest) and a bounded span
+        long long span = (long long)a.shifts[cfg.taps - 1] - a.shifts[0];
+        bool ascending = true;
+        for (int l = 1; l < cfg.taps; ++l) ascending = ascending && a.shifts[l] >= a.shifts[l - 1];
+        cfg.replica = (ascending && span <= kMaxReplicaSpan && !c->force_direct) ? 1 : 0;
+        a.rep_span = cfg.replica ? (int)span : 0;
+        const int slots = (int)((chunk + a.rep_span + 3) / 4);
+        a.rep_plane_stride = cfg.replica ? ((slots + 23) / 32) * 32 + 8 : 0; // >= slots, == 8 (mod 32)
+        cfg.lds_bytes = (unsigned)(((c->Lc + 15) & ~15) + 4 * 64 * sizeof(float) +
+                                   (size_t)2 * 4 * a.rep_plane_stride * sizeof(float));
         GAT_HIP(c, launch_dc(a, cfg, c->stream));
     }
     const bool fin = !atomic && splits > 1;
@@ -220,6 +232,7 @@ GAT_API int32_t gat_create(int32_t device, void *hip_stream, gat_ctx **out_ctx)
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    if (const char *e = std::getenv("GAT_DIRECT_CHIPS")) c->force_direct = e[0] == '1';
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
         delete c;
         return -(int32_t)e;

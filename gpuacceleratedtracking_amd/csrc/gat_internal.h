@@ -11,6 +11,16 @@ namespace gat {
 constexpr int kThreads = 256;       // 4 wave64 per workgroup
 constexpr int kMaxTapsPerLaunch = 8; // taps handled by one launch (register accumulators)
 constexpr int kMaxAntTile = 4;       // antennas handled by one workgroup
+constexpr int kMaxReplicaSpan = 2048; // largest tap span served from the LDS replica segment
+
+// Sample ownership of one lane per step in dc_kernel: G groups of S consecutive samples, one
+// 16-byte load per plane and group (vec == 4) or scalar loads (vec == 1).
+#ifndef GAT_PLANAR_GROUPS
+#define GAT_PLANAR_GROUPS 1
+#endif
+constexpr int dc_group_samples(int vec, bool il) { return vec == 4 ? (il ? 2 : 4) : 1; }
+constexpr int dc_groups(int vec, bool il) { return vec == 4 ? (il ? 2 : GAT_PLANAR_GROUPS) : 1; }
+constexpr int dc_chunk(int vec, bool il) { return kThreads * dc_group_samples(vec, il) * dc_groups(vec, il); }
 
 // Arguments of the fused correlator kernel (passed by value in the kernarg segment).
 struct DcArgs {
@@ -26,6 +36,9 @@ struct DcArgs {
     int M, K, B, Lc, num_prns;
     int splits, chunks_per_split, total_chunks, ant_tiles;
     int Ltot, tap_off;
+    int max_abs_shift;     // max |shift| over ALL taps of the call (range check)
+    int rep_span;          // shifts[last] - shifts[0] of THIS launch's taps (replica halo)
+    int rep_plane_stride;  // floats per replica plane (== 8 mod 32: conflict-free planes)
     unsigned flags;
     int shifts[kMaxTapsPerLaunch];
 };
@@ -35,6 +48,7 @@ struct DcLaunch {
     int taps;     // L of this launch
     int vec;      // 4 or 1
     int interleaved;
+    int replica; // 1: LDS replica segment shared by the taps; 0: direct chip evaluation
     unsigned grid;
     unsigned lds_bytes;
 };

@@ -28,6 +28,15 @@ namespace gat {
 // ------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte streaming load.  The signal is read exactly once, so the loads are non-temporal
+// (global_load_dwordx4 ... nt): measured +7 % on a pure read of this access pattern
+// (scripts/bw_probe.hip: 6.13 -> 6.58 TB/s on MI355X).
+__device__ __forceinline__ f32x4 load_stream16(const float *p)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+}
 
 // exp(j*2*pi*theta) for theta in cycles (double).  Octant reduction in double (exact), float
 // Taylor polynomials on |a| <= pi/4 (|err| < 3e-8), quadrant fix-up.
@@ -52,17 +61,14 @@ __device__ __forceinline__ void sincos_cycles(double theta, float &c, float &s)
     s = (qi >= 2) ? -sn : sn;
 }
 
-// floor(p) mod Lc with floored (Julia) semantics; valid for |ip| / Lc < 2^21 (host-checked).
+// floor(p) mod Lc with floored (Julia) semantics; valid for |ip| < 2^30 and |ip| / Lc < 2^21
+// (checked on the host and again per workgroup in dc_kernel; other callers clamp).
 __device__ __forceinline__ int floormod_fast(int ip, int Lc, float inv_lc)
 {
     const float q = __builtin_floorf((float)ip * inv_lc);
     int r = ip - (int)q * Lc;
     r += (r < 0) ? Lc : 0;
     r -= (r >= Lc) ? Lc : 0;
-    if ((unsigned)r >= (unsigned)Lc) { // estimate off by more than one: huge |ip| (never on checked inputs)
-        r = ip % Lc;
-        r += (r < 0) ? Lc : 0;
-    }
     return r;
 }
 
@@ -117,12 +123,20 @@ __device__ __forceinline__ float wave_sum(float v)
 // ------------------------------------------------------------------------------------------
 // fused downconvert + correlate
 // ------------------------------------------------------------------------------------------
-template <int MT, int L, int VEC, bool IL>
+// REP = true: the chips of one step are generated ONCE per workgroup into an LDS replica
+// segment [CHUNK + num_of_shifts] (what gen_code_replica! materialises in global memory in
+// the reference, src/algorithms.jl:752-758) and every tap reads it at its own offset, so a
+// step costs (CHUNK + shifts)/256 = ~4.1 FP64 code-phase evaluations per lane instead of
+// S*G*L = 12.  The segment is stored as 4 interleaved planes (element i at plane i&3, slot
+// i>>2) so that the lanes of a wave, which own samples 4*lane + j, read consecutive dwords.
+// REP = false: every (sample, tap) chip is evaluated directly (huge tap spans).
+template <int MT, int L, int VEC, bool IL, bool REP>
 __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int8_t *s_code = reinterpret_cast<int8_t *>(smem);
     float *s_part = reinterpret_cast<float *>(smem + ((a.Lc + 15) & ~15)); // [4][64]
+    float *s_rep = s_part + 4 * 64;                                        // [2][4][rep_ps]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -137,21 +151,27 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
     const int b = wg / a.K;
 
     const gat_channel_params P = a.params[(size_t)b * a.K + k];
-    const bool bad_prn = P.prn < 0 || P.prn >= a.num_prns;
-    const int prn = bad_prn ? 0 : P.prn;
     const int Lc = a.Lc;
+    const int N = (int)a.N;
+    const double ratio = P.code_freq_hz / a.fs;    // src/algorithms.jl:179 (Float64 division)
+    const double step = P.carrier_freq_hz / a.fs;  // cycles per sample
+    const double tau = P.code_phase_chips;
+    const double phi = P.carrier_phase_cycles;
+    const float inv_lc = 1.0f / (float)Lc;
+
+    // Parameters this kernel cannot evaluate exactly poison the output with NaN (fail loudly):
+    // prn outside the table, or a code-phase span beyond the int32 / float-reciprocal modulo range
+    // (the host entry point rejects these up front; device-resident parameters are checked here).
+    const double span = __builtin_fabs(tau) + __builtin_fabs(ratio) * (double)(N + a.max_abs_shift) + 1.0;
+    const bool bad = P.prn < 0 || P.prn >= a.num_prns || !(span < 1073741824.0) ||
+                     !(span < 2097152.0 * (double)Lc) || !(ratio >= 0.0) || !(step == step) || !(phi == phi);
+    const int prn = (P.prn < 0 || P.prn >= a.num_prns) ? 0 : P.prn;
 
     {
         const int8_t *g = a.codes + (size_t)prn * Lc;
         for (int i = tid; i < Lc; i += kThreads) s_code[i] = g[i];
     }
     __syncthreads();
-
-    const double ratio = P.code_freq_hz / a.fs;    // src/algorithms.jl:179 (Float64 division)
-    const double step = P.carrier_freq_hz / a.fs;  // cycles per sample
-    const double tau = P.code_phase_chips;
-    const double phi = P.carrier_phase_cycles;
-    const float inv_lc = 1.0f / (float)Lc;
 
     float wr, wi; // one-sample rotation exp(+j*2*pi*step)
     sincos_cycles(step - __builtin_rint(step), wr, wi);
@@ -162,19 +182,36 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
 #pragma unroll
         for (int l = 0; l < L; ++l) acc_re[m][l] = acc_im[m][l] = 0.f;
 
-    const int N = (int)a.N;
     const size_t base = (size_t)b * a.block_stride + (size_t)k * a.chan_stride +
                         (size_t)(at * MT) * a.ant_stride;
-    constexpr int CHUNK = kThreads * VEC;
+    // A lane owns G groups of S consecutive samples per step; one group = one 16-byte load per
+    // plane (planar: 4 samples; interleaved ComplexF32: 2 samples), so every wave-instruction
+    // covers 1 KiB of contiguous memory in both layouts.
+    constexpr int S = dc_group_samples(VEC, IL);
+    constexpr int G = dc_groups(VEC, IL);
+    constexpr int GSTRIDE = kThreads * S;
+    constexpr int CHUNK = GSTRIDE * G;
+    static_assert(CHUNK == dc_chunk(VEC, IL), "host and device disagree on the chunk size");
     const int c_begin = split * a.chunks_per_split;
-    const int c_end = min(c_begin + a.chunks_per_split, a.total_chunks);
+    const int c_end = bad ? c_begin : min(c_begin + a.chunks_per_split, a.total_chunks);
+    const int shift0 = a.shifts[0];
+    const int rep_ps = a.rep_plane_stride;
+    const int rep_cnt = CHUNK + a.rep_span; // entries of one replica segment
 
-    // one sample: carrier (cr, ci), chips for the L taps, MT antennas
-    auto accumulate = [&](const float (&xr)[MT], const float (&xi)[MT], float cr, float ci, int n) {
-        float chip[L];
+    // chips of sample n (block-relative) for the L taps; rel = n - chunk start, rep = this step's segment
+    auto get_chips = [&](float (&chip)[L], int n, int rel, const float *rep) {
 #pragma unroll
-        for (int l = 0; l < L; ++l)
-            chip[l] = (float)s_code[chip_index(ratio, tau, n + a.shifts[l], Lc, inv_lc)];
+        for (int l = 0; l < L; ++l) {
+            if constexpr (REP) {
+                const int i = rel + (a.shifts[l] - shift0);
+                chip[l] = rep[(i & 3) * rep_ps + (i >> 2)];
+            } else {
+                chip[l] = (float)s_code[chip_index(ratio, tau, n + a.shifts[l], Lc, inv_lc)];
+            }
+        }
+    };
+    // one sample: carrier (cr, ci), chips, MT antennas
+    auto accumulate = [&](const float (&xr)[MT], const float (&xi)[MT], float cr, float ci, const float (&chip)[L]) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             // conj(carrier) wipe-off, src/algorithms.jl:175-176
@@ -187,63 +224,94 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
             }
         }
     };
+    auto load_group = [&](float (&xr)[S][MT], float (&xi)[S][MT], int n) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const size_t e = base + (size_t)m * a.ant_stride + n;
+            if constexpr (VEC == 4 && !IL) {
+                const f32x4 vr = load_stream16(a.re + e);
+                const f32x4 vi = load_stream16(a.im + e);
+                xr[0][m] = vr.x; xr[1][m] = vr.y; xr[2][m] = vr.z; xr[3][m] = vr.w;
+                xi[0][m] = vi.x; xi[1][m] = vi.y; xi[2][m] = vi.z; xi[3][m] = vi.w;
+            } else if constexpr (VEC == 4 && IL) {
+                const f32x4 v = load_stream16(a.re + 2 * e);
+                xr[0][m] = v.x; xi[0][m] = v.y; xr[1][m] = v.z; xi[1][m] = v.w;
+            } else {
+                xr[0][m] = IL ? a.re[2 * e] : a.re[e];
+                xi[0][m] = IL ? a.re[2 * e + 1] : a.im[e];
+            }
+        }
+    };
+    // S consecutive samples starting at n: one FP64 carrier anchor, then S-1 rotations
+    auto process_group = [&](const float (&xr)[S][MT], const float (&xi)[S][MT], int n, int rel, const float *rep) {
+        float cr, ci;
+        const double th0 = __builtin_fma((double)n, step, phi);
+        sincos_cycles(th0 - __builtin_rint(th0), cr, ci);
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+            float chip[L];
+            get_chips(chip, n + j, rel + j, rep);
+            accumulate(xr[j], xi[j], cr, ci, chip);
+            if (j + 1 < S) {
+                const float t = __builtin_fmaf(cr, wr, -(ci * wi));
+                ci = __builtin_fmaf(cr, wi, ci * wr);
+                cr = t;
+            }
+        }
+    };
+    // ragged end of a block: samples [n_lo, N), fewer than S of them, scalar loads
+    auto scalar_tail = [&](int n_lo, int rel, const float *rep) {
+        for (int n = n_lo; n < N; ++n, ++rel) {
+            float xr[MT], xi[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const size_t e = base + (size_t)m * a.ant_stride + n;
+                xr[m] = IL ? a.re[2 * e] : a.re[e];
+                xi[m] = IL ? a.re[2 * e + 1] : a.im[e];
+            }
+            const double th = __builtin_fma((double)n, step, phi);
+            float cr, ci, chip[L];
+            sincos_cycles(th - __builtin_rint(th), cr, ci);
+            get_chips(chip, n, rel, rep);
+            accumulate(xr, xi, cr, ci, chip);
+        }
+    };
+    // this step's replica segment: entry i <-> sample c*CHUNK + shift0 + i (src/algorithms.jl:753-757)
+    auto fill_replica = [&](float *rep, int c) {
+        const int x0 = c * CHUNK + shift0;
+        for (int i = tid; i < rep_cnt; i += kThreads)
+            rep[(i & 3) * rep_ps + (i >> 2)] = (float)s_code[chip_index(ratio, tau, x0 + i, Lc, inv_lc)];
+    };
 
     for (int c = c_begin; c < c_end; ++c) {
-        const int n0 = c * CHUNK + tid * VEC;
-        if (n0 + VEC <= N) {
-            float xr[VEC][MT], xi[VEC][MT];
-            if constexpr (VEC == 4 && !IL) {
+        const int rel0 = tid * S;
+        const int cb = c * CHUNK + rel0;
+        float *rep = s_rep + ((c - c_begin) & 1) * 4 * rep_ps; // double-buffered: one barrier per step
+        if (c * CHUNK + CHUNK <= N) { // whole chunk inside the block: issue every load first
+            float xr[G][S][MT], xi[G][S][MT];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const float4 vr = *reinterpret_cast<const float4 *>(a.re + base + (size_t)m * a.ant_stride + n0);
-                    const float4 vi = *reinterpret_cast<const float4 *>(a.im + base + (size_t)m * a.ant_stride + n0);
-                    xr[0][m] = vr.x; xr[1][m] = vr.y; xr[2][m] = vr.z; xr[3][m] = vr.w;
-                    xi[0][m] = vi.x; xi[1][m] = vi.y; xi[2][m] = vi.z; xi[3][m] = vi.w;
-                }
-            } else if constexpr (VEC == 4 && IL) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const float4 *p = reinterpret_cast<const float4 *>(a.re + 2 * (base + (size_t)m * a.ant_stride + n0));
-                    const float4 v0 = p[0], v1 = p[1];
-                    xr[0][m] = v0.x; xi[0][m] = v0.y; xr[1][m] = v0.z; xi[1][m] = v0.w;
-                    xr[2][m] = v1.x; xi[2][m] = v1.y; xr[3][m] = v1.z; xi[3][m] = v1.w;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < VEC; ++j)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        const size_t e = base + (size_t)m * a.ant_stride + n0 + j;
-                        xr[j][m] = IL ? a.re[2 * e] : a.re[e];
-                        xi[j][m] = IL ? a.re[2 * e + 1] : a.im[e];
-                    }
+            for (int g = 0; g < G; ++g) load_group(xr[g], xi[g], cb + g * GSTRIDE);
+            if constexpr (REP) { // generated while the loads are in flight
+                fill_replica(rep, c);
+                __syncthreads();
             }
-            float cr, ci;
-            const double th0 = __builtin_fma((double)n0, step, phi);
-            sincos_cycles(th0 - __builtin_rint(th0), cr, ci);
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                accumulate(xr[j], xi[j], cr, ci, n0 + j);
-                if (j + 1 < VEC) {
-                    const float t = __builtin_fmaf(cr, wr, -(ci * wi));
-                    ci = __builtin_fmaf(cr, wi, ci * wr);
-                    cr = t;
-                }
+            for (int g = 0; g < G; ++g) process_group(xr[g], xi[g], cb + g * GSTRIDE, rel0 + g * GSTRIDE, rep);
+        } else {
+            if constexpr (REP) {
+                fill_replica(rep, c);
+                __syncthreads();
             }
-        } else if (VEC > 1 && n0 < N) {
-            // ragged end of the block: at most one lane, at most VEC-1 samples
-            for (int n = n0; n < N; ++n) {
-                float xr[MT], xi[MT];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    const size_t e = base + (size_t)m * a.ant_stride + n;
-                    xr[m] = IL ? a.re[2 * e] : a.re[e];
-                    xi[m] = IL ? a.re[2 * e + 1] : a.im[e];
+            for (int g = 0; g < G; ++g) {
+                const int n = cb + g * GSTRIDE;
+                if (n + S <= N) {
+                    float xr[S][MT], xi[S][MT];
+                    load_group(xr, xi, n);
+                    process_group(xr, xi, n, rel0 + g * GSTRIDE, rep);
+                } else if (S > 1 && n < N) {
+                    scalar_tail(n, rel0 + g * GSTRIDE, rep);
                 }
-                const double th = __builtin_fma((double)n, step, phi);
-                float cr, ci;
-                sincos_cycles(th - __builtin_rint(th), cr, ci);
-                accumulate(xr, xi, cr, ci, n);
             }
         }
     }
@@ -268,7 +336,7 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
 
     if (tid < NV) {
         float tot = (s_part[tid] + s_part[64 + tid]) + (s_part[128 + tid] + s_part[192 + tid]);
-        if (bad_prn) tot = __builtin_nanf("");
+        if (bad) tot = __builtin_nanf("");
         const int comp = tid & 1;
         const int ml = tid >> 1;
         const int m = at * MT + (ml % MT);
@@ -397,17 +465,21 @@ template <int MT, int L>
 static hipError_t launch_dc_ml(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
 {
     const dim3 grid(cfg.grid), block(kThreads);
+#define GAT_LAUNCH(V, I, R) hipLaunchKernelGGL((dc_kernel<MT, L, V, I, R>), grid, block, cfg.lds_bytes, s, a)
     if (cfg.vec == 4) {
-        if (cfg.interleaved)
-            hipLaunchKernelGGL((dc_kernel<MT, L, 4, true>), grid, block, cfg.lds_bytes, s, a);
-        else
-            hipLaunchKernelGGL((dc_kernel<MT, L, 4, false>), grid, block, cfg.lds_bytes, s, a);
+        if (cfg.interleaved) {
+            if (cfg.replica) GAT_LAUNCH(4, true, true); else GAT_LAUNCH(4, true, false);
+        } else {
+            if (cfg.replica) GAT_LAUNCH(4, false, true); else GAT_LAUNCH(4, false, false);
+        }
     } else {
-        if (cfg.interleaved)
-            hipLaunchKernelGGL((dc_kernel<MT, L, 1, true>), grid, block, cfg.lds_bytes, s, a);
-        else
-            hipLaunchKernelGGL((dc_kernel<MT, L, 1, false>), grid, block, cfg.lds_bytes, s, a);
+        if (cfg.interleaved) {
+            if (cfg.replica) GAT_LAUNCH(1, true, true); else GAT_LAUNCH(1, true, false);
+        } else {
+            if (cfg.replica) GAT_LAUNCH(1, false, true); else GAT_LAUNCH(1, false, false);
+        }
     }
+#undef GAT_LAUNCH
     return hipGetLastError();
 }
 
