@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--atomic", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    ap.add_argument("--block-ms", type=float, default=1.0, help="duration of one integration block (fs = N / block)")
     return ap.parse_args()
 
 
@@ -119,7 +120,7 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("GAT_BENCH_FORCE_DIST") == "1":  # the latter: exercise the RCCL path on 1 GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -131,9 +132,10 @@ def main():
     N, M, L, K, B = args.num_samples, args.num_ants, args.num_taps, args.channels, args.blocks
     # channel sharding: rank r correlates PRNs [r*K, (r+1)*K) of the constellation on a replicated signal
     plan = g.shard_channels(K * world, world, rank)
-    op, desc, sig, prm = g.build_stream(args.gnss, N, M, L, K, B, layout=layout, first_prn=plan.lo, flags=flags)
+    op, desc, sig, prm = g.build_stream(args.gnss, N, M, L, K, B, layout=layout, first_prn=plan.lo, flags=flags,
+                                        block_seconds=args.block_ms * 1e-3)
     ctx = op.ctx
-    fs = N / 1e-3
+    fs = N / (args.block_ms * 1e-3)
 
     def barrier():
         torch.cuda.synchronize()
@@ -196,8 +198,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.gnss} C/A, {M} ants, {K} PRN/GPU, {L} correlators, 1 ms @ {fs / 1e6:g} MHz "
-                            f"(BASELINE configs[1]), batched stream of {B} blocks/launch",
+                "workload": f"{args.gnss}, {M} ants, {K} PRN/GPU, {L} correlators, {args.block_ms:g} ms @ {fs / 1e6:g} MHz "
+                            f"{'(BASELINE configs[1]) ' if (args.gnss, N, M, L, K) == ('GPSL1', 20000, 4, 3, 1) else ''}"
+                            f"batched stream of {B} blocks/launch",
                 "num_samples": N, "num_ants": M, "num_taps": L, "channels_per_gpu": K, "blocks_per_launch": B,
                 "layout": args.layout, "second_stage": "atomic" if args.atomic else "deterministic",
                 "sharding": f"channels x{world} (replicated signal, no collective)",

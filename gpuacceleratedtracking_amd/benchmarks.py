@@ -135,11 +135,11 @@ def algorithmic_bytes(num_blocks, num_samples, num_ants, num_taps, num_channels)
 
 def build_stream(system_name: str, num_samples: int, num_ants: int, num_taps: int, num_channels: int,
                  num_blocks: int, layout: int = _lib.GAT_LAYOUT_PLANAR, first_prn: int = 0, flags: int = 0,
-                 device=None):
+                 device=None, block_seconds: float = 1e-3):
     """Allocate + synthesise the device-resident stream and the operator.  Returns
     (op, desc, (re, im), params)."""
     system = GNSSDICT[system_name](use_gpu=True)
-    fs = num_samples / 1e-3
+    fs = num_samples / block_seconds
     shifts = get_correlator_sample_shifts(system, EarlyPromptLateCorrelator(num_ants, num_taps), fs, 0.5)
     prm, prm_sig = stream_scenario(system, num_blocks, num_channels, fs, num_samples, first_prn=first_prn)
     re, im = gen_signal_stream(system, prm_sig, fs, num_samples, num_ants, layout=layout, device=device)

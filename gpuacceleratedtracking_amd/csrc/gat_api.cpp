@@ -125,7 +125,9 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     splits = std::min(splits, chunks);
     const long long cps = (chunks + splits - 1) / splits;
     splits = (chunks + cps - 1) / cps;
-    if (groups * splits >= (1ll << 31)) return fail(c, GAT_ERR_RANGE, "grid too large");
+    const long long tiles = (long long)B * AT * splits;
+    const long long grid_wgs = ((tiles + 7) / 8) * 8 * K;
+    if (grid_wgs >= (1ll << 31)) return fail(c, GAT_ERR_RANGE, "grid too large");
 
     const bool atomic = (flags & GAT_FLAG_ATOMIC) != 0;
     const size_t out_elems = (size_t)B * K * L * M;
@@ -159,6 +161,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     a.chunks_per_split = (int)cps;
     a.total_chunks = (int)chunks;
     a.ant_tiles = AT;
+    a.num_tiles = (int)tiles;
     a.Ltot = L;
     a.flags = flags;
 
@@ -166,7 +169,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     cfg.ant_tile = MT;
     cfg.vec = vec;
     cfg.interleaved = il ? 1 : 0;
-    cfg.grid = (unsigned)(groups * splits);
+    cfg.grid = (unsigned)grid_wgs;
     a.max_abs_shift = (int)max_shift;
 
     for (int t0 = 0; t0 < L; t0 += kMaxTapsPerLaunch) {

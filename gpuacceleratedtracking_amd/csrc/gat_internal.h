@@ -35,6 +35,7 @@ struct DcArgs {
     double fs;
     int M, K, B, Lc, num_prns;
     int splits, chunks_per_split, total_chunks, ant_tiles;
+    int num_tiles; // B * ant_tiles * splits
     int Ltot, tap_off;
     int max_abs_shift;     // max |shift| over ALL taps of the call (range check)
     int rep_span;          // shifts[last] - shifts[0] of THIS launch's taps (replica halo)

@@ -142,13 +142,19 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    unsigned wg = blockIdx.x;
-    const int split = wg % a.splits;
-    wg /= a.splits;
-    const int at = wg % a.ant_tiles;
-    wg /= a.ant_tiles;
-    const int k = wg % a.K;
-    const int b = wg / a.K;
+    // Workgroup -> (tile, channel).  A tile = (block b, antenna tile, split): the bytes K channel
+    // workgroups share.  Blocks id and id+8 land on the same XCD (round-robin dispatch), so the K
+    // workgroups of one tile get ids tile%8 + 8*(k + K*(tile/8)): same XCD, dispatched back to
+    // back -> the tile comes from HBM once and from that XCD's L2 for the other K-1 channels.
+    // (Speed only: nothing depends on the placement.)
+    const unsigned xcd = blockIdx.x & 7u, jq = blockIdx.x >> 3;
+    const int k = (int)(jq % (unsigned)a.K);
+    unsigned tile = (jq / (unsigned)a.K) * 8u + xcd;
+    if (tile >= (unsigned)a.num_tiles) return; // padding of the last group of 8 (whole workgroup exits)
+    const int split = tile % a.splits;
+    tile /= a.splits;
+    const int at = tile % a.ant_tiles;
+    const int b = tile / a.ant_tiles;
 
     const gat_channel_params P = a.params[(size_t)b * a.K + k];
     const int Lc = a.Lc;
