@@ -116,6 +116,31 @@ class Context:
                 C.c_void_p(_ptr(out_im)), flags)
             self.check(rc, "gat_downconvert_and_correlate")
 
+    def prepared_call(self, desc: _lib.SignalDesc, params_dev: torch.Tensor, num_blocks: int, num_channels: int,
+                      shifts, sampling_frequency: float, out_re: torch.Tensor, out_im: torch.Tensor, flags: int = 0):
+        """Validate once and return a zero-argument callable that enqueues
+        gat_downconvert_and_correlate_dev with pre-converted ctypes arguments (a tracking loop calls
+        the same operator thousands of times per second; the reference pays Julia dispatch +
+        `@cuda` argument conversion per launch, src/algorithms.jl:896)."""
+        sh = np.ascontiguousarray(shifts, dtype=np.int32)
+        need = num_blocks * num_channels * sh.size * desc.num_ants
+        if out_re.numel() < need or out_im.numel() < need or out_re.dtype != torch.float32:
+            raise ValueError("output tensors too small or not float32")
+        if params_dev.numel() * params_dev.element_size() < num_blocks * num_channels * 40:
+            raise ValueError("device params tensor too small")
+        fn = self.lib.gat_downconvert_and_correlate_dev
+        args = (self._h, C.byref(desc), C.c_void_p(_ptr(params_dev)), num_blocks, num_channels, int(sh.size),
+                sh.ctypes.data_as(C.POINTER(C.c_int32)), float(sampling_frequency), C.c_void_p(_ptr(out_re)),
+                C.c_void_p(_ptr(out_im)), int(flags))
+        keep = (desc, sh, params_dev, out_re, out_im)  # keep the buffers alive with the closure
+
+        def call(_fn=fn, _args=args, _keep=keep, _check=self.check):
+            rc = _fn(*_args)
+            if rc != 0:
+                _check(rc, "gat_downconvert_and_correlate_dev")
+
+        return call
+
     def gen_code_replica(self, out: torch.Tensor, count: int, prn: int, code_frequency: float,
                          sampling_frequency: float, code_phase: float, first_shift: int):
         if out.numel() < count or out.dtype != torch.float32:

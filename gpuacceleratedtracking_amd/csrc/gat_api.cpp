@@ -123,6 +123,8 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     const long long target = 8ll * c->num_cus;
     long long splits = std::max<long long>(1, (target + groups - 1) / groups);
     splits = std::min(splits, chunks);
+    // tiny blocks (latency regime): a second launch costs more than a few serial steps
+    if (chunks <= 4 && !(flags & GAT_FLAG_ATOMIC)) splits = 1;
     const long long cps = (chunks + splits - 1) / splits;
     splits = (chunks + cps - 1) / cps;
     const long long tiles = (long long)B * AT * splits;

@@ -360,21 +360,26 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
     }
 }
 
-// second stage: fixed-order sum of the per-split partials (deterministic).
+// second stage: sum of the per-split partials in a FIXED order (deterministic): one wave64 per
+// output element, lane i adds splits i, i+64, ... sequentially, then a fixed butterfly.
 // partial [groups][splits][elems], elems = cols*2 with re/im interleaved innermost.
 __global__ void __launch_bounds__(kThreads)
 finalize_kernel(const float *__restrict__ partial, float *__restrict__ out_re,
                 float *__restrict__ out_im, int splits, int elems, long long groups)
 {
-    const long long gid = (long long)blockIdx.x * kThreads + threadIdx.x;
-    if (gid >= groups * elems) return;
-    const long long g = gid / elems;
-    const int e = (int)(gid - g * elems);
+    const long long wave_id = (long long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (wave_id >= groups * elems) return;
+    const int lane = threadIdx.x & 63;
+    const long long g = wave_id / elems;
+    const int e = (int)(wave_id - g * elems);
     const float *p = partial + (size_t)g * splits * elems + e;
     float s = 0.f;
-    for (int i = 0; i < splits; ++i) s += p[(size_t)i * elems];
-    float *o = (e & 1) ? out_im : out_re;
-    o[(size_t)g * (elems / 2) + (e >> 1)] = s;
+    for (int i = lane; i < splits; i += 64) s += p[(size_t)i * elems];
+    s = wave_sum(s);
+    if (lane == 0) {
+        float *o = (e & 1) ? out_im : out_re;
+        o[(size_t)g * (elems / 2) + (e >> 1)] = s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -524,8 +529,8 @@ hipError_t launch_dc(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
 hipError_t launch_finalize(const float *partial, float *out_re, float *out_im, int splits, int elems,
                            long long groups, hipStream_t s)
 {
-    const long long total = groups * elems;
-    const unsigned grid = (unsigned)((total + kThreads - 1) / kThreads);
+    const long long waves = groups * elems;
+    const unsigned grid = (unsigned)((waves + kThreads / 64 - 1) / (kThreads / 64));
     hipLaunchKernelGGL(finalize_kernel, dim3(grid), dim3(kThreads), 0, s, partial, out_re, out_im,
                        splits, elems, groups);
     return hipGetLastError();
