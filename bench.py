@@ -46,7 +46,8 @@ def parse_args():
     ap.add_argument("--num-taps", type=int, default=3)
     ap.add_argument("--channels", type=int, default=1, help="K: PRN channels per GPU")
     ap.add_argument("--gnss", default="GPSL1")
-    ap.add_argument("--layout", choices=["planar", "interleaved"], default="planar")
+    ap.add_argument("--layout", choices=["planar", "interleaved", "i16", "i8"], default="planar",
+                    help="sample format: planar/interleaved ComplexF32 (headline), int16 / int8 ingest")
     ap.add_argument("--atomic", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
@@ -127,7 +128,8 @@ def main():
 
     import gpuacceleratedtracking_amd as g
 
-    layout = g.GAT_LAYOUT_PLANAR if args.layout == "planar" else g.GAT_LAYOUT_INTERLEAVED
+    layout = {"planar": g.GAT_LAYOUT_PLANAR, "interleaved": g.GAT_LAYOUT_INTERLEAVED,
+              "i16": g.GAT_LAYOUT_INTERLEAVED_I16, "i8": g.GAT_LAYOUT_INTERLEAVED_I8}[args.layout]
     flags = g.GAT_FLAG_ATOMIC if args.atomic else 0
     N, M, L, K, B = args.num_samples, args.num_ants, args.num_taps, args.channels, args.blocks
     # channel sharding: rank r correlates PRNs [r*K, (r+1)*K) of the constellation on a replicated signal
@@ -162,7 +164,7 @@ def main():
         total_samples = float(B) * N * K * world * args.steps
         value = total_samples / elapsed / 1e6
         launch_s = kernel_ms_total * 1e-3 / args.steps
-        alg_bytes = g.algorithmic_bytes(B, N, M, L, K)
+        alg_bytes = g.algorithmic_bytes(B, N, M, L, K, g.SAMPLE_BYTES[layout])
         achieved = alg_bytes / launch_s / 1e9
         info = ctx.last_launch_info()
         # parity spot-check of the timed output against the FP64 oracle (first / last blocks)
@@ -172,7 +174,7 @@ def main():
             h_re = sig[0][:, :host_blocks * N].cpu().numpy()
             h_im = sig[1][:, :host_blocks * N].cpu().numpy()
         else:
-            h = sig[0][:, :host_blocks * N, :].cpu().numpy()
+            h = sig[0][:, :host_blocks * N, :].cpu().numpy().astype(np.float32)  # ints convert exactly
             h_re, h_im = np.ascontiguousarray(h[..., 0]), np.ascontiguousarray(h[..., 1])
         got = op.result()
         oprm = oracle.make_params(prm["prn"], prm["code_freq_hz"], prm["carrier_freq_hz"],
@@ -195,7 +197,7 @@ def main():
             "metric": "Msamples/s downconvert+correlate (E/P/L x ants x sats); real-time factor @ 1ms",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 6),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.layout in ("planar", "interleaved") else f"f32 (samples {args.layout})",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.gnss}, {M} ants, {K} PRN/GPU, {L} correlators, {args.block_ms:g} ms @ {fs / 1e6:g} MHz "

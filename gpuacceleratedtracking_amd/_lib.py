@@ -15,6 +15,10 @@ GAT_OK = 0
 GAT_FLAG_ATOMIC = 1
 GAT_LAYOUT_PLANAR = 0
 GAT_LAYOUT_INTERLEAVED = 1
+GAT_LAYOUT_INTERLEAVED_I16 = 2
+GAT_LAYOUT_INTERLEAVED_I8 = 3
+# bytes of one complex sample per layout
+SAMPLE_BYTES = {0: 8, 1: 8, 2: 4, 3: 2}
 GAT_MAX_TAPS = 32
 
 EXPORTS = [
@@ -104,7 +108,7 @@ def load(build_if_missing: bool = True):
         "gat_downconvert_and_correlate": (i32, [vp, sp, pp, i32, i32, i32, i32p, dbl, vp, vp, u32]),
         "gat_downconvert_and_correlate_dev": (i32, [vp, sp, vp, i32, i32, i32, i32p, dbl, vp, vp, u32]),
         "gat_gen_code_replica": (i32, [vp, vp, i64, i32, dbl, dbl, dbl, i64]),
-        "gat_gen_signal": (i32, [vp, vp, vp, i32, i64, i32, i64, i64, i32, i32, vp, dbl]),
+        "gat_gen_signal": (i32, [vp, vp, vp, i32, i64, i32, i64, i64, i32, i32, vp, dbl, dbl]),
         "gat_reduce_cplx_multi": (i32, [vp, vp, vp, i64, i32, vp, vp]),
         "gat_malloc": (i32, [vp, C.c_size_t, C.POINTER(vp)]),
         "gat_free": (i32, [vp, vp]),

@@ -128,21 +128,27 @@ def stream_scenario(system, num_blocks: int, num_channels: int, sampling_frequen
     return prm, prm_sig
 
 
-def algorithmic_bytes(num_blocks, num_samples, num_ants, num_taps, num_channels) -> int:
-    """every ComplexF32 antenna sample read once + outputs written once."""
-    return num_blocks * (8 * num_samples * num_ants + 8 * num_ants * num_taps * num_channels)
+def algorithmic_bytes(num_blocks, num_samples, num_ants, num_taps, num_channels, sample_bytes: int = 8) -> int:
+    """every antenna sample read once (8 B as ComplexF32; 4 / 2 B for the
+    int16 / int8 ingest layouts) + ComplexF32 outputs written once."""
+    return num_blocks * (sample_bytes * num_samples * num_ants + 8 * num_ants * num_taps * num_channels)
 
 
 def build_stream(system_name: str, num_samples: int, num_ants: int, num_taps: int, num_channels: int,
                  num_blocks: int, layout: int = _lib.GAT_LAYOUT_PLANAR, first_prn: int = 0, flags: int = 0,
-                 device=None, block_seconds: float = 1e-3):
+                 device=None, block_seconds: float = 1e-3, amplitude: float | None = None):
     """Allocate + synthesise the device-resident stream and the operator.  Returns
     (op, desc, (re, im), params)."""
     system = GNSSDICT[system_name](use_gpu=True)
     fs = num_samples / block_seconds
     shifts = get_correlator_sample_shifts(system, EarlyPromptLateCorrelator(num_ants, num_taps), fs, 0.5)
     prm, prm_sig = stream_scenario(system, num_blocks, num_channels, fs, num_samples, first_prn=first_prn)
-    re, im = gen_signal_stream(system, prm_sig, fs, num_samples, num_ants, layout=layout, device=device)
+    if amplitude is None:  # integer layouts: use most of the range, leave head-room for K summed channels
+        amplitude = {_lib.GAT_LAYOUT_INTERLEAVED_I16: 16000.0, _lib.GAT_LAYOUT_INTERLEAVED_I8: 60.0}.get(layout, 1.0)
+        if layout >= _lib.GAT_LAYOUT_INTERLEAVED_I16:
+            amplitude /= num_channels
+    re, im = gen_signal_stream(system, prm_sig, fs, num_samples, num_ants, layout=layout, device=device,
+                               amplitude=amplitude)
     op = StreamCorrelator(system, num_samples, num_ants, num_blocks, num_channels, shifts, fs, flags=flags,
                           device=device)
     op.set_params(prm)

@@ -151,10 +151,10 @@ class Context:
 
     def gen_signal(self, re: torch.Tensor, im: torch.Tensor | None, layout: int, num_samples: int,
                    num_ants: int, ant_stride: int, block_stride: int, num_blocks: int, num_channels: int,
-                   params_dev: torch.Tensor, sampling_frequency: float):
+                   params_dev: torch.Tensor, sampling_frequency: float, amplitude: float = 1.0):
         rc = self.lib.gat_gen_signal(self._h, C.c_void_p(_ptr(re)), C.c_void_p(_ptr(im)), layout, num_samples,
                                      num_ants, ant_stride, block_stride, num_blocks, num_channels,
-                                     C.c_void_p(_ptr(params_dev)), float(sampling_frequency))
+                                     C.c_void_p(_ptr(params_dev)), float(sampling_frequency), float(amplitude))
         self.check(rc, "gat_gen_signal")
 
     def reduce_cplx_multi(self, in_re: torch.Tensor, in_im: torch.Tensor, n: int, cols: int,

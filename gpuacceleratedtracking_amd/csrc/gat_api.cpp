@@ -6,6 +6,7 @@
 //   splits   = workgroups per (block, channel, antenna tile): 1 once B*K*M/MT already fills the
 //              chip (>= 8 workgroups per CU), otherwise the block's samples are split and a
 //              finalize launch sums the per-split partials in fixed order.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -22,7 +23,7 @@ struct gat_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int8_t *d_codes = nullptr;
-    int Lc = 0, P = 0;
+    int Lc = 0, P = 0, code_row_stride = 0; // rows padded to a multiple of 16 bytes
     float *d_partial = nullptr;
     size_t partial_bytes = 0;
     gat_channel_params *d_params = nullptr;
@@ -30,7 +31,6 @@ struct gat_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timer_running = false;
     int num_cus = 256;
-    bool force_direct = false; // GAT_DIRECT_CHIPS=1: disable the LDS replica path (A/B experiments)
     std::string err;
     gat_launch_info last{};
 };
@@ -79,10 +79,10 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
 {
     if (!sig || !params_dev || !shifts || !out_re || !out_im) return fail(c, GAT_ERR_ARG, "null argument");
     if (!c->d_codes) return fail(c, GAT_ERR_STATE, "gat_set_codes has not been called");
-    if (sig->layout != GAT_LAYOUT_PLANAR && sig->layout != GAT_LAYOUT_INTERLEAVED)
-        return fail(c, GAT_ERR_ARG, "unknown signal layout");
-    const bool il = sig->layout == GAT_LAYOUT_INTERLEAVED;
-    if (!sig->re || (!il && !sig->im) || (il && sig->im))
+    const int fmt = sig->layout;
+    if (fmt < GAT_LAYOUT_PLANAR || fmt > GAT_LAYOUT_INTERLEAVED_I8) return fail(c, GAT_ERR_ARG, "unknown signal layout");
+    const bool planar = fmt == GAT_LAYOUT_PLANAR;
+    if (!sig->re || (planar && !sig->im) || (!planar && sig->im))
         return fail(c, GAT_ERR_ARG, "signal pointers do not match the layout");
     if (B < 1 || K < 1 || sig->num_ants < 1 || sig->num_samples < 1)
         return fail(c, GAT_ERR_ARG, "sizes must be positive");
@@ -105,19 +105,16 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         }
     const int AT = M / MT;
 
+    // 16-byte vector loads need every group start 16-byte aligned: plane bases and all strides
+    // multiples of the samples one 16-byte load holds (4 / 2 / 4 / 8 by format)
+    const int spv = dc_group_samples(4, fmt);
     int vec = 1;
-    if (!il) {
-        if (aligned16(sig->re) && aligned16(sig->im) && sig->ant_stride % 4 == 0 &&
-            sig->block_stride % 4 == 0 && sig->chan_stride % 4 == 0)
-            vec = 4;
-    } else {
-        if (aligned16(sig->re) && sig->ant_stride % 2 == 0 && sig->block_stride % 2 == 0 &&
-            sig->chan_stride % 2 == 0)
-            vec = 4;
-    }
+    if (aligned16(sig->re) && (!planar || aligned16(sig->im)) && sig->ant_stride % spv == 0 &&
+        sig->block_stride % spv == 0 && sig->chan_stride % spv == 0)
+        vec = 4;
 
     const long long N = sig->num_samples;
-    const long long chunk = dc_chunk(vec, il);
+    const long long chunk = dc_chunk(vec, fmt);
     const long long chunks = (N + chunk - 1) / chunk;
     const long long groups = (long long)B * K * AT;
     const long long target = 8ll * c->num_cus;
@@ -159,6 +156,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     a.B = B;
     a.Lc = c->Lc;
     a.num_prns = c->P;
+    a.code_row_stride = c->code_row_stride;
     a.splits = (int)splits;
     a.chunks_per_split = (int)cps;
     a.total_chunks = (int)chunks;
@@ -170,26 +168,37 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     DcLaunch cfg{};
     cfg.ant_tile = MT;
     cfg.vec = vec;
-    cfg.interleaved = il ? 1 : 0;
+    cfg.format = fmt;
     cfg.grid = (unsigned)grid_wgs;
     a.max_abs_shift = (int)max_shift;
 
-    for (int t0 = 0; t0 < L; t0 += kMaxTapsPerLaunch) {
-        cfg.taps = std::min(kMaxTapsPerLaunch, L - t0);
-        a.tap_off = t0;
-        for (int l = 0; l < kMaxTapsPerLaunch; ++l) a.shifts[l] = l < cfg.taps ? shifts[t0 + l] : 0;
-        // LDS replica segment: needs ascending taps (shifts[0] is the earliest) and a bounded span
-        long long span = (long long)a.shifts[cfg.taps - 1] - a.shifts[0];
-        bool ascending = true;
-        for (int l = 1; l < cfg.taps; ++l) ascending = ascending && a.shifts[l] >= a.shifts[l - 1];
-        cfg.replica = (ascending && span <= kMaxReplicaSpan && !c->force_direct) ? 1 : 0;
-        a.rep_span = cfg.replica ? (int)span : 0;
+    // Taps in any order: sort them, then cut the sorted list into launches of at most
+    // kMaxTapsPerLaunch taps whose span fits the LDS replica segment; tap_index maps each tap back
+    // to its position in the caller's list (a single-tap launch always fits: span 0).
+    int order[GAT_MAX_TAPS];
+    for (int l = 0; l < L; ++l) order[l] = l;
+    std::stable_sort(order, order + L, [&](int x, int y) { return shifts[x] < shifts[y]; });
+    int nlaunch = 0;
+    for (int t0 = 0; t0 < L;) {
+        int t1 = t0 + 1;
+        while (t1 < L && t1 - t0 < kMaxTapsPerLaunch &&
+               (long long)shifts[order[t1]] - shifts[order[t0]] <= kMaxReplicaSpan)
+            ++t1;
+        cfg.taps = t1 - t0;
+        for (int l = 0; l < kMaxTapsPerLaunch; ++l) {
+            a.shifts[l] = shifts[order[t0 + std::min(l, cfg.taps - 1)]];
+            a.tap_index[l] = order[t0 + std::min(l, cfg.taps - 1)];
+        }
+        a.rep_span = a.shifts[cfg.taps - 1] - a.shifts[0];
         const int slots = (int)((chunk + a.rep_span + 3) / 4);
-        a.rep_plane_stride = cfg.replica ? ((slots + 23) / 32) * 32 + 8 : 0; // >= slots, == 8 (mod 32)
+        a.rep_plane_stride = ((slots + 23) / 32) * 32 + 8; // >= slots, == 8 (mod 32)
         cfg.lds_bytes = (unsigned)(((c->Lc + 15) & ~15) + 4 * 64 * sizeof(float) +
                                    (size_t)2 * 4 * a.rep_plane_stride * sizeof(float));
         GAT_HIP(c, launch_dc(a, cfg, c->stream));
+        t0 = t1;
+        ++nlaunch;
     }
+    (void)nlaunch;
     const bool fin = !atomic && splits > 1;
     if (fin)
         GAT_HIP(c, launch_finalize(c->d_partial, out_re, out_im, (int)splits, L * M * 2, (long long)B * K,
@@ -237,7 +246,6 @@ GAT_API int32_t gat_create(int32_t device, void *hip_stream, gat_ctx **out_ctx)
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
-    if (const char *e = std::getenv("GAT_DIRECT_CHIPS")) c->force_direct = e[0] == '1';
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
         delete c;
         return -(int32_t)e;
@@ -318,9 +326,13 @@ GAT_API int32_t gat_set_codes(gat_ctx *c, const int8_t *codes_host, int32_t code
         GAT_HIP(c, hipFree(c->d_codes));
         c->d_codes = nullptr;
     }
-    const size_t bytes = (size_t)code_length * num_prns;
+    const int stride = (code_length + 15) & ~15; // 16-byte rows: dc_kernel stages them with 16-byte copies
+    const size_t bytes = (size_t)stride * num_prns;
     GAT_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->d_codes), bytes));
-    GAT_HIP(c, hipMemcpy(c->d_codes, codes_host, bytes, hipMemcpyHostToDevice));
+    GAT_HIP(c, hipMemset(c->d_codes, 0, bytes));
+    GAT_HIP(c, hipMemcpy2D(c->d_codes, (size_t)stride, codes_host, (size_t)code_length, (size_t)code_length,
+                           (size_t)num_prns, hipMemcpyHostToDevice));
+    c->code_row_stride = stride;
     c->Lc = code_length;
     c->P = num_prns;
     return GAT_OK;
@@ -395,24 +407,24 @@ GAT_API int32_t gat_gen_code_replica(gat_ctx *c, float *rep, int64_t count, int3
     if (!(fs > 0.0) || !std::isfinite(fc) || !std::isfinite(tau)) return fail(c, GAT_ERR_ARG, "bad frequency / phase");
     if (count + std::llabs((long long)first_shift) >= (1ll << 30)) return fail(c, GAT_ERR_RANGE, "replica too long");
     GAT_HIP(c, hipSetDevice(c->device));
-    GAT_HIP(c, launch_gen_code_replica(rep, count, c->d_codes + (size_t)prn * c->Lc, c->Lc, fc, fs, tau,
+    GAT_HIP(c, launch_gen_code_replica(rep, count, c->d_codes + (size_t)prn * c->code_row_stride, c->Lc, fc, fs, tau,
                                        first_shift, c->stream));
     return GAT_OK;
 }
 
-GAT_API int32_t gat_gen_signal(gat_ctx *c, float *re, float *im, int32_t layout, int64_t N, int32_t M,
+GAT_API int32_t gat_gen_signal(gat_ctx *c, void *re, void *im, int32_t layout, int64_t N, int32_t M,
                                int64_t ant_stride, int64_t block_stride, int32_t B, int32_t K,
-                               const gat_channel_params *params_dev, double fs)
+                               const gat_channel_params *params_dev, double fs, double amplitude)
 {
     if (!c || !re || !params_dev) return fail(c, GAT_ERR_ARG, "null argument");
     if (!c->d_codes) return fail(c, GAT_ERR_STATE, "gat_set_codes has not been called");
-    if (layout != GAT_LAYOUT_PLANAR && layout != GAT_LAYOUT_INTERLEAVED) return fail(c, GAT_ERR_ARG, "unknown layout");
+    if (layout < GAT_LAYOUT_PLANAR || layout > GAT_LAYOUT_INTERLEAVED_I8) return fail(c, GAT_ERR_ARG, "unknown layout");
     if ((layout == GAT_LAYOUT_PLANAR) != (im != nullptr)) return fail(c, GAT_ERR_ARG, "signal pointers do not match the layout");
     if (N < 1 || N >= (1ll << 30) || M < 1 || B < 1 || B > 65535 || K < 1) return fail(c, GAT_ERR_RANGE, "size out of range");
-    if (!(fs > 0.0)) return fail(c, GAT_ERR_ARG, "sampling frequency must be positive");
+    if (!(fs > 0.0) || !std::isfinite(amplitude)) return fail(c, GAT_ERR_ARG, "bad sampling frequency / amplitude");
     GAT_HIP(c, hipSetDevice(c->device));
-    GAT_HIP(c, launch_gen_signal(re, im, layout == GAT_LAYOUT_INTERLEAVED, N, M, ant_stride, block_stride, B, K,
-                                 params_dev, c->d_codes, c->Lc, c->P, fs, c->stream));
+    GAT_HIP(c, launch_gen_signal(re, im, layout, N, M, ant_stride, block_stride, B, K, params_dev, c->d_codes,
+                                 c->code_row_stride, c->Lc, c->P, fs, (float)amplitude, c->stream));
     return GAT_OK;
 }
 

@@ -14,42 +14,49 @@ constexpr int kMaxAntTile = 4;       // antennas handled by one workgroup
 constexpr int kMaxReplicaSpan = 2048; // largest tap span served from the LDS replica segment
 
 // Sample ownership of one lane per step in dc_kernel: G groups of S consecutive samples, one
-// 16-byte load per plane and group (vec == 4) or scalar loads (vec == 1).
+// 16-byte load per plane and group (vec == 4) or scalar loads (vec == 1).  S by format:
+// planar f32 4, interleaved ComplexF32 2, interleaved int16 4, interleaved int8 8.
 #ifndef GAT_PLANAR_GROUPS
 #define GAT_PLANAR_GROUPS 1
 #endif
-constexpr int dc_group_samples(int vec, bool il) { return vec == 4 ? (il ? 2 : 4) : 1; }
-constexpr int dc_groups(int vec, bool il) { return vec == 4 ? (il ? 2 : GAT_PLANAR_GROUPS) : 1; }
-constexpr int dc_chunk(int vec, bool il) { return kThreads * dc_group_samples(vec, il) * dc_groups(vec, il); }
+constexpr int dc_group_samples(int vec, int fmt)
+{
+    return vec != 4 ? 1 : fmt == GAT_LAYOUT_PLANAR ? 4 : fmt == GAT_LAYOUT_INTERLEAVED ? 2 : fmt == GAT_LAYOUT_INTERLEAVED_I16 ? 4 : 8;
+}
+constexpr int dc_groups(int vec, int fmt)
+{
+    return vec != 4 ? 1 : fmt == GAT_LAYOUT_PLANAR ? GAT_PLANAR_GROUPS : fmt == GAT_LAYOUT_INTERLEAVED ? 2 : 1;
+}
+constexpr int dc_chunk(int vec, int fmt) { return kThreads * dc_group_samples(vec, fmt) * dc_groups(vec, fmt); }
 
 // Arguments of the fused correlator kernel (passed by value in the kernarg segment).
 struct DcArgs {
-    const float *re;
-    const float *im;
+    const void *re;                   // planar: float re plane; interleaved formats: base pointer
+    const void *im;                   // planar: float im plane; otherwise unused
     const gat_channel_params *params; // dev, [B*K], channel fastest
-    const int8_t *codes;              // dev, [P][Lc]
+    const int8_t *codes;              // dev, [P][code_row_stride] (rows padded to 16 bytes)
     float *out_re;                    // dev, [B][K][Ltot][M]
     float *out_im;
     float *partial;                   // dev, [B*K][splits][Ltot*M*2] (splits > 1 only)
     long long N, ant_stride, block_stride, chan_stride;
     double fs;
-    int M, K, B, Lc, num_prns;
+    int M, K, B, Lc, num_prns, code_row_stride;
     int splits, chunks_per_split, total_chunks, ant_tiles;
-    int num_tiles; // B * ant_tiles * splits
-    int Ltot, tap_off;
+    int num_tiles;         // B * ant_tiles * splits
+    int Ltot;              // taps of the whole call (output indexing)
     int max_abs_shift;     // max |shift| over ALL taps of the call (range check)
     int rep_span;          // shifts[last] - shifts[0] of THIS launch's taps (replica halo)
     int rep_plane_stride;  // floats per replica plane (== 8 mod 32: conflict-free planes)
     unsigned flags;
-    int shifts[kMaxTapsPerLaunch];
+    int shifts[kMaxTapsPerLaunch];    // ascending
+    int tap_index[kMaxTapsPerLaunch]; // position of each tap in the caller's list
 };
 
 struct DcLaunch {
     int ant_tile; // MT
     int taps;     // L of this launch
     int vec;      // 4 or 1
-    int interleaved;
-    int replica; // 1: LDS replica segment shared by the taps; 0: direct chip evaluation
+    int format;   // GAT_LAYOUT_*
     unsigned grid;
     unsigned lds_bytes;
 };
@@ -61,10 +68,10 @@ hipError_t launch_finalize(const float *partial, float *out_re, float *out_im, i
 hipError_t launch_gen_code_replica(float *rep, long long count, const int8_t *code_row, int Lc,
                                    double fc, double fs, double tau, long long first_shift,
                                    hipStream_t s);
-hipError_t launch_gen_signal(float *re, float *im, int interleaved, long long N, int M,
+hipError_t launch_gen_signal(void *re, void *im, int format, long long N, int M,
                              long long ant_stride, long long block_stride, int B, int K,
-                             const gat_channel_params *params, const int8_t *codes, int Lc,
-                             int num_prns, double fs, hipStream_t s);
+                             const gat_channel_params *params, const int8_t *codes, int code_row_stride,
+                             int Lc, int num_prns, double fs, float amplitude, hipStream_t s);
 hipError_t launch_reduce_stage1(const float *in_re, const float *in_im, long long n, int cols,
                                 int chunks, float *partial, hipStream_t s);
 bool dc_supported(int ant_tile, int taps);

@@ -123,20 +123,86 @@ __device__ __forceinline__ float wave_sum(float v)
 // ------------------------------------------------------------------------------------------
 // fused downconvert + correlate
 // ------------------------------------------------------------------------------------------
-// REP = true: the chips of one step are generated ONCE per workgroup into an LDS replica
-// segment [CHUNK + num_of_shifts] (what gen_code_replica! materialises in global memory in
-// the reference, src/algorithms.jl:752-758) and every tap reads it at its own offset, so a
-// step costs (CHUNK + shifts)/256 = ~4.1 FP64 code-phase evaluations per lane instead of
-// S*G*L = 12.  The segment is stored as 4 interleaved planes (element i at plane i&3, slot
-// i>>2) so that the lanes of a wave, which own samples 4*lane + j, read consecutive dwords.
-// REP = false: every (sample, tap) chip is evaluated directly (huge tap spans).
-template <int MT, int L, int VEC, bool IL, bool REP>
+// The chips of one step are generated ONCE per workgroup into an LDS replica segment
+// [CHUNK + span of the taps] (what gen_code_replica! materialises in global memory in the
+// reference, src/algorithms.jl:752-758) and every tap reads it at its own offset, so a step costs
+// (CHUNK + span)/256 = ~4.1 FP64 code-phase evaluations per lane instead of samples*taps = 12.
+// The segment is stored as 4 interleaved planes (element i at plane i&3, slot i>>2) so that
+// the lanes of a wave, which own samples 4*lane + j, read consecutive dwords (no bank conflict).
+//
+// FMT: sample format of the signal (GAT_LAYOUT_*): planar f32, interleaved ComplexF32,
+// interleaved int16 pairs, interleaved int8 pairs.  VEC = 4: one 16-byte non-temporal load per
+// lane, plane and group (4 / 2 / 4 / 8 complex samples); VEC = 1: scalar loads (unaligned input).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <int FMT>
+struct SampleIO {
+    // number of 16-byte vectors per antenna and group
+    static constexpr int NV = (FMT == GAT_LAYOUT_PLANAR) ? 2 : 1;
+    // bytes of one complex sample
+    static constexpr int BYTES = (FMT == GAT_LAYOUT_INTERLEAVED_I16) ? 4 : (FMT == GAT_LAYOUT_INTERLEAVED_I8) ? 2 : 8;
+
+    // 16-byte loads of the group starting at complex-sample index e
+    static __device__ __forceinline__ void load16(i32x4 (&raw)[NV], const void *re, const void *im, size_t e)
+    {
+        if constexpr (FMT == GAT_LAYOUT_PLANAR) {
+            raw[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(static_cast<const float *>(re) + e));
+            raw[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(static_cast<const float *>(im) + e));
+        } else {
+            raw[0] = __builtin_nontemporal_load(
+                reinterpret_cast<const i32x4 *>(static_cast<const unsigned char *>(re) + e * BYTES));
+        }
+    }
+    // sample j of a loaded group
+    static __device__ __forceinline__ void get(const i32x4 (&raw)[NV], int j, float &xr, float &xi)
+    {
+        // NOTE: copy the vector element into a scalar BEFORE the bit cast: __builtin_bit_cast applied
+        // directly to an ext-vector element lvalue reads element 0 whatever the index (hipcc 7.2).
+        if constexpr (FMT == GAT_LAYOUT_PLANAR) {
+            const int wr_ = raw[0][j], wi_ = raw[1][j];
+            xr = __int_as_float(wr_);
+            xi = __int_as_float(wi_);
+        } else if constexpr (FMT == GAT_LAYOUT_INTERLEAVED) {
+            const int wr_ = raw[0][2 * j], wi_ = raw[0][2 * j + 1];
+            xr = __int_as_float(wr_);
+            xi = __int_as_float(wi_);
+        } else if constexpr (FMT == GAT_LAYOUT_INTERLEAVED_I16) {
+            const int w = raw[0][j]; // {re: low half, im: high half}, little endian
+            xr = (float)(short)(w & 0xffff);
+            xi = (float)(w >> 16);
+        } else {
+            const int w = raw[0][j >> 1] >> ((j & 1) * 16); // two complex int8 samples per dword
+            xr = (float)(signed char)(w & 0xff);
+            xi = (float)(signed char)((w >> 8) & 0xff);
+        }
+    }
+    // one sample with scalar loads
+    static __device__ __forceinline__ void load1(const void *re, const void *im, size_t e, float &xr, float &xi)
+    {
+        if constexpr (FMT == GAT_LAYOUT_PLANAR) {
+            xr = static_cast<const float *>(re)[e];
+            xi = static_cast<const float *>(im)[e];
+        } else if constexpr (FMT == GAT_LAYOUT_INTERLEAVED) {
+            xr = static_cast<const float *>(re)[2 * e];
+            xi = static_cast<const float *>(re)[2 * e + 1];
+        } else if constexpr (FMT == GAT_LAYOUT_INTERLEAVED_I16) {
+            xr = (float)static_cast<const short *>(re)[2 * e];
+            xi = (float)static_cast<const short *>(re)[2 * e + 1];
+        } else {
+            xr = (float)static_cast<const signed char *>(re)[2 * e];
+            xi = (float)static_cast<const signed char *>(re)[2 * e + 1];
+        }
+    }
+};
+
+template <int MT, int L, int VEC, int FMT>
 __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int8_t *s_code = reinterpret_cast<int8_t *>(smem);
     float *s_part = reinterpret_cast<float *>(smem + ((a.Lc + 15) & ~15)); // [4][64]
     float *s_rep = s_part + 4 * 64;                                        // [2][4][rep_ps]
+    using IO = SampleIO<FMT>;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -173,9 +239,10 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
                      !(span < 2097152.0 * (double)Lc) || !(ratio >= 0.0) || !(step == step) || !(phi == phi);
     const int prn = (P.prn < 0 || P.prn >= a.num_prns) ? 0 : P.prn;
 
-    {
-        const int8_t *g = a.codes + (size_t)prn * Lc;
-        for (int i = tid; i < Lc; i += kThreads) s_code[i] = g[i];
+    { // stage this PRN's chip table: rows are padded to 16 bytes on the device -> 16-byte copies
+        const i32x4 *g = reinterpret_cast<const i32x4 *>(a.codes + (size_t)prn * a.code_row_stride);
+        i32x4 *d = reinterpret_cast<i32x4 *>(s_code);
+        for (int i = tid; i < (Lc + 15) / 16; i += kThreads) d[i] = g[i];
     }
     __syncthreads();
 
@@ -191,73 +258,55 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
     const size_t base = (size_t)b * a.block_stride + (size_t)k * a.chan_stride +
                         (size_t)(at * MT) * a.ant_stride;
     // A lane owns G groups of S consecutive samples per step; one group = one 16-byte load per
-    // plane (planar: 4 samples; interleaved ComplexF32: 2 samples), so every wave-instruction
-    // covers 1 KiB of contiguous memory in both layouts.
-    constexpr int S = dc_group_samples(VEC, IL);
-    constexpr int G = dc_groups(VEC, IL);
+    // plane, so every wave-instruction covers 1 KiB of contiguous memory in every format.
+    constexpr int S = dc_group_samples(VEC, FMT);
+    constexpr int G = dc_groups(VEC, FMT);
     constexpr int GSTRIDE = kThreads * S;
     constexpr int CHUNK = GSTRIDE * G;
-    static_assert(CHUNK == dc_chunk(VEC, IL), "host and device disagree on the chunk size");
+    static_assert(CHUNK == dc_chunk(VEC, FMT), "host and device disagree on the chunk size");
     const int c_begin = split * a.chunks_per_split;
     const int c_end = bad ? c_begin : min(c_begin + a.chunks_per_split, a.total_chunks);
     const int shift0 = a.shifts[0];
     const int rep_ps = a.rep_plane_stride;
     const int rep_cnt = CHUNK + a.rep_span; // entries of one replica segment
 
-    // chips of sample n (block-relative) for the L taps; rel = n - chunk start, rep = this step's segment
-    auto get_chips = [&](float (&chip)[L], int n, int rel, const float *rep) {
+    // chips of the sample at chunk-relative position rel, for the L taps
+    auto get_chips = [&](float (&chip)[L], int rel, const float *rep) {
 #pragma unroll
         for (int l = 0; l < L; ++l) {
-            if constexpr (REP) {
-                const int i = rel + (a.shifts[l] - shift0);
-                chip[l] = rep[(i & 3) * rep_ps + (i >> 2)];
-            } else {
-                chip[l] = (float)s_code[chip_index(ratio, tau, n + a.shifts[l], Lc, inv_lc)];
-            }
+            const int i = rel + (a.shifts[l] - shift0);
+            chip[l] = rep[(i & 3) * rep_ps + (i >> 2)];
         }
     };
-    // one sample: carrier (cr, ci), chips, MT antennas
-    auto accumulate = [&](const float (&xr)[MT], const float (&xi)[MT], float cr, float ci, const float (&chip)[L]) {
+    // one sample of one antenna: conj(carrier) wipe-off (src/algorithms.jl:175-176), L taps
+    auto accumulate = [&](int m, float xr, float xi, float cr, float ci, const float (&chip)[L]) {
+        const float dr = __builtin_fmaf(xr, cr, xi * ci);
+        const float di = __builtin_fmaf(xi, cr, -(xr * ci));
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            // conj(carrier) wipe-off, src/algorithms.jl:175-176
-            const float dr = __builtin_fmaf(xr[m], cr, xi[m] * ci);
-            const float di = __builtin_fmaf(xi[m], cr, -(xr[m] * ci));
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
-                acc_re[m][l] = __builtin_fmaf(chip[l], dr, acc_re[m][l]);
-                acc_im[m][l] = __builtin_fmaf(chip[l], di, acc_im[m][l]);
-            }
+        for (int l = 0; l < L; ++l) {
+            acc_re[m][l] = __builtin_fmaf(chip[l], dr, acc_re[m][l]);
+            acc_im[m][l] = __builtin_fmaf(chip[l], di, acc_im[m][l]);
         }
     };
-    auto load_group = [&](float (&xr)[S][MT], float (&xi)[S][MT], int n) {
+    auto load_group = [&](i32x4 (&raw)[MT][IO::NV], int n) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const size_t e = base + (size_t)m * a.ant_stride + n;
-            if constexpr (VEC == 4 && !IL) {
-                const f32x4 vr = load_stream16(a.re + e);
-                const f32x4 vi = load_stream16(a.im + e);
-                xr[0][m] = vr.x; xr[1][m] = vr.y; xr[2][m] = vr.z; xr[3][m] = vr.w;
-                xi[0][m] = vi.x; xi[1][m] = vi.y; xi[2][m] = vi.z; xi[3][m] = vi.w;
-            } else if constexpr (VEC == 4 && IL) {
-                const f32x4 v = load_stream16(a.re + 2 * e);
-                xr[0][m] = v.x; xi[0][m] = v.y; xr[1][m] = v.z; xi[1][m] = v.w;
-            } else {
-                xr[0][m] = IL ? a.re[2 * e] : a.re[e];
-                xi[0][m] = IL ? a.re[2 * e + 1] : a.im[e];
-            }
-        }
+        for (int m = 0; m < MT; ++m) IO::load16(raw[m], a.re, a.im, base + (size_t)m * a.ant_stride + n);
     };
     // S consecutive samples starting at n: one FP64 carrier anchor, then S-1 rotations
-    auto process_group = [&](const float (&xr)[S][MT], const float (&xi)[S][MT], int n, int rel, const float *rep) {
+    auto process_group = [&](const i32x4 (&raw)[MT][IO::NV], int n, int rel, const float *rep) {
         float cr, ci;
         const double th0 = __builtin_fma((double)n, step, phi);
         sincos_cycles(th0 - __builtin_rint(th0), cr, ci);
 #pragma unroll
         for (int j = 0; j < S; ++j) {
             float chip[L];
-            get_chips(chip, n + j, rel + j, rep);
-            accumulate(xr[j], xi[j], cr, ci, chip);
+            get_chips(chip, rel + j, rep);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                float xr, xi;
+                IO::get(raw[m], j, xr, xi);
+                accumulate(m, xr, xi, cr, ci, chip);
+            }
             if (j + 1 < S) {
                 const float t = __builtin_fmaf(cr, wr, -(ci * wi));
                 ci = __builtin_fmaf(cr, wi, ci * wr);
@@ -265,21 +314,19 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
             }
         }
     };
-    // ragged end of a block: samples [n_lo, N), fewer than S of them, scalar loads
-    auto scalar_tail = [&](int n_lo, int rel, const float *rep) {
-        for (int n = n_lo; n < N; ++n, ++rel) {
-            float xr[MT], xi[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const size_t e = base + (size_t)m * a.ant_stride + n;
-                xr[m] = IL ? a.re[2 * e] : a.re[e];
-                xi[m] = IL ? a.re[2 * e + 1] : a.im[e];
-            }
+    // samples [n_lo, n_hi) one at a time with scalar loads (ragged block end, unaligned input)
+    auto scalar_run = [&](int n_lo, int n_hi, int rel, const float *rep) {
+        for (int n = n_lo; n < n_hi; ++n, ++rel) {
             const double th = __builtin_fma((double)n, step, phi);
             float cr, ci, chip[L];
             sincos_cycles(th - __builtin_rint(th), cr, ci);
-            get_chips(chip, n, rel, rep);
-            accumulate(xr, xi, cr, ci, chip);
+            get_chips(chip, rel, rep);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                float xr, xi;
+                IO::load1(a.re, a.im, base + (size_t)m * a.ant_stride + n, xr, xi);
+                accumulate(m, xr, xi, cr, ci, chip);
+            }
         }
     };
     // this step's replica segment: entry i <-> sample c*CHUNK + shift0 + i (src/algorithms.jl:753-757)
@@ -293,30 +340,26 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
         const int rel0 = tid * S;
         const int cb = c * CHUNK + rel0;
         float *rep = s_rep + ((c - c_begin) & 1) * 4 * rep_ps; // double-buffered: one barrier per step
-        if (c * CHUNK + CHUNK <= N) { // whole chunk inside the block: issue every load first
-            float xr[G][S][MT], xi[G][S][MT];
+        if (VEC == 4 && c * CHUNK + CHUNK <= N) { // whole chunk inside the block: issue every load first
+            i32x4 raw[G][MT][IO::NV];
 #pragma unroll
-            for (int g = 0; g < G; ++g) load_group(xr[g], xi[g], cb + g * GSTRIDE);
-            if constexpr (REP) { // generated while the loads are in flight
-                fill_replica(rep, c);
-                __syncthreads();
-            }
+            for (int g = 0; g < G; ++g) load_group(raw[g], cb + g * GSTRIDE);
+            fill_replica(rep, c); // generated while the loads are in flight
+            __syncthreads();
 #pragma unroll
-            for (int g = 0; g < G; ++g) process_group(xr[g], xi[g], cb + g * GSTRIDE, rel0 + g * GSTRIDE, rep);
+            for (int g = 0; g < G; ++g) process_group(raw[g], cb + g * GSTRIDE, rel0 + g * GSTRIDE, rep);
         } else {
-            if constexpr (REP) {
-                fill_replica(rep, c);
-                __syncthreads();
-            }
+            fill_replica(rep, c);
+            __syncthreads();
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const int n = cb + g * GSTRIDE;
-                if (n + S <= N) {
-                    float xr[S][MT], xi[S][MT];
-                    load_group(xr, xi, n);
-                    process_group(xr, xi, n, rel0 + g * GSTRIDE, rep);
-                } else if (S > 1 && n < N) {
-                    scalar_tail(n, rel0 + g * GSTRIDE, rep);
+                if (VEC == 4 && n + S <= N) {
+                    i32x4 raw[MT][IO::NV];
+                    load_group(raw, n);
+                    process_group(raw, n, rel0 + g * GSTRIDE, rep);
+                } else if (n < N) {
+                    scalar_run(n, min(n + S, N), rel0 + g * GSTRIDE, rep);
                 }
             }
         }
@@ -346,7 +389,7 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
         const int comp = tid & 1;
         const int ml = tid >> 1;
         const int m = at * MT + (ml % MT);
-        const int l = a.tap_off + ml / MT;
+        const int l = a.tap_index[ml / MT]; // position of this tap in the caller's shift list
         const size_t bk = (size_t)b * a.K + k;
         const size_t o = (bk * a.Ltot + l) * a.M + m;
         if (a.flags & GAT_FLAG_ATOMIC) {
@@ -400,11 +443,12 @@ code_replica_kernel(float *__restrict__ rep, long long count, const int8_t *__re
 
 // gen_signal! (src/gen_signal.jl:64-70, :86-90): Float64 code phase, carrier phase evaluated in
 // Float64 then rounded to Float32 BEFORE cos/sin (src/gen_signal.jl:88), identical antennas.
+// `amplitude` scales the sum (1 = the reference); integer formats store rint(value) saturated.
 __global__ void __launch_bounds__(kThreads)
-gen_signal_kernel(float *__restrict__ re, float *__restrict__ im, int interleaved, long long N,
+gen_signal_kernel(void *__restrict__ re_v, void *__restrict__ im_v, int format, long long N,
                   int M, long long ant_stride, long long block_stride, int K,
                   const gat_channel_params *__restrict__ params, const int8_t *__restrict__ codes,
-                  int Lc, int num_prns, double fs)
+                  int code_row_stride, int Lc, int num_prns, double fs, float amplitude)
 {
     const int b = blockIdx.y;
     const float inv_lc = 1.0f / (float)Lc;
@@ -415,7 +459,7 @@ gen_signal_kernel(float *__restrict__ re, float *__restrict__ im, int interleave
             const gat_channel_params P = params[(size_t)b * K + k];
             const int prn = (P.prn < 0 || P.prn >= num_prns) ? 0 : P.prn;
             const double ratio = P.code_freq_hz / fs;
-            const float chip = (float)codes[(size_t)prn * Lc +
+            const float chip = (float)codes[(size_t)prn * code_row_stride +
                                             chip_index(ratio, P.code_phase_chips, (int)n, Lc, inv_lc)];
             // 2pi * n * f / fs + phase, left to right as the reference broadcasts it
             const double ph64 = __dadd_rn(__ddiv_rn(__dmul_rn(__dmul_rn(6.283185307179586, (double)n), P.carrier_freq_hz), fs),
@@ -424,14 +468,22 @@ gen_signal_kernel(float *__restrict__ re, float *__restrict__ im, int interleave
             sr = __builtin_fmaf(cosf(ph), chip, sr);
             si = __builtin_fmaf(sinf(ph), chip, si);
         }
+        sr *= amplitude;
+        si *= amplitude;
         for (int m = 0; m < M; ++m) {
             const size_t e = (size_t)b * block_stride + (size_t)m * ant_stride + n;
-            if (interleaved) {
-                re[2 * e] = sr;
-                re[2 * e + 1] = si;
+            if (format == GAT_LAYOUT_PLANAR) {
+                static_cast<float *>(re_v)[e] = sr;
+                static_cast<float *>(im_v)[e] = si;
+            } else if (format == GAT_LAYOUT_INTERLEAVED) {
+                static_cast<float *>(re_v)[2 * e] = sr;
+                static_cast<float *>(re_v)[2 * e + 1] = si;
+            } else if (format == GAT_LAYOUT_INTERLEAVED_I16) {
+                static_cast<short *>(re_v)[2 * e] = (short)fminf(fmaxf(rintf(sr), -32768.f), 32767.f);
+                static_cast<short *>(re_v)[2 * e + 1] = (short)fminf(fmaxf(rintf(si), -32768.f), 32767.f);
             } else {
-                re[e] = sr;
-                im[e] = si;
+                static_cast<signed char *>(re_v)[2 * e] = (signed char)fminf(fmaxf(rintf(sr), -128.f), 127.f);
+                static_cast<signed char *>(re_v)[2 * e + 1] = (signed char)fminf(fmaxf(rintf(si), -128.f), 127.f);
             }
         }
     }
@@ -476,20 +528,16 @@ template <int MT, int L>
 static hipError_t launch_dc_ml(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
 {
     const dim3 grid(cfg.grid), block(kThreads);
-#define GAT_LAUNCH(V, I, R) hipLaunchKernelGGL((dc_kernel<MT, L, V, I, R>), grid, block, cfg.lds_bytes, s, a)
-    if (cfg.vec == 4) {
-        if (cfg.interleaved) {
-            if (cfg.replica) GAT_LAUNCH(4, true, true); else GAT_LAUNCH(4, true, false);
-        } else {
-            if (cfg.replica) GAT_LAUNCH(4, false, true); else GAT_LAUNCH(4, false, false);
-        }
-    } else {
-        if (cfg.interleaved) {
-            if (cfg.replica) GAT_LAUNCH(1, true, true); else GAT_LAUNCH(1, true, false);
-        } else {
-            if (cfg.replica) GAT_LAUNCH(1, false, true); else GAT_LAUNCH(1, false, false);
-        }
+#define GAT_LAUNCH(V, F) hipLaunchKernelGGL((dc_kernel<MT, L, V, F>), grid, block, cfg.lds_bytes, s, a)
+#define GAT_LAUNCH_V(F) do { if (cfg.vec == 4) GAT_LAUNCH(4, F); else GAT_LAUNCH(1, F); } while (0)
+    switch (cfg.format) {
+    case GAT_LAYOUT_PLANAR: GAT_LAUNCH_V(GAT_LAYOUT_PLANAR); break;
+    case GAT_LAYOUT_INTERLEAVED: GAT_LAUNCH_V(GAT_LAYOUT_INTERLEAVED); break;
+    case GAT_LAYOUT_INTERLEAVED_I16: GAT_LAUNCH_V(GAT_LAYOUT_INTERLEAVED_I16); break;
+    case GAT_LAYOUT_INTERLEAVED_I8: GAT_LAUNCH_V(GAT_LAYOUT_INTERLEAVED_I8); break;
+    default: return hipErrorInvalidValue;
     }
+#undef GAT_LAUNCH_V
 #undef GAT_LAUNCH
     return hipGetLastError();
 }
@@ -547,16 +595,16 @@ hipError_t launch_gen_code_replica(float *rep, long long count, const int8_t *co
     return hipGetLastError();
 }
 
-hipError_t launch_gen_signal(float *re, float *im, int interleaved, long long N, int M,
+hipError_t launch_gen_signal(void *re, void *im, int format, long long N, int M,
                              long long ant_stride, long long block_stride, int B, int K,
-                             const gat_channel_params *params, const int8_t *codes, int Lc,
-                             int num_prns, double fs, hipStream_t s)
+                             const gat_channel_params *params, const int8_t *codes, int code_row_stride,
+                             int Lc, int num_prns, double fs, float amplitude, hipStream_t s)
 {
     long long bx = (N + kThreads - 1) / kThreads;
     if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(gen_signal_kernel, dim3((unsigned)bx, (unsigned)B), dim3(kThreads), 0, s, re,
-                       im, interleaved, N, M, ant_stride, block_stride, K, params, codes, Lc,
-                       num_prns, fs);
+                       im, format, N, M, ant_stride, block_stride, K, params, codes, code_row_stride, Lc,
+                       num_prns, fs, amplitude);
     return hipGetLastError();
 }
 

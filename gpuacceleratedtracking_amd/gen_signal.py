@@ -60,12 +60,18 @@ def make_params(prn, code_frequency, carrier_frequency, code_phase, carrier_phas
     return out
 
 
+_LAYOUT_DTYPE = {_lib.GAT_LAYOUT_INTERLEAVED: torch.float32, _lib.GAT_LAYOUT_INTERLEAVED_I16: torch.int16,
+                 _lib.GAT_LAYOUT_INTERLEAVED_I8: torch.int8}
+
+
 def gen_signal_stream(system: GNSSSystem, params: np.ndarray, sampling_frequency: float, num_samples: int,
-                      num_ants: int = 1, layout: int = _lib.GAT_LAYOUT_PLANAR, device=None):
+                      num_ants: int = 1, layout: int = _lib.GAT_LAYOUT_PLANAR, device=None,
+                      amplitude: float = 1.0):
     """Batched form used by the stream benchmark: ``params`` is [B, K] (carrier phase in
     RADIANS, as ``start_carrier_phase`` in src/gen_signal.jl:88); block b holds the sum of its K
-    channels.  Returns float32 tensors: planar (re [M, B*N], im [M, B*N]); interleaved
-    (x [M, B*N, 2], None)."""
+    channels times ``amplitude``.  Returns tensors: planar (re [M, B*N], im [M, B*N]) float32;
+    interleaved layouts (x [M, B*N, 2], None) of float32 / int16 / int8 (integer layouts store
+    ``rint(amplitude * x)`` saturated -- what an ADC front-end delivers)."""
     ctx = get_context(device)
     ctx.set_codes(system.codes)
     params = np.ascontiguousarray(params, dtype=_lib.PARAMS_DTYPE)
@@ -78,10 +84,10 @@ def gen_signal_stream(system: GNSSSystem, params: np.ndarray, sampling_frequency
         re = torch.empty((m, B * num_samples), dtype=torch.float32, device=ctx.device)
         im = torch.empty_like(re)
     else:
-        re = torch.empty((m, B * num_samples, 2), dtype=torch.float32, device=ctx.device)
+        re = torch.empty((m, B * num_samples, 2), dtype=_LAYOUT_DTYPE[layout], device=ctx.device)
         im = None
     ctx.gen_signal(re, im, layout, num_samples, m, B * num_samples, num_samples, B, K, dparams,
-                   sampling_frequency)
+                   sampling_frequency, amplitude)
     return re, im
 
 

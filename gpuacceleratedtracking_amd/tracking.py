@@ -26,32 +26,43 @@ from .gen_signal import StructSignal, make_params
 from .signals import GNSSSystem, get_code_frequency
 
 
+_DTYPE_LAYOUT = {torch.float32: _lib.GAT_LAYOUT_INTERLEAVED, torch.int16: _lib.GAT_LAYOUT_INTERLEAVED_I16,
+                 torch.int8: _lib.GAT_LAYOUT_INTERLEAVED_I8}
+
+
 def _signal_desc(re: torch.Tensor, im: torch.Tensor | None, num_samples: int, start: int = 0,
                  block_stride: int | None = None, per_channel: bool = False) -> _lib.SignalDesc:
-    """Describe a planar [(...K,) M, Ntot] (or interleaved [(K,) M, Ntot, 2]) tensor pair."""
+    """Describe a planar float32 pair [(K,) M, Ntot] or an interleaved tensor [(K,) M, Ntot, 2] of
+    float32 (ComplexF32), int16 or int8 {re, im} pairs."""
     il = im is None
     t = re
+    if not t.is_cuda:
+        raise ValueError("signal must live on the HIP device")
     if il:
+        if t.dtype not in _DTYPE_LAYOUT:
+            raise ValueError("interleaved signal must be float32, int16 or int8")
         if t.shape[-1] != 2 or t.stride(-1) != 1 or t.stride(-2) != 2:
             raise ValueError("interleaved signal must be [..., N, 2] with unit inner strides")
         dims = t.dim() - 1
         stride = lambda d: t.stride(d - 1) // 2  # noqa: E731  (in complex samples)
         ntot = t.shape[-2]
+        layout = _DTYPE_LAYOUT[t.dtype]
     else:
+        if t.dtype != torch.float32 or im.dtype != torch.float32:
+            raise ValueError("planar signal planes must be float32")
         if t.stride(-1) != 1 or im.stride() != t.stride() or im.shape != t.shape:
             raise ValueError("planar signal planes must be sample-contiguous with equal strides")
         dims = t.dim()
         stride = lambda d: t.stride(d)  # noqa: E731
         ntot = t.shape[-1]
-    if t.dtype != torch.float32 or not t.is_cuda:
-        raise ValueError("signal must be float32 on the HIP device")
+        layout = _lib.GAT_LAYOUT_PLANAR
     if start < 0 or start + num_samples > ntot:
         raise ValueError("signal_start_sample/num_samples outside the signal")
     d = _lib.SignalDesc()
-    off = start * (8 if il else 4)
+    off = start * (_lib.SAMPLE_BYTES[layout] if il else 4)
     d.re = t.data_ptr() + off
     d.im = None if il else im.data_ptr() + off
-    d.layout = _lib.GAT_LAYOUT_INTERLEAVED if il else _lib.GAT_LAYOUT_PLANAR
+    d.layout = layout
     d.num_samples = num_samples
     d.num_ants = t.shape[dims - 2] if dims >= 2 else 1
     d.ant_stride = stride(-2) if dims >= 2 else ntot

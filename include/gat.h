@@ -51,10 +51,12 @@ extern "C" {
                            /* src/algorithms.jl:625-632); default = deterministic two-stage */
 
 /* ---- signal layouts ---------------------------------------------------------------------- */
-#define GAT_LAYOUT_PLANAR 0      /* re[] and im[] planes (reference StructArray layout)       */
-#define GAT_LAYOUT_INTERLEAVED 1 /* ComplexF32 {re,im} pairs; .im must be NULL                */
+#define GAT_LAYOUT_PLANAR 0          /* float32 re[] and im[] planes (reference StructArray)   */
+#define GAT_LAYOUT_INTERLEAVED 1     /* ComplexF32 {re,im} pairs; .im must be NULL             */
+#define GAT_LAYOUT_INTERLEAVED_I16 2 /* {int16 re, int16 im} pairs (front-end "sc16"), 4 B/sample */
+#define GAT_LAYOUT_INTERLEAVED_I8 3  /* {int8 re, int8 im} pairs (front-end "sc8"), 2 B/sample  */
 
-#define GAT_MAX_TAPS 32 /* correlator taps per call (L); reference uses 3 and 7           */
+#define GAT_MAX_TAPS 32 /* correlator taps per call (L), any order; reference uses 3 and 7 */
 
 typedef struct gat_ctx gat_ctx;
 
@@ -75,8 +77,8 @@ typedef struct gat_channel_params {
  * handed to kernel_algorithm (src/algorithms.jl:887-888) -- element (n, m, b, k) lives at
  *   n + m*ant_stride + b*block_stride + k*chan_stride          (in samples). */
 typedef struct gat_signal_desc {
-    const float *re;      /* dev; planar: real plane. interleaved: ComplexF32 base            */
-    const float *im;      /* dev; planar: imaginary plane. interleaved: NULL                  */
+    const void *re;       /* dev; planar: float real plane. interleaved formats: base pointer */
+    const void *im;       /* dev; planar: float imaginary plane. interleaved formats: NULL    */
     int32_t layout;       /* GAT_LAYOUT_*                                                     */
     int32_t num_ants;     /* M                                                                */
     int64_t num_samples;  /* N per integration block                                          */
@@ -167,11 +169,14 @@ GAT_API int32_t gat_gen_code_replica(gat_ctx *ctx, float *replica_dev, int64_t c
  * antenna.  Writes, for every block b, x[n,m,b] = sum_k c_k[floor(fc_k/fs*n + tau_kb) mod Lc]
  *   * (cos, sin)(float32(2pi*n*f_kb/fs + phase_kb)).  NOTE: for THIS call the
  * carrier_phase_cycles field is interpreted in RADIANS, as start_carrier_phase is in the
- * reference (src/gen_signal.jl:88).  params_dev: [num_channels x num_blocks]. */
-GAT_API int32_t gat_gen_signal(gat_ctx *ctx, float *re_dev, float *im_dev, int32_t layout,
+ * reference (src/gen_signal.jl:88).  params_dev: [num_channels x num_blocks].  `amplitude`
+ * scales the sum (1.0 = the reference); the integer layouts store rint(amplitude * x),
+ * saturated -- e.g. amplitude 2000 for int16, 40 for int8. */
+GAT_API int32_t gat_gen_signal(gat_ctx *ctx, void *re_dev, void *im_dev, int32_t layout,
                                int64_t num_samples, int32_t num_ants, int64_t ant_stride,
                                int64_t block_stride, int32_t num_blocks, int32_t num_channels,
-                               const gat_channel_params *params_dev, double sampling_freq_hz);
+                               const gat_channel_params *params_dev, double sampling_freq_hz,
+                               double amplitude);
 
 /* reduce_cplx_multi_3/4/5 two-pass sum (src/reduction.jl:93, :331, :548; launch sequence
  * src/algorithms.jl:914-922): column sums of a planar complex [n x num_cols] array.

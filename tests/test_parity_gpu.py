@@ -307,3 +307,67 @@ def test_run_kernel_benchmark(gat):
         assert key in r
     assert r["algorithm"] == "4_4_cplx_multi_textmem" and r["Minimum"] > 0
     assert np.allclose(r["accumulators"][:, 0], [1024, 2048, 1024], rtol=1e-5)
+
+
+# ---- "next" row 1: packed integer IF samples (int16 / int8 {re, im} pairs) -------------------------
+def _quantised_case(seed, dtype, amp, **kw):
+    case = make_case(seed, **kw)
+    lim = np.iinfo(dtype)
+    q_re = np.clip(np.rint(case["re"] * amp), lim.min, lim.max).astype(dtype)
+    q_im = np.clip(np.rint(case["im"] * amp), lim.min, lim.max).astype(dtype)
+    case["re"], case["im"] = q_re.astype(np.float32), q_im.astype(np.float32)  # what the oracle sees (exact)
+    return case, np.stack([q_re, q_im], axis=-1)  # [M, B*N, 2]
+
+
+@pytest.mark.parametrize("dtype,amp", [(np.int16, 3000.0), (np.int8, 25.0)])
+@pytest.mark.parametrize("cfg", [("GPSL1", 20000, 4, 3, 1, 3), ("GPSL1", 4099, 2, 3, 2, 2), ("GPSL5", 32768, 1, 5, 2, 1),
+                                 ("GPSL1", 8, 3, 7, 1, 2)], ids=lambda c: f"{c[0]}-N{c[1]}-M{c[2]}-L{c[3]}-K{c[4]}-B{c[5]}")
+def test_int_ingest_parity(gat, cfg, dtype, amp):
+    import torch
+    g = gat
+    system, N, M, L, K, B = cfg
+    case, q = _quantised_case(zlib.crc32(repr(cfg).encode()), dtype, amp / K, system=system, N=N, M=M, L=L, K=K, B=B)
+    ref = oracle_result(case)
+    dev = g.get_context().device
+    sysobj = g.GNSSDICT[system](use_gpu=True)
+    prm = g.make_params(case["prm"]["prn0"], case["prm"]["code_freq_hz"], case["prm"]["carrier_freq_hz"],
+                        case["prm"]["code_phase_chips"], case["prm"]["carrier_phase_cycles"])
+    for mis in (0, 1):
+        x = torch.from_numpy(q).to(dev)
+        if mis:
+            pad = torch.zeros((M, mis, 2), dtype=x.dtype, device=dev)
+            x = torch.cat([pad, x], dim=1)[:, mis:]
+        op = g.StreamCorrelator(sysobj, N, M, B, K, case["shifts"], case["fs"])
+        op.set_params(prm)
+        op(x, None)
+        spv = 4 if dtype == np.int16 else 8
+        assert op.ctx.last_launch_info()["vec"] == (4 if (mis == 0 and N % spv == 0) else 1)
+        check_close(op.result(), ref, what=f"{cfg} {dtype.__name__} mis={mis}")
+
+
+def test_gen_signal_int_layouts(gat):
+    """gat_gen_signal in the integer layouts == rint(amplitude * float signal), saturated."""
+    g = gat
+    system = g.GPSL1(use_gpu=True)
+    N, M, B = 5000, 2, 2
+    prm = g.make_params([[3], [7]], 1.023e6, [[1500.0], [-900.0]], [[10.5], [700.25]], [[0.3], [1.1]], shape=(B, 1))
+    f_re, f_im = g.gen_signal_stream(system, prm, 5e6, N, M)
+    for layout, amp, lim in ((g.GAT_LAYOUT_INTERLEAVED_I16, 2000.0, 32767), (g.GAT_LAYOUT_INTERLEAVED_I8, 300.0, 127)):
+        x, _ = g.gen_signal_stream(system, prm, 5e6, N, M, layout=layout, amplitude=amp)
+        want_re = np.clip(np.rint(f_re.cpu().numpy() * np.float32(amp)), -lim - 1, lim)
+        want_im = np.clip(np.rint(f_im.cpu().numpy() * np.float32(amp)), -lim - 1, lim)
+        got = x.cpu().numpy()
+        assert np.array_equal(got[..., 0], want_re) and np.array_equal(got[..., 1], want_im)
+    xf, _ = g.gen_signal_stream(system, prm, 5e6, N, M, layout=g.GAT_LAYOUT_INTERLEAVED)
+    assert np.array_equal(xf.cpu().numpy()[..., 0], f_re.cpu().numpy())
+
+
+# ---- taps in any order / wider than the LDS replica segment: host-side tap grouping ----------------
+@pytest.mark.parametrize("shifts", [[5, -3000, 0, 2500, -1, 7], [3, 2, 1, 0, -1, -2, -3, 4, 5, 6, -7], [0], [40000, -40000]])
+def test_unsorted_and_wide_taps(gat, shifts):
+    case = make_case(31 + len(shifts), N=12000, M=2, L=3, K=2, B=2, fs=8e6)
+    case["shifts"] = np.asarray(shifts, dtype=np.int32)
+    case["L"] = len(shifts)
+    for layout in (0, 1):
+        got, _ = run_hip(gat, case, layout=layout)
+        check_close(got, oracle_result(case), what=f"shifts={shifts}")
