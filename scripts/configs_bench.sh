@@ -8,4 +8,4 @@ run --gnss GPSL1 --num-samples 4000  --num-ants 1  --num-taps 3 --channels 1  --
 run --gnss GPSL1 --num-samples 20000 --num-ants 4  --num-taps 3 --channels 1  --blocks 4096       # C2
 run --gnss GPSL5 --num-samples 50000 --num-ants 4  --num-taps 5 --channels 12 --blocks 1024       # C3
 run --gnss GPSL1 --num-samples 50000 --num-ants 16 --num-taps 3 --channels 4  --blocks 512        # C4 per GPU
-run --gnss GPSL1 --num-samples 2000000 --num-ants 64 --num-taps 3 --channels 8 --blocks 2        # C5 (8 of 64 channels)
+run --gnss GPSL1 --num-samples 2000000 --num-ants 64 --num-taps 3 --channels 8 --blocks 2 --block-ms 20   # C5 (8 of 64 channels)
