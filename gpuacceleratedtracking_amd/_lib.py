@@ -25,6 +25,7 @@ EXPORTS = [
     "gat_create", "gat_destroy", "gat_set_stream", "gat_sync", "gat_last_error", "gat_version",
     "gat_device_info", "gat_set_codes", "gat_gen_codes", "gat_sample_shifts",
     "gat_downconvert_and_correlate", "gat_downconvert_and_correlate_dev", "gat_gen_code_replica",
+    "gat_gen_code_replica_f32coord",
     "gat_gen_signal", "gat_reduce_cplx_multi", "gat_malloc", "gat_free", "gat_memcpy_h2d",
     "gat_memcpy_d2h", "gat_memset", "gat_timer_start", "gat_timer_stop", "gat_last_launch_info",
 ]
@@ -108,6 +109,7 @@ def load(build_if_missing: bool = True):
         "gat_downconvert_and_correlate": (i32, [vp, sp, pp, i32, i32, i32, i32p, dbl, vp, vp, u32]),
         "gat_downconvert_and_correlate_dev": (i32, [vp, sp, vp, i32, i32, i32, i32p, dbl, vp, vp, u32]),
         "gat_gen_code_replica": (i32, [vp, vp, i64, i32, dbl, dbl, dbl, i64]),
+        "gat_gen_code_replica_f32coord": (i32, [vp, vp, i64, i32, dbl, dbl, dbl, i64]),
         "gat_gen_signal": (i32, [vp, vp, vp, i32, i64, i32, i64, i64, i32, i32, vp, dbl, dbl]),
         "gat_reduce_cplx_multi": (i32, [vp, vp, vp, i64, i32, vp, vp]),
         "gat_malloc": (i32, [vp, C.c_size_t, C.POINTER(vp)]),

@@ -142,11 +142,13 @@ class Context:
         return call
 
     def gen_code_replica(self, out: torch.Tensor, count: int, prn: int, code_frequency: float,
-                         sampling_frequency: float, code_phase: float, first_shift: int):
+                         sampling_frequency: float, code_phase: float, first_shift: int,
+                         f32_coordinates: bool = False):
         if out.numel() < count or out.dtype != torch.float32:
             raise ValueError("replica tensor too small or not float32")
-        rc = self.lib.gat_gen_code_replica(self._h, C.c_void_p(_ptr(out)), count, prn, float(code_frequency),
-                                           float(sampling_frequency), float(code_phase), int(first_shift))
+        fn = self.lib.gat_gen_code_replica_f32coord if f32_coordinates else self.lib.gat_gen_code_replica
+        rc = fn(self._h, C.c_void_p(_ptr(out)), count, prn, float(code_frequency), float(sampling_frequency),
+                float(code_phase), int(first_shift))
         self.check(rc, "gat_gen_code_replica")
 
     def gen_signal(self, re: torch.Tensor, im: torch.Tensor | None, layout: int, num_samples: int,

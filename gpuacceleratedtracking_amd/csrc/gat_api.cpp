@@ -397,8 +397,8 @@ GAT_API int32_t gat_downconvert_and_correlate(gat_ctx *c, const gat_signal_desc 
     return correlate_impl(c, sig, c->d_params, B, K, L, shifts, fs, out_re, out_im, flags);
 }
 
-GAT_API int32_t gat_gen_code_replica(gat_ctx *c, float *rep, int64_t count, int32_t prn, double fc,
-                                     double fs, double tau, int64_t first_shift)
+static int32_t gen_code_replica_impl(gat_ctx *c, float *rep, int64_t count, int32_t prn, double fc, double fs,
+                                     double tau, int64_t first_shift, bool f32_coordinates)
 {
     if (!c || !rep) return fail(c, GAT_ERR_ARG, "null argument");
     if (!c->d_codes) return fail(c, GAT_ERR_STATE, "gat_set_codes has not been called");
@@ -408,8 +408,20 @@ GAT_API int32_t gat_gen_code_replica(gat_ctx *c, float *rep, int64_t count, int3
     if (count + std::llabs((long long)first_shift) >= (1ll << 30)) return fail(c, GAT_ERR_RANGE, "replica too long");
     GAT_HIP(c, hipSetDevice(c->device));
     GAT_HIP(c, launch_gen_code_replica(rep, count, c->d_codes + (size_t)prn * c->code_row_stride, c->Lc, fc, fs, tau,
-                                       first_shift, c->stream));
+                                       first_shift, f32_coordinates, c->stream));
     return GAT_OK;
+}
+
+GAT_API int32_t gat_gen_code_replica(gat_ctx *c, float *rep, int64_t count, int32_t prn, double fc,
+                                     double fs, double tau, int64_t first_shift)
+{
+    return gen_code_replica_impl(c, rep, count, prn, fc, fs, tau, first_shift, false);
+}
+
+GAT_API int32_t gat_gen_code_replica_f32coord(gat_ctx *c, float *rep, int64_t count, int32_t prn, double fc,
+                                              double fs, double tau, int64_t first_shift)
+{
+    return gen_code_replica_impl(c, rep, count, prn, fc, fs, tau, first_shift, true);
 }
 
 GAT_API int32_t gat_gen_signal(gat_ctx *c, void *re, void *im, int32_t layout, int64_t N, int32_t M,

@@ -67,7 +67,7 @@ hipError_t launch_finalize(const float *partial, float *out_re, float *out_im, i
                            long long groups, hipStream_t s);
 hipError_t launch_gen_code_replica(float *rep, long long count, const int8_t *code_row, int Lc,
                                    double fc, double fs, double tau, long long first_shift,
-                                   hipStream_t s);
+                                   bool f32_coordinates, hipStream_t s);
 hipError_t launch_gen_signal(void *re, void *im, int format, long long N, int M,
                              long long ant_stride, long long block_stride, int B, int K,
                              const gat_channel_params *params, const int8_t *codes, int code_row_stride,

@@ -430,6 +430,13 @@ finalize_kernel(const float *__restrict__ partial, float *__restrict__ out_re,
 // ------------------------------------------------------------------------------------------
 
 // gen_code_replica_kernel! (src/algorithms.jl:13-32), grid-stride as _strided_ (:34-54).
+// F32COORD = true emulates the reference's texture-memory variants
+// (gen_code_replica_texture_mem_kernel!, src/algorithms.jl:121-140): the code phase is divided by
+// the code length in Float64, rounded to a Float32 NORMALISED coordinate, wrapped and scaled back
+// in Float32 with nearest-texel (floor) addressing -- the arithmetic that gives the texture path
+// its code-phase error (paper/paper.tex:318-331).  It is an emulation of float32 normalised-
+// coordinate addressing, not of a particular texture unit.
+template <bool F32COORD>
 __global__ void __launch_bounds__(kThreads)
 code_replica_kernel(float *__restrict__ rep, long long count, const int8_t *__restrict__ code,
                     int Lc, double fc, double fs, double tau, long long first_shift)
@@ -437,8 +444,19 @@ code_replica_kernel(float *__restrict__ rep, long long count, const int8_t *__re
     const double ratio = fc / fs;
     const float inv_lc = 1.0f / (float)Lc;
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < count;
-         i += (long long)gridDim.x * kThreads)
-        rep[i] = (float)code[chip_index(ratio, tau, (int)(i + first_shift), Lc, inv_lc)];
+         i += (long long)gridDim.x * kThreads) {
+        int idx;
+        if constexpr (F32COORD) {
+            const double p = __dadd_rn(__dmul_rn(ratio, (double)(i + first_shift)), tau);
+            const float u = (float)__ddiv_rn(p, (double)Lc);  // normalised coordinate, Float32
+            const float w = u - __builtin_floorf(u);          // ADDRESS_MODE_WRAP
+            idx = (int)__builtin_floorf(w * (float)Lc);       // NearestNeighbour == floor(u * N)
+            idx = idx >= Lc ? Lc - 1 : (idx < 0 ? 0 : idx);
+        } else {
+            idx = chip_index(ratio, tau, (int)(i + first_shift), Lc, inv_lc);
+        }
+        rep[i] = (float)code[idx];
+    }
 }
 
 // gen_signal! (src/gen_signal.jl:64-70, :86-90): Float64 code phase, carrier phase evaluated in
@@ -586,12 +604,16 @@ hipError_t launch_finalize(const float *partial, float *out_re, float *out_im, i
 
 hipError_t launch_gen_code_replica(float *rep, long long count, const int8_t *code_row, int Lc,
                                    double fc, double fs, double tau, long long first_shift,
-                                   hipStream_t s)
+                                   bool f32_coordinates, hipStream_t s)
 {
     long long blocks = (count + kThreads - 1) / kThreads;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(code_replica_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, s, rep, count,
-                       code_row, Lc, fc, fs, tau, first_shift);
+    if (f32_coordinates)
+        hipLaunchKernelGGL(code_replica_kernel<true>, dim3((unsigned)blocks), dim3(kThreads), 0, s, rep, count,
+                           code_row, Lc, fc, fs, tau, first_shift);
+    else
+        hipLaunchKernelGGL(code_replica_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0, s, rep, count,
+                           code_row, Lc, fc, fs, tau, first_shift);
     return hipGetLastError();
 }
 

@@ -165,6 +165,16 @@ GAT_API int32_t gat_gen_code_replica(gat_ctx *ctx, float *replica_dev, int64_t c
                                      double code_freq_hz, double sampling_freq_hz,
                                      double code_phase_chips, int64_t first_shift);
 
+/* gen_code_replica_texture_mem_kernel! (src/algorithms.jl:121-140): the same replica addressed
+ * through a Float32 NORMALISED coordinate (phase / code_length rounded to float32, wrap, nearest
+ * texel) -- an emulation of the arithmetic behind the texture path's code-phase error
+ * (paper/paper.tex:318-331; scripts/code_replica_experiment.jl).  Study use only: the
+ * correlator never uses it. */
+GAT_API int32_t gat_gen_code_replica_f32coord(gat_ctx *ctx, float *replica_dev, int64_t count,
+                                              int32_t prn, double code_freq_hz,
+                                              double sampling_freq_hz, double code_phase_chips,
+                                              int64_t first_shift);
+
 /* gen_signal! (src/gen_signal.jl:53-175): noise-free synthetic IF signal, identical on every
  * antenna.  Writes, for every block b, x[n,m,b] = sum_k c_k[floor(fc_k/fs*n + tau_kb) mod Lc]
  *   * (cos, sin)(float32(2pi*n*f_kb/fs + phase_kb)).  NOTE: for THIS call the

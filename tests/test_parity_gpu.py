@@ -371,3 +371,27 @@ def test_unsorted_and_wide_taps(gat, shifts):
     for layout in (0, 1):
         got, _ = run_hip(gat, case, layout=layout)
         check_close(got, oracle_result(case), what=f"shifts={shifts}")
+
+
+# ---- "next" row 3: code-phase error of the Float32 normalised-coordinate (texture) replica -----------
+@pytest.mark.parametrize("N", [2048, 20000, 262144])
+def test_f32_coordinate_replica_matches_its_definition(gat, N):
+    """gat_gen_code_replica_f32coord against a numpy statement of the same Float32 arithmetic
+    (src/algorithms.jl:121-140: phase / code_length as a normalised texture coordinate)."""
+    import torch
+    g = gat
+    system = g.GPSL1(use_gpu=True)
+    fs, fc, lc = N / 1e-3, 1.023e6, 1023
+    shifts = g.get_correlator_sample_shifts(system, g.EarlyPromptLateCorrelator(1, 3), fs, 0.5)
+    count = N + int(shifts[-1] - shifts[0])
+    rep = torch.zeros(count, device=g.get_context().device)
+    g.gen_code_replica(rep, system, fc, fs, 0.0, 1, N, shifts, 1, texture_coordinates=True)
+    i = np.arange(count, dtype=np.float64) + float(shifts[0])
+    u = ((np.float64(fc) / np.float64(fs)) * i + 0.0) / np.float64(lc)
+    u = u.astype(np.float32)
+    w = u - np.floor(u)
+    idx = np.clip(np.floor(w * np.float32(lc)).astype(np.int64), 0, lc - 1)
+    assert np.array_equal(rep.cpu().numpy(), system.codes[0][idx].astype(np.float32))
+    exact = oracle.gen_code_replica(system.codes, 0, fc, fs, 0.0, int(shifts[0]), count)
+    err = np.abs(rep.cpu().numpy() - exact).sum() / N
+    assert err < 0.05  # a small fraction of samples sits within float32 resolution of a chip edge
