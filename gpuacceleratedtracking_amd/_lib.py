@@ -26,7 +26,7 @@ EXPORTS = [
     "gat_device_info", "gat_set_codes", "gat_gen_codes", "gat_sample_shifts",
     "gat_downconvert_and_correlate", "gat_downconvert_and_correlate_dev", "gat_gen_code_replica",
     "gat_gen_code_replica_f32coord",
-    "gat_gen_signal", "gat_reduce_cplx_multi", "gat_malloc", "gat_free", "gat_memcpy_h2d",
+    "gat_gen_signal", "gat_reduce_cplx_multi", "gat_tracking_update", "gat_malloc", "gat_free", "gat_memcpy_h2d",
     "gat_memcpy_d2h", "gat_memset", "gat_timer_start", "gat_timer_stop", "gat_last_launch_info",
 ]
 
@@ -61,6 +61,20 @@ class SignalDesc(C.Structure):
     _fields_ = [("re", C.c_void_p), ("im", C.c_void_p), ("layout", C.c_int32),
                 ("num_ants", C.c_int32), ("num_samples", C.c_int64), ("ant_stride", C.c_int64),
                 ("block_stride", C.c_int64), ("chan_stride", C.c_int64)]
+
+
+class LoopConfig(C.Structure):
+    """gat_loop_config (include/gat.h)."""
+
+    _fields_ = [("block_seconds", C.c_double), ("pll_bandwidth_hz", C.c_double), ("dll_bandwidth_hz", C.c_double),
+                ("code_freq_nominal_hz", C.c_double), ("carrier_center_hz", C.c_double), ("if_hz", C.c_double),
+                ("early_late_spacing_chips", C.c_double), ("code_length", C.c_int32), ("num_taps", C.c_int32),
+                ("early_index", C.c_int32), ("prompt_index", C.c_int32), ("late_index", C.c_int32)]
+
+
+LOOP_STATE_DTYPE = np.dtype([(n, "<f8") for n in (
+    "init_carrier_doppler_hz", "carrier_doppler_hz", "code_doppler_hz", "pll_acc1", "pll_acc2", "dll_acc",
+    "last_pll_error_cycles", "last_dll_error_chips", "prompt_power")])
 
 
 class LaunchInfo(C.Structure):
@@ -112,6 +126,7 @@ def load(build_if_missing: bool = True):
         "gat_gen_code_replica_f32coord": (i32, [vp, vp, i64, i32, dbl, dbl, dbl, i64]),
         "gat_gen_signal": (i32, [vp, vp, vp, i32, i64, i32, i64, i64, i32, i32, vp, dbl, dbl]),
         "gat_reduce_cplx_multi": (i32, [vp, vp, vp, i64, i32, vp, vp]),
+        "gat_tracking_update": (i32, [vp, vp, vp, i32, i32, C.POINTER(LoopConfig), vp, vp, vp]),
         "gat_malloc": (i32, [vp, C.c_size_t, C.POINTER(vp)]),
         "gat_free": (i32, [vp, vp]),
         "gat_memcpy_h2d": (i32, [vp, vp, vp, C.c_size_t]),

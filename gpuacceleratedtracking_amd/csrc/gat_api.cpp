@@ -456,6 +456,25 @@ GAT_API int32_t gat_reduce_cplx_multi(gat_ctx *c, const float *in_re, const floa
     return GAT_OK;
 }
 
+GAT_API int32_t gat_tracking_update(gat_ctx *c, const float *acc_re, const float *acc_im, int32_t K, int32_t M,
+                                    const gat_loop_config *cfg, gat_loop_state *state,
+                                    const gat_channel_params *cur, gat_channel_params *next)
+{
+    if (!c || !acc_re || !acc_im || !cfg || !state || !cur || !next) return fail(c, GAT_ERR_ARG, "null argument");
+    if (K < 1 || M < 1) return fail(c, GAT_ERR_ARG, "sizes must be positive");
+    const int L = cfg->num_taps;
+    if (L < 1 || L > GAT_MAX_TAPS || cfg->early_index < 0 || cfg->early_index >= L || cfg->prompt_index < 0 ||
+        cfg->prompt_index >= L || cfg->late_index < 0 || cfg->late_index >= L)
+        return fail(c, GAT_ERR_RANGE, "tap indices outside the tap list");
+    if (!(cfg->block_seconds > 0.0) || !(cfg->pll_bandwidth_hz >= 0.0) || !(cfg->dll_bandwidth_hz >= 0.0) ||
+        !(cfg->code_freq_nominal_hz > 0.0) || !(cfg->carrier_center_hz > 0.0) || cfg->code_length < 1 ||
+        !(cfg->early_late_spacing_chips > 0.0 && cfg->early_late_spacing_chips < 2.0))
+        return fail(c, GAT_ERR_ARG, "bad loop configuration");
+    GAT_HIP(c, hipSetDevice(c->device));
+    GAT_HIP(c, launch_tracking_update(acc_re, acc_im, K, M, *cfg, state, cur, next, c->stream));
+    return GAT_OK;
+}
+
 GAT_API int32_t gat_malloc(gat_ctx *c, size_t bytes, void **out)
 {
     if (!c || !out || bytes == 0) return fail(c, GAT_ERR_ARG, "bad argument");

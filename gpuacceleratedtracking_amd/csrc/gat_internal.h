@@ -74,6 +74,9 @@ hipError_t launch_gen_signal(void *re, void *im, int format, long long N, int M,
                              int Lc, int num_prns, double fs, float amplitude, hipStream_t s);
 hipError_t launch_reduce_stage1(const float *in_re, const float *in_im, long long n, int cols,
                                 int chunks, float *partial, hipStream_t s);
+hipError_t launch_tracking_update(const float *acc_re, const float *acc_im, int K, int M, const gat_loop_config &cfg,
+                                  gat_loop_state *state, const gat_channel_params *cur, gat_channel_params *next,
+                                  hipStream_t s);
 bool dc_supported(int ant_tile, int taps);
 
 } // namespace gat

@@ -1,0 +1,84 @@
+"""Closed tracking loop around the correlator: the layer Tracking.jl's
+``track`` provides and the reference only touches to borrow buffers (``TrackingState``,
+src/benchmarks.jl:54-61).  One ``TrackingLoop.step`` = one fused correlate launch for K channels
+on one integration block + one ``gat_tracking_update`` launch that turns the accumulators into
+the next block's parameters ON THE DEVICE (ping-pong parameter buffers, no host round trip)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .context import Context, get_context
+from .gen_signal import make_params
+from .signals import GNSSSystem, get_code_frequency
+from .tracking import _signal_desc
+
+
+class TrackingLoop:
+    def __init__(self, system: GNSSSystem, prns, num_samples: int, num_ants: int, sampling_frequency: float,
+                 correlator_sample_shifts, init_carrier_doppler, init_code_phase, if_hz: float = 0.0,
+                 carrier_center_hz: float = 1575.42e6, pll_bandwidth_hz: float = 18.0, dll_bandwidth_hz: float = 1.0,
+                 init_carrier_phase=0.0, device=None, ctx: Context | None = None):
+        self.ctx = ctx if ctx is not None else get_context(device)
+        self.ctx.set_codes(system.codes)
+        self.system = system
+        prns = np.atleast_1d(np.asarray(prns))
+        self.K, self.N, self.M = int(prns.size), int(num_samples), int(num_ants)
+        self.fs = float(sampling_frequency)
+        self.shifts = np.ascontiguousarray(correlator_sample_shifts, dtype=np.int32)
+        self.L = int(self.shifts.size)
+        order = np.argsort(self.shifts, kind="stable")
+        fc = get_code_frequency(system)
+        cfg = _lib.LoopConfig()
+        cfg.block_seconds = self.N / self.fs
+        cfg.pll_bandwidth_hz, cfg.dll_bandwidth_hz = pll_bandwidth_hz, dll_bandwidth_hz
+        cfg.code_freq_nominal_hz, cfg.carrier_center_hz, cfg.if_hz = fc, carrier_center_hz, if_hz
+        cfg.code_length, cfg.num_taps = system.code_length, self.L
+        cfg.early_index, cfg.late_index = int(order[0]), int(order[-1])
+        zero = np.nonzero(self.shifts == 0)[0]
+        if zero.size == 0:
+            raise ValueError("the tap list needs a prompt tap (shift 0)")
+        cfg.prompt_index = int(zero[0])
+        cfg.early_late_spacing_chips = float(self.shifts[order[-1]] - self.shifts[order[0]]) * fc / self.fs
+        self.config = cfg
+        dop = np.broadcast_to(np.asarray(init_carrier_doppler, dtype=np.float64), (self.K,))
+        prm = make_params(prns - 1, fc + dop * fc / carrier_center_hz, if_hz + dop, init_code_phase,
+                          init_carrier_phase, shape=(1, self.K))
+        dev = self.ctx.device
+        self._params = [self.ctx.params_to_device(prm), self.ctx.params_to_device(prm)]
+        self._cur = 0
+        st = np.zeros(self.K, dtype=_lib.LOOP_STATE_DTYPE)
+        st["init_carrier_doppler_hz"] = dop
+        st["carrier_doppler_hz"] = dop
+        self._state = torch.from_numpy(st.view(np.uint8).reshape(-1).copy()).to(dev)
+        self.out_re = torch.empty((1, self.K, self.L, self.M), dtype=torch.float32, device=dev)
+        self.out_im = torch.empty_like(self.out_re)
+        self.blocks_done = 0
+
+    def step(self, re: torch.Tensor, im: torch.Tensor | None = None, start: int = 0):
+        """Correlate the block starting at sample ``start`` of the given signal with the current
+        parameters, then update them on the device.  Nothing is synchronised."""
+        desc = _signal_desc(re, im, self.N, start=start)
+        cur, nxt = self._params[self._cur], self._params[1 - self._cur]
+        self.ctx.downconvert_and_correlate(desc, cur, 1, self.K, self.shifts, self.fs, self.out_re, self.out_im)
+        rc = self.ctx.lib.gat_tracking_update(self.ctx._h, C.c_void_p(self.out_re.data_ptr()),
+                                              C.c_void_p(self.out_im.data_ptr()), self.K, self.M,
+                                              C.byref(self.config), C.c_void_p(self._state.data_ptr()),
+                                              C.c_void_p(cur.data_ptr()), C.c_void_p(nxt.data_ptr()))
+        self.ctx.check(rc, "gat_tracking_update")
+        self._cur = 1 - self._cur
+        self.blocks_done += 1
+
+    def params(self) -> np.ndarray:
+        """Current per-channel parameters (host copy; synchronises)."""
+        return self._params[self._cur].cpu().numpy().view(_lib.PARAMS_DTYPE).copy()
+
+    def state(self) -> np.ndarray:
+        return self._state.cpu().numpy().view(_lib.LOOP_STATE_DTYPE).copy()
+
+    def accumulators(self) -> np.ndarray:
+        """complex64 [K, L, M] of the last block."""
+        return (self.out_re.cpu().numpy() + 1j * self.out_im.cpu().numpy())[0].astype(np.complex64)

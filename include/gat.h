@@ -195,6 +195,49 @@ GAT_API int32_t gat_reduce_cplx_multi(gat_ctx *ctx, const float *in_re_dev, cons
                                       int64_t n, int32_t num_cols, float *out_re_dev,
                                       float *out_im_dev);
 
+/* ---- closed tracking-loop step ------------------------------------
+ * What Tracking.jl's `track` does around the correlator (the reference touches that layer only
+ * to borrow buffers: TrackingState, src/benchmarks.jl:54-61): discriminators + loop filters turn
+ * the accumulators of the block just correlated into the parameters of the next block, ON THE
+ * DEVICE, so a receiver loop is {correlate, update} with no host round trip.  Textbook loop
+ * (Kaplan & Hegarty ch. 5; the same structure Tracking.jl uses):
+ *   prompt/early/late = sum over antennas of R[m, tap]                      (identical antennas)
+ *   PLL: Costas arctan discriminator atan(Q/I)/2pi [cycles] -> 3rd-order bilinear loop filter
+ *   DLL: (2-d)/2 * (|L|-|E|)/(|E|+|L|) [chips], d = E-L spacing in chips -> 2nd-order bilinear
+ *        filter, carrier aided (code_doppler += carrier_doppler * code_freq / carrier_center)
+ *   next block: carrier_phase += carrier_freq * T, code_phase += code_freq * T (mod code_length),
+ *               carrier_freq = if_hz + doppler, code_freq = nominal + code_doppler
+ * No reference implementation of this step is available here (Tracking.jl is un-vendored):
+ * parity is against the oracle's restatement of the same equations only ("unpinned"). */
+typedef struct gat_loop_config {
+    double block_seconds;        /* T = N / fs                                                 */
+    double pll_bandwidth_hz;     /* carrier loop noise bandwidth (e.g. 18 Hz)                  */
+    double dll_bandwidth_hz;     /* code loop noise bandwidth (e.g. 1 Hz)                      */
+    double code_freq_nominal_hz; /* e.g. 1.023e6                                               */
+    double carrier_center_hz;    /* RF centre frequency for carrier aiding (e.g. 1575.42e6)    */
+    double if_hz;                /* intermediate frequency of the sampled signal               */
+    double early_late_spacing_chips; /* d: distance between the early and the late tap in chips */
+    int32_t code_length;
+    int32_t num_taps, early_index, prompt_index, late_index; /* positions in the tap list      */
+} gat_loop_config;
+
+typedef struct gat_loop_state { /* one per channel, device-resident; zero everything but      */
+    double init_carrier_doppler_hz; /* ... this: the acquisition estimate the loop starts from */
+    double carrier_doppler_hz;  /* out: current carrier Doppler estimate                       */
+    double code_doppler_hz;     /* out: current code Doppler estimate                          */
+    double pll_acc1, pll_acc2;  /* loop-filter integrators                                     */
+    double dll_acc;
+    double last_pll_error_cycles, last_dll_error_chips; /* diagnostics                         */
+    double prompt_power;        /* |P|^2 of the last block                                     */
+} gat_loop_state;
+
+/* acc_re/acc_im: dev float [M x L x K] of ONE block (as written by the correlator);
+ * cur/next: dev gat_channel_params[K] (may alias); state: dev gat_loop_state[K]. */
+GAT_API int32_t gat_tracking_update(gat_ctx *ctx, const float *acc_re_dev, const float *acc_im_dev,
+                                    int32_t num_channels, int32_t num_ants,
+                                    const gat_loop_config *config_host, gat_loop_state *state_dev,
+                                    const gat_channel_params *cur_dev, gat_channel_params *next_dev);
+
 /* ---- memory + timing helpers (for hosts without their own HIP array type) ---------------- */
 GAT_API int32_t gat_malloc(gat_ctx *ctx, size_t bytes, void **out_dev);
 GAT_API int32_t gat_free(gat_ctx *ctx, void *dev);

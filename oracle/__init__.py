@@ -276,3 +276,47 @@ def np_correlate(re, im, code_row, fc, fs, f, tau, phi_cycles, shifts):
         idx = np.mod(np.floor(p).astype(np.int64), lc)
         out[li] = (dw * code_row[idx].astype(np.float64)[None, :]).sum(axis=1)
     return out
+
+
+def np_tracking_update(acc, cfg: dict, state: dict, cur: np.ndarray):
+    """Numpy restatement of gat_tracking_update (include/gat.h): textbook Costas-PLL (3rd-order
+    bilinear filter, Kaplan & Hegarty table 5.6) + carrier-aided normalised early-minus-late DLL
+    (2nd-order bilinear).  No reference implementation exists in the reference tree (Tracking.jl is
+    un-vendored): UNPINNED -- it pins the device kernel to these equations only.
+    acc complex [K, L, M]; cfg: dict of gat_loop_config fields; state: dict of float64 [K] arrays
+    (gat_loop_state fields); cur: structured params [K].  Returns (next_params, new_state)."""
+    T = cfg["block_seconds"]
+    P = acc[:, cfg["prompt_index"], :].astype(np.complex128).sum(axis=1)
+    E = acc[:, cfg["early_index"], :].astype(np.complex128).sum(axis=1)
+    Lt = acc[:, cfg["late_index"], :].astype(np.complex128).sum(axis=1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        pll = np.where(P == 0, 0.0, np.arctan(P.imag / P.real) / (2 * np.pi))
+    e, l = np.abs(E), np.abs(Lt)
+    dll = np.where(e + l > 0, 0.5 * (2.0 - cfg["early_late_spacing_chips"]) * (l - e) / np.where(e + l > 0, e + l, 1), 0.0)
+    st = {k: np.array(v, dtype=np.float64, copy=True) for k, v in state.items()}
+    w0p = cfg["pll_bandwidth_hz"] / 0.7845
+    in1 = w0p ** 3 * pll
+    out1 = st["pll_acc1"] + 0.5 * T * in1
+    st["pll_acc1"] += T * in1
+    in2 = out1 + 1.1 * w0p ** 2 * pll
+    out2 = st["pll_acc2"] + 0.5 * T * in2
+    st["pll_acc2"] += T * in2
+    carrier_rate = out2 + 2.4 * w0p * pll
+    w0d = cfg["dll_bandwidth_hz"] / 0.53
+    ind = w0d ** 2 * dll
+    outd = st["dll_acc"] + 0.5 * T * ind
+    st["dll_acc"] += T * ind
+    code_rate = outd + 1.414 * w0d * dll
+    car_dop = st["init_carrier_doppler_hz"] + carrier_rate
+    code_dop = code_rate + car_dop * cfg["code_freq_nominal_hz"] / cfg["carrier_center_hz"]
+    nxt = cur.copy()
+    phi = cur["carrier_phase_cycles"] + cur["carrier_freq_hz"] * T
+    nxt["carrier_phase_cycles"] = phi - np.floor(phi)
+    tau = cur["code_phase_chips"] + cur["code_freq_hz"] * T
+    nxt["code_phase_chips"] = tau - np.floor(tau / cfg["code_length"]) * cfg["code_length"]
+    nxt["carrier_freq_hz"] = cfg["if_hz"] + car_dop
+    nxt["code_freq_hz"] = cfg["code_freq_nominal_hz"] + code_dop
+    st["carrier_doppler_hz"], st["code_doppler_hz"] = car_dop, code_dop
+    st["last_pll_error_cycles"], st["last_dll_error_chips"] = pll, dll
+    st["prompt_power"] = np.abs(P) ** 2
+    return nxt, st
