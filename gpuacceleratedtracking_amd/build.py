@@ -51,5 +51,16 @@ def build_libgat(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_c_example(force: bool = False) -> str:
+    """gcc build of examples/gat_known_answer.c against libgat.so (plain C host of the C ABI)."""
+    src = os.path.join(ROOT, "examples", "gat_known_answer.c")
+    out = os.path.join(ROOT, "build", "gat_known_answer")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(LIB)):
+        subprocess.run(["gcc", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-o", out, "-L" + HERE,
+                        "-lgat", "-Wl,-rpath," + HERE, "-lm"], check=True)
+    return out
+
+
 if __name__ == "__main__":
     print(build_libgat(force=True, verbose=True))

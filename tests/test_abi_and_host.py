@@ -155,3 +155,11 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 for needle in ("import oracle", "from oracle", "libgat_oracle", "gat_oracle_", "oracle/"):
                     assert needle not in src, f"{f} references the test oracle ({needle})"
+
+
+def test_c_example_builds_against_the_header():
+    """The plain-C host compiles and links against include/gat.h + libgat.so (run on the GPU in
+    tests/test_parity_gpu.py::test_c_abi_from_plain_c)."""
+    from gpuacceleratedtracking_amd import build
+    exe = build.build_c_example(force=True)
+    assert os.path.exists(exe)

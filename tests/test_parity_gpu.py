@@ -395,3 +395,14 @@ def test_f32_coordinate_replica_matches_its_definition(gat, N):
     exact = oracle.gen_code_replica(system.codes, 0, fc, fs, 0.0, int(shifts[0]), count)
     err = np.abs(rep.cpu().numpy() - exact).sum() / N
     assert err < 0.05  # a small fraction of samples sits within float32 resolution of a chip edge
+
+
+def test_c_abi_from_plain_c(gat):
+    """examples/gat_known_answer.c: the C ABI driven from plain C (no Python objects, library-owned
+    stream and memory) reproduces the reference's known answer."""
+    import subprocess
+    from gpuacceleratedtracking_amd import build
+    exe = build.build_c_example()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK (known answer 1476 2500 1476)" in r.stdout
