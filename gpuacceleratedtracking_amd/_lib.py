@@ -27,7 +27,7 @@ EXPORTS = [
     "gat_downconvert_and_correlate", "gat_downconvert_and_correlate_dev", "gat_gen_code_replica",
     "gat_gen_code_replica_f32coord",
     "gat_gen_signal", "gat_reduce_cplx_multi", "gat_tracking_update", "gat_malloc", "gat_free", "gat_memcpy_h2d",
-    "gat_memcpy_d2h", "gat_memset", "gat_timer_start", "gat_timer_stop", "gat_last_launch_info",
+    "gat_memcpy_d2h", "gat_memset", "gat_timer_start", "gat_timer_stop", "gat_last_launch_info", "gat_set_matrix_core",
 ]
 
 
@@ -79,7 +79,7 @@ LOOP_STATE_DTYPE = np.dtype([(n, "<f8") for n in (
 
 class LaunchInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("workgroups", "threads", "splits", "ant_tile", "vec",
-                                          "lds_bytes", "finalize_launched", "reserved")]
+                                          "lds_bytes", "finalize_launched", "matrix_core")]
 
 
 _LIB = None
@@ -135,6 +135,7 @@ def load(build_if_missing: bool = True):
         "gat_timer_start": (i32, [vp]),
         "gat_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
         "gat_last_launch_info": (i32, [vp, C.POINTER(LaunchInfo)]),
+        "gat_set_matrix_core": (i32, [vp, i32]),
     }
     assert sorted(sigs) == sorted(EXPORTS)
     for name, (res, args) in sigs.items():

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgat.so")
-SOURCES = ["gat_kernels.hip", "gat_api.cpp", "gat_codes.cpp"]
+SOURCES = ["gat_kernels.hip", "gat_mfma.hip", "gat_api.cpp", "gat_codes.cpp"]
 HEADERS = [os.path.join(CSRC, "gat_internal.h"), os.path.join(ROOT, "include", "gat.h")]
 
 

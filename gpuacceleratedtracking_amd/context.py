@@ -66,7 +66,11 @@ class Context:
     def last_launch_info(self) -> dict:
         info = _lib.LaunchInfo()
         self.check(self.lib.gat_last_launch_info(self._h, C.byref(info)), "gat_last_launch_info")
-        return {n: getattr(info, n) for n, _ in info._fields_ if n != "reserved"}
+        return {n: getattr(info, n) for n, _ in info._fields_}
+
+    def set_matrix_core(self, enable: bool):
+        """Allow (default) or forbid the MFMA kernel for antenna-rich shapes (A/B, bit comparisons)."""
+        self.check(self.lib.gat_set_matrix_core(self._h, 1 if enable else 0), "gat_set_matrix_core")
 
     def timer_start(self):
         self.check(self.lib.gat_timer_start(self._h), "gat_timer_start")

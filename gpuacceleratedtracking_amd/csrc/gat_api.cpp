@@ -31,6 +31,7 @@ struct gat_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timer_running = false;
     int num_cus = 256;
+    bool no_mfma = false; // GAT_NO_MFMA=1: always use the vector kernel (A/B experiments)
     std::string err;
     gat_launch_info last{};
 };
@@ -114,6 +115,80 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         vec = 4;
 
     const long long N = sig->num_samples;
+
+    // ---- matrix-core path (gat_mfma.hip): antenna-rich shapes whose (channel, tap) columns fill
+    // a useful part of a 32-column tile; everything else takes the vector kernel below.
+    {
+        int order[GAT_MAX_TAPS];
+        for (int l = 0; l < L; ++l) order[l] = l;
+        std::stable_sort(order, order + L, [&](int x, int y) { return shifts[x] < shifts[y]; });
+        const long long span = (long long)shifts[order[L - 1]] - shifts[order[0]];
+        const int CT = L <= kMfmaMaxTaps ? 16 / L : 0;
+        const bool eligible = !c->no_mfma && planar && vec == 4 && M % 16 == 0 && sig->chan_stride == 0 && CT >= 1 &&
+                              span <= kMfmaMaxSpan && 2 * std::min(K, CT) * L >= 12 /* >= 3/8 of the columns */;
+        if (eligible) {
+            const int nct_total = (K + CT - 1) / CT;
+            const int nct = nct_total >= 4 ? 4 : (nct_total >= 2 ? 2 : 1);
+            MfArgs m{};
+            m.re = static_cast<const float *>(sig->re);
+            m.im = static_cast<const float *>(sig->im);
+            m.params = params_dev;
+            m.codes = c->d_codes;
+            m.out_re = out_re;
+            m.out_im = out_im;
+            m.N = N;
+            m.ant_stride = sig->ant_stride;
+            m.block_stride = sig->block_stride;
+            m.fs = fs;
+            m.M = M; m.K = K; m.B = B; m.L = L; m.Lc = c->Lc; m.num_prns = c->P; m.code_row_stride = c->code_row_stride;
+            m.CT = CT;
+            m.chan_groups = (nct_total + nct - 1) / nct;
+            m.ant_tiles = M / 16;
+            m.total_steps = (int)((N + 255) / 256);
+            const long long groups_m = (long long)B * m.ant_tiles * m.chan_groups;
+            long long sp = std::max<long long>(1, (4ll * c->num_cus + groups_m - 1) / groups_m);
+            sp = std::min<long long>(sp, m.total_steps);
+            m.steps_per_split = (int)((m.total_steps + sp - 1) / sp);
+            m.splits = (m.total_steps + m.steps_per_split - 1) / m.steps_per_split;
+            m.num_tiles = B * m.ant_tiles * m.splits;
+            m.max_abs_shift = (int)max_shift;
+            m.rep_span = (int)span;
+            m.rep_stride = ((256 + (int)span + 31) / 32) * 32 + 1; // odd: channel rows land on different banks
+            m.flags = flags;
+            for (int l = 0; l < kMfmaMaxTaps; ++l) {
+                m.shifts[l] = shifts[order[std::min(l, L - 1)]];
+                m.tap_index[l] = order[std::min(l, L - 1)];
+            }
+            const long long grid_m = ((long long)(m.num_tiles + 7) / 8) * 8 * m.chan_groups;
+            if (grid_m >= (1ll << 31)) return fail(c, GAT_ERR_RANGE, "grid too large");
+            const bool atomic_m = (flags & GAT_FLAG_ATOMIC) != 0;
+            const size_t out_elems_m = (size_t)B * K * L * M;
+            if (atomic_m) {
+                GAT_HIP(c, hipMemsetAsync(out_re, 0, out_elems_m * sizeof(float), c->stream));
+                GAT_HIP(c, hipMemsetAsync(out_im, 0, out_elems_m * sizeof(float), c->stream));
+            } else if (m.splits > 1) {
+                const int32_t rc = ensure_partial(c, (size_t)B * K * m.splits * L * M * 2 * sizeof(float));
+                if (rc != GAT_OK) return rc;
+            }
+            m.partial = c->d_partial;
+            const unsigned lds = (unsigned)mfma_lds_bytes(nct, CT, m.rep_stride);
+            GAT_HIP(c, launch_mfma(m, nct, (unsigned)grid_m, lds, c->stream));
+            const bool fin_m = !atomic_m && m.splits > 1;
+            if (fin_m)
+                GAT_HIP(c, launch_finalize(c->d_partial, out_re, out_im, m.splits, L * M * 2, (long long)B * K, c->stream));
+            c->last.workgroups = (int32_t)grid_m;
+            c->last.threads = kThreads;
+            c->last.splits = m.splits;
+            c->last.ant_tile = 16;
+            c->last.vec = 4;
+            c->last.lds_bytes = (int32_t)lds;
+            c->last.finalize_launched = fin_m ? 1 : 0;
+            c->last.matrix_core = 1;
+            return GAT_OK;
+        }
+    }
+    c->last.matrix_core = 0;
+
     const long long chunk = dc_chunk(vec, fmt);
     const long long chunks = (N + chunk - 1) / chunk;
     const long long groups = (long long)B * K * AT;
@@ -246,6 +321,7 @@ GAT_API int32_t gat_create(int32_t device, void *hip_stream, gat_ctx **out_ctx)
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    if (const char *e = std::getenv("GAT_NO_MFMA")) c->no_mfma = e[0] == '1';
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
         delete c;
         return -(int32_t)e;
@@ -535,6 +611,13 @@ GAT_API int32_t gat_timer_stop(gat_ctx *c, float *ms)
     GAT_HIP(c, hipEventSynchronize(c->ev1));
     GAT_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
     c->timer_running = false;
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_set_matrix_core(gat_ctx *c, int32_t enable)
+{
+    if (!c) return GAT_ERR_ARG;
+    c->no_mfma = enable == 0;
     return GAT_OK;
 }
 

@@ -61,6 +61,32 @@ struct DcLaunch {
     unsigned lds_bytes;
 };
 
+// Arguments of the matrix-core kernel (gat_mfma.hip): 16-antenna tiles, planar f32 input.
+constexpr int kMfmaMaxTaps = 16;     // 2 * CT * L <= 32 columns with CT >= 1
+constexpr int kMfmaMaxSpan = 768;    // replica halo served per 256-sample step
+struct MfArgs {
+    const float *re;
+    const float *im;
+    const gat_channel_params *params;
+    const int8_t *codes;
+    float *out_re;
+    float *out_im;
+    float *partial;
+    long long N, ant_stride, block_stride;
+    double fs;
+    int M, K, B, L, Lc, num_prns, code_row_stride;
+    int CT;              // channels per 32-column tile = 16 / L
+    int chan_groups;     // ceil(ceil(K / CT) / NCT)
+    int ant_tiles;       // M / 16
+    int splits, steps_per_split, total_steps, num_tiles;
+    int max_abs_shift, rep_span, rep_stride;
+    unsigned flags;
+    int shifts[kMfmaMaxTaps];    // ascending
+    int tap_index[kMfmaMaxTaps]; // position in the caller's list
+};
+hipError_t launch_mfma(const MfArgs &a, int nct, unsigned grid, unsigned lds_bytes, hipStream_t s);
+size_t mfma_lds_bytes(int nct, int ct, int rep_stride);
+
 // Launchers implemented in gat_kernels.hip.  All return hipError_t of the launch.
 hipError_t launch_dc(const DcArgs &a, const DcLaunch &cfg, hipStream_t s);
 hipError_t launch_finalize(const float *partial, float *out_re, float *out_im, int splits, int elems,

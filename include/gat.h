@@ -250,9 +250,15 @@ GAT_API int32_t gat_memset(gat_ctx *ctx, void *dst_dev, int32_t value, size_t by
 GAT_API int32_t gat_timer_start(gat_ctx *ctx);
 GAT_API int32_t gat_timer_stop(gat_ctx *ctx, float *elapsed_ms);
 
+/* Kernel selection: by default antenna-rich shapes (M % 16 == 0, enough (channel, tap) columns)
+ * run on the matrix cores (gat_mfma.hip), everything else on the vector kernel.  enable = 0 forces
+ * the vector kernel (A/B measurements, bit-comparisons); enable = 1 restores the default. */
+GAT_API int32_t gat_set_matrix_core(gat_ctx *ctx, int32_t enable);
+
 /* Launch geometry chosen for the last correlate call (diagnostics / DESIGN.md tables). */
 typedef struct gat_launch_info {
-    int32_t workgroups, threads, splits, ant_tile, vec, lds_bytes, finalize_launched, reserved;
+    int32_t workgroups, threads, splits, ant_tile, vec, lds_bytes, finalize_launched;
+    int32_t matrix_core; /* 1: the MFMA kernel ran (antenna-rich shapes), 0: the vector kernel */
 } gat_launch_info;
 GAT_API int32_t gat_last_launch_info(const gat_ctx *ctx, gat_launch_info *out);
 
