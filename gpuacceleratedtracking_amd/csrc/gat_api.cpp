@@ -31,6 +31,7 @@ struct gat_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timer_running = false;
     int num_cus = 256;
+    unsigned long long *dbg_ptr = nullptr; // diagnostic builds only
     bool no_mfma = false; // GAT_NO_MFMA=1: always use the vector kernel (A/B experiments)
     std::string err;
     gat_launch_info last{};
@@ -124,11 +125,14 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         std::stable_sort(order, order + L, [&](int x, int y) { return shifts[x] < shifts[y]; });
         const long long span = (long long)shifts[order[L - 1]] - shifts[order[0]];
         const int CT = L <= kMfmaMaxTaps ? 16 / L : 0;
-        const bool eligible = !c->no_mfma && planar && vec == 4 && M % 16 == 0 && sig->chan_stride == 0 && CT >= 1 &&
-                              span <= kMfmaMaxSpan && 2 * std::min(K, CT) * L >= 12 /* >= 3/8 of the columns */;
+        bool eligible = !c->no_mfma && planar && vec == 4 && M % 16 == 0 && sig->chan_stride == 0 && CT >= 1 &&
+                        span <= kMfmaMaxSpan && 2 * std::min(K, CT) * L >= 12 /* >= 3/8 of the columns */;
+        const int nct_total = eligible ? (K + CT - 1) / CT : 1;
+        const int nct = nct_total >= 4 ? 4 : (nct_total >= 2 ? 2 : 1);
+        const int rep_stride_m = ((256 + (int)span + 31) / 32) * 32 + 1; // odd: channel rows land on different banks
+        if (eligible && mfma_lds_bytes(nct, CT, rep_stride_m, c->code_row_stride, 0) > 160 * 1024)
+            eligible = false; // tile does not fit in LDS: the vector kernel takes it
         if (eligible) {
-            const int nct_total = (K + CT - 1) / CT;
-            const int nct = nct_total >= 4 ? 4 : (nct_total >= 2 ? 2 : 1);
             MfArgs m{};
             m.re = static_cast<const float *>(sig->re);
             m.im = static_cast<const float *>(sig->im);
@@ -153,7 +157,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             m.num_tiles = B * m.ant_tiles * m.splits;
             m.max_abs_shift = (int)max_shift;
             m.rep_span = (int)span;
-            m.rep_stride = ((256 + (int)span + 31) / 32) * 32 + 1; // odd: channel rows land on different banks
+            m.rep_stride = rep_stride_m;
             m.flags = flags;
             for (int l = 0; l < kMfmaMaxTaps; ++l) {
                 m.shifts[l] = shifts[order[std::min(l, L - 1)]];
@@ -171,13 +175,24 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
                 if (rc != GAT_OK) return rc;
             }
             m.partial = c->d_partial;
-            const unsigned lds = (unsigned)mfma_lds_bytes(nct, CT, m.rep_stride);
+#ifdef GAT_MFMA_STAMPS
+            {
+                static unsigned long long *dbg = nullptr;
+                if (!dbg) hipMalloc(reinterpret_cast<void **>(&dbg), 8u << 20);
+                m.dbg = dbg;
+                if (const char *e = std::getenv("GAT_DBG_DUMP")) (void)e;
+                c->dbg_ptr = dbg;
+            }
+#endif
+            m.codes_in_lds = 1;
+            if (mfma_lds_bytes(nct, CT, m.rep_stride, c->code_row_stride, 1) > 160 * 1024) m.codes_in_lds = 0;
+            const unsigned lds = (unsigned)mfma_lds_bytes(nct, CT, m.rep_stride, c->code_row_stride, m.codes_in_lds);
             GAT_HIP(c, launch_mfma(m, nct, (unsigned)grid_m, lds, c->stream));
             const bool fin_m = !atomic_m && m.splits > 1;
             if (fin_m)
                 GAT_HIP(c, launch_finalize(c->d_partial, out_re, out_im, m.splits, L * M * 2, (long long)B * K, c->stream));
             c->last.workgroups = (int32_t)grid_m;
-            c->last.threads = kThreads;
+            c->last.threads = 2 * kThreads;
             c->last.splits = m.splits;
             c->last.ant_tile = 16;
             c->last.vec = 4;
@@ -613,6 +628,16 @@ GAT_API int32_t gat_timer_stop(gat_ctx *c, float *ms)
     c->timer_running = false;
     return GAT_OK;
 }
+
+#ifdef GAT_MFMA_STAMPS
+extern "C" GAT_API int32_t gat_debug_read(gat_ctx *c, unsigned long long *host, size_t count)
+{
+    if (!c || !c->dbg_ptr) return GAT_ERR_STATE;
+    GAT_HIP(c, hipStreamSynchronize(c->stream));
+    GAT_HIP(c, hipMemcpy(host, c->dbg_ptr, count * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return GAT_OK;
+}
+#endif
 
 GAT_API int32_t gat_set_matrix_core(gat_ctx *c, int32_t enable)
 {

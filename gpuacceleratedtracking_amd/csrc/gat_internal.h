@@ -80,12 +80,14 @@ struct MfArgs {
     int ant_tiles;       // M / 16
     int splits, steps_per_split, total_steps, num_tiles;
     int max_abs_shift, rep_span, rep_stride;
+    int codes_in_lds;    // 1: the workgroup's chip tables are staged in LDS (they fit)
+    unsigned long long *dbg; // diagnostic builds only (GAT_MFMA_STAMPS): per-wave cycle sums
     unsigned flags;
     int shifts[kMfmaMaxTaps];    // ascending
     int tap_index[kMfmaMaxTaps]; // position in the caller's list
 };
 hipError_t launch_mfma(const MfArgs &a, int nct, unsigned grid, unsigned lds_bytes, hipStream_t s);
-size_t mfma_lds_bytes(int nct, int ct, int rep_stride);
+size_t mfma_lds_bytes(int nct, int ct, int rep_stride, int code_row_stride, int codes_in_lds);
 
 // Launchers implemented in gat_kernels.hip.  All return hipError_t of the launch.
 hipError_t launch_dc(const DcArgs &a, const DcLaunch &cfg, hipStream_t s);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Throughput of every BASELINE config that fits one GPU (parity for these shapes is in tests/).
-run() { python bench.py --no-cpu-baseline --steps 10 --warmup 2 "$@" 2>/dev/null | python -c "
+run() { timeout 180 python bench.py --no-cpu-baseline --steps 10 --warmup 2 "$@" 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); r=d['roofline']; c=d['config']
 print(c['workload']); print('   value %.1f Msamples/s  rtf %.1f  achieved %.1f GB/s frac %.3f  ms/launch %.4f err %.2e launch %s' % (d['value'], d['real_time_factor'], r['achieved'], r['frac'], r['kernel_ms_per_launch'], d['parity_max_rel_err_vs_f64_oracle'], c['launch']))"; }

@@ -7,14 +7,14 @@ OUT=$REPO/gpurun_out/pmcg_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/p" -- python3 "$REPO/bench.py" --steps 4 --warmup 1 --no-cpu-baseline "$@" > "$OUT/b.json" 2> "$OUT/p.log"
+timeout 300 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d "$OUT/p" -- python3 "$REPO/bench.py" --steps 4 --warmup 1 --no-cpu-baseline "$@" > "$OUT/b.json" 2> "$OUT/p.log"
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 out = sys.argv[1]
 acc = {}
 for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "dc_kernel" in r["Kernel_Name"]:
+        if "dc_kernel" in r["Kernel_Name"] or "mfma_kernel" in r["Kernel_Name"]:
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
             acc.setdefault("_dur_ns", []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for k in sorted(acc):
