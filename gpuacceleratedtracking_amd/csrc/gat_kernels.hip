@@ -82,10 +82,14 @@ __device__ __forceinline__ int chip_index(double ratio, double tau, int x, int L
 }
 
 // Butterfly reduce-scatter over one wave64: NV per-lane values -> after 6 steps each lane
-// holds the full wave sum of ONE value (id[0]); 25 shuffles for NV = 24 instead of 144.
+// holds the full wave sum of ONE value; 25 shuffles for NV = 24 instead of 144.  At a step with
+// offset OFF, values 2i / 2i+1 are paired: the lane whose OFF bit is clear keeps 2i and sends
+// 2i+1, its partner does the opposite; an odd leftover is all-reduced.  Which value a lane ends
+// up with is a function of its lane id only (butterfly_index) -- no index array travels with the
+// values (it would double the register footprint of the epilogue, the kernel's pressure peak).
 template <int NV, int OFF>
 struct Butterfly {
-    static __device__ __forceinline__ void run(float *v, int *id, int lane)
+    static __device__ __forceinline__ void run(float *v, int lane)
     {
         constexpr int H = NV / 2;
         const bool up = (lane & OFF) != 0;
@@ -94,23 +98,26 @@ struct Butterfly {
             // load both operands unconditionally: a ternary on the array elements themselves is
             // turned into a dynamically indexed (scratch) access by the compiler
             const float lo = v[2 * i], hi = v[2 * i + 1];
-            const int ilo = id[2 * i], ihi = id[2 * i + 1];
             const float keep = up ? hi : lo;
             const float send = up ? lo : hi;
-            const float recv = __shfl_xor(send, OFF, 64);
-            v[i] = keep + recv;
-            id[i] = up ? ihi : ilo;
+            v[i] = keep + __shfl_xor(send, OFF, 64);
         }
-        if constexpr (NV & 1) {
-            v[H] = v[NV - 1] + __shfl_xor(v[NV - 1], OFF, 64);
-            id[H] = id[NV - 1];
-        }
-        Butterfly<(NV + 1) / 2, OFF / 2>::run(v, id, lane);
+        if constexpr (NV & 1) v[H] = v[NV - 1] + __shfl_xor(v[NV - 1], OFF, 64);
+        Butterfly<(NV + 1) / 2, OFF / 2>::run(v, lane);
+    }
+    // original index of the value that ends in slot `slot` after this and all later steps
+    static __device__ __forceinline__ int index(int lane)
+    {
+        const int j = Butterfly<(NV + 1) / 2, OFF / 2>::index(lane); // slot before the later steps
+        constexpr int H = NV / 2;
+        if ((NV & 1) && j == H) return NV - 1;
+        return 2 * j + ((lane & OFF) ? 1 : 0);
     }
 };
 template <int NV>
 struct Butterfly<NV, 0> {
-    static __device__ __forceinline__ void run(float *, int *, int) {}
+    static __device__ __forceinline__ void run(float *, int) {}
+    static __device__ __forceinline__ int index(int) { return 0; } // the survivor sits in slot 0
 };
 
 __device__ __forceinline__ float wave_sum(float v)
@@ -195,6 +202,8 @@ struct SampleIO {
     }
 };
 
+// No minimum-waves bound on purpose: <4,3,4,planar> needs 136 VGPRs (3 waves/SIMD) and any tighter
+// bound spills to scratch (measured: 4 waves/SIMD no gain at configs[1], 5 and 6 are 1.3-1.8x slower).
 template <int MT, int L, int VEC, int FMT>
 __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
 {
@@ -332,6 +341,9 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
     // this step's replica segment: entry i <-> sample c*CHUNK + shift0 + i (src/algorithms.jl:753-757)
     auto fill_replica = [&](float *rep, int c) {
         const int x0 = c * CHUNK + shift0;
+        // not unrolled on purpose: the FP64 temporaries of 4-5 unrolled iterations cost ~30 VGPRs,
+        // i.e. one wave per SIMD of occupancy, and this loop runs in the shadow of the sample loads
+#pragma unroll 1
         for (int i = tid; i < rep_cnt; i += kThreads)
             rep[(i & 3) * rep_ps + (i >> 2)] = (float)s_code[chip_index(ratio, tau, x0 + i, Lc, inv_lc)];
     };
@@ -369,7 +381,6 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
     constexpr int NV = 2 * MT * L;
     static_assert(NV <= 64, "one value per lane after the butterfly");
     float v[NV];
-    int id[NV];
 #pragma unroll
     for (int l = 0; l < L; ++l)
 #pragma unroll
@@ -377,10 +388,8 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
             v[(l * MT + m) * 2 + 0] = acc_re[m][l];
             v[(l * MT + m) * 2 + 1] = acc_im[m][l];
         }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) id[i] = i;
-    Butterfly<NV, 32>::run(v, id, lane);
-    s_part[wave * 64 + id[0]] = v[0]; // lanes sharing an id hold bit-identical sums
+    Butterfly<NV, 32>::run(v, lane);
+    s_part[wave * 64 + Butterfly<NV, 32>::index(lane)] = v[0]; // lanes sharing an index hold bit-identical sums
     __syncthreads();
 
     if (tid < NV) {
