@@ -20,6 +20,8 @@ GAT_LAYOUT_INTERLEAVED_I8 = 3
 # bytes of one complex sample per layout
 SAMPLE_BYTES = {0: 8, 1: 8, 2: 4, 3: 2}
 GAT_MAX_TAPS = 32
+# kernel selection (gat_set_matrix_core)
+GAT_MC_VECTOR, GAT_MC_AUTO, GAT_MC_F32, GAT_MC_BF16_SPLIT = 0, 1, 2, 3
 
 EXPORTS = [
     "gat_create", "gat_destroy", "gat_set_stream", "gat_sync", "gat_last_error", "gat_version",

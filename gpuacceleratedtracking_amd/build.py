@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgat.so")
-SOURCES = ["gat_kernels.hip", "gat_mfma.hip", "gat_api.cpp", "gat_codes.cpp"]
+SOURCES = ["gat_kernels.hip", "gat_mfma.hip", "gat_mfma_bf16.hip", "gat_api.cpp", "gat_codes.cpp"]
 HEADERS = [os.path.join(CSRC, "gat_internal.h"), os.path.join(ROOT, "include", "gat.h")]
 
 
@@ -24,31 +24,57 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
-def command(out: str = LIB) -> list[str]:
+def _flags(extra: tuple[str, ...] = ()) -> list[str]:
     # -ffp-contract=off: the double-precision code phase must not be fused (gat_kernels.hip);
-    # fused multiply-adds in the hot loop are written explicitly with __builtin_fmaf.
-    return [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-            "-fvisibility=hidden", "-DGAT_BUILD", "-ffp-contract=off",
-            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-            *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
+    # fused multiply-adds in the hot loops are written explicitly with __builtin_fmaf.
+    return ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-DGAT_BUILD",
+            "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *extra]
 
 
-def is_stale() -> bool:
-    if not os.path.exists(LIB):
+def command(out: str = LIB) -> list[str]:
+    """The one-line recipe (what INTEGRATION.md quotes); build_libgat() runs the same flags per source
+    so that an edit to one kernel file does not recompile the others."""
+    return [hipcc_path(), *_flags(), "-shared", *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
+
+
+def is_stale(lib: str = LIB) -> bool:
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_libgat(force: bool = False, verbose: bool = False) -> str:
-    """Compile libgat.so for gfx950 if missing or older than its sources."""
-    if force or is_stale():
-        cmd = command()
+def build_libgat(force: bool = False, verbose: bool = False, extra_flags: tuple[str, ...] = (), out: str = LIB) -> str:
+    """Compile libgat.so for gfx950 if missing or older than its sources: one object per source under
+    build/obj/ (compiled concurrently, reused while newer than source + headers), then one link.
+    ``extra_flags`` / ``out``: diagnostic variants (e.g. -DGAT_MFMA_STAMPS -> build/libgat_stamps.so)."""
+    if not (force or is_stale(out)):
+        return out
+    from concurrent.futures import ThreadPoolExecutor
+
+    tag = "obj" + ("_" + "_".join(f.lstrip("-").replace("=", "_") for f in extra_flags) if extra_flags else "")
+    objdir = os.path.join(ROOT, "build", tag)
+    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    hdr_t = max(os.path.getmtime(h) for h in HEADERS + [os.path.abspath(__file__)])
+    jobs, objs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(sp), hdr_t):
+            jobs.append([hipcc_path(), *_flags(extra_flags), "-c", sp, "-o", obj])
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
-    return LIB
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out])
+    return out
 
 
 def build_c_example(force: bool = False) -> str:
@@ -63,4 +89,10 @@ def build_c_example(force: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build_libgat(force=True, verbose=True))
+    import sys
+
+    if "--stamps" in sys.argv:  # diagnostic build of the matrix kernels with per-wave cycle stamps
+        print(build_libgat(extra_flags=("-DGAT_MFMA_STAMPS",), out=os.path.join(ROOT, "build", "libgat_stamps.so"),
+                           verbose=True))
+    else:
+        print(build_libgat(force="--force" in sys.argv, verbose=True))

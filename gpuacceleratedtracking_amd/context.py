@@ -68,9 +68,11 @@ class Context:
         self.check(self.lib.gat_last_launch_info(self._h, C.byref(info)), "gat_last_launch_info")
         return {n: getattr(info, n) for n, _ in info._fields_}
 
-    def set_matrix_core(self, enable: bool):
-        """Allow (default) or forbid the MFMA kernel for antenna-rich shapes (A/B, bit comparisons)."""
-        self.check(self.lib.gat_set_matrix_core(self._h, 1 if enable else 0), "gat_set_matrix_core")
+    def set_matrix_core(self, mode):
+        """Kernel selection for antenna-rich shapes (include/gat.h GAT_MC_*): True / 1 = auto (default:
+        split-bf16 MFMA kernel where it applies), False / 0 = vector kernel only, 2 = f32-MFMA kernel,
+        3 = split-bf16 MFMA kernel only."""
+        self.check(self.lib.gat_set_matrix_core(self._h, int(mode)), "gat_set_matrix_core")
 
     def timer_start(self):
         self.check(self.lib.gat_timer_start(self._h), "gat_timer_start")

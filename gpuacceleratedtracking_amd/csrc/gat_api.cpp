@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "gat_internal.h"
 
@@ -23,6 +24,8 @@ struct gat_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int8_t *d_codes = nullptr;
+    uint32_t *d_code_bits = nullptr; // bit i of row p = (chip i of PRN p is -1); only when every chip is +-1
+    int code_bits_stride = 0;        // dwords per row, a multiple of 4
     int Lc = 0, P = 0, code_row_stride = 0; // rows padded to a multiple of 16 bytes
     float *d_partial = nullptr;
     size_t partial_bytes = 0;
@@ -32,7 +35,7 @@ struct gat_ctx {
     bool timer_running = false;
     int num_cus = 256;
     unsigned long long *dbg_ptr = nullptr; // diagnostic builds only
-    bool no_mfma = false; // GAT_NO_MFMA=1: always use the vector kernel (A/B experiments)
+    int mc_mode = 1; // GAT_MC_* kernel selection (gat_set_matrix_core); env GAT_NO_MFMA=1 starts at 0
     std::string err;
     gat_launch_info last{};
 };
@@ -117,22 +120,40 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
 
     const long long N = sig->num_samples;
 
-    // ---- matrix-core path (gat_mfma.hip): antenna-rich shapes whose (channel, tap) columns fill
-    // a useful part of a 32-column tile; everything else takes the vector kernel below.
+    // ---- matrix-core paths: antenna-rich shapes whose (channel, tap) columns fill a useful part of
+    // a 32-column tile run on the matrix cores -- the split-bf16 kernel (gat_mfma_bf16.hip) by default,
+    // the f32-MFMA kernel (gat_mfma.hip) on request; everything else takes the vector kernel below.
     {
         int order[GAT_MAX_TAPS];
         for (int l = 0; l < L; ++l) order[l] = l;
         std::stable_sort(order, order + L, [&](int x, int y) { return shifts[x] < shifts[y]; });
         const long long span = (long long)shifts[order[L - 1]] - shifts[order[0]];
         const int CT = L <= kMfmaMaxTaps ? 16 / L : 0;
-        bool eligible = !c->no_mfma && planar && vec == 4 && M % 16 == 0 && sig->chan_stride == 0 && CT >= 1 &&
-                        span <= kMfmaMaxSpan && 2 * std::min(K, CT) * L >= 12 /* >= 3/8 of the columns */;
-        const int nct_total = eligible ? (K + CT - 1) / CT : 1;
-        const int nct = nct_total >= 4 ? 4 : (nct_total >= 2 ? 2 : 1);
-        const int rep_stride_m = ((256 + (int)span + 31) / 32) * 32 + 1; // odd: channel rows land on different banks
-        if (eligible && mfma_lds_bytes(nct, CT, rep_stride_m, c->code_row_stride, 0) > 160 * 1024)
-            eligible = false; // tile does not fit in LDS: the vector kernel takes it
-        if (eligible) {
+        const bool shape_ok = c->mc_mode != 0 && planar && vec == 4 && M % 16 == 0 && sig->chan_stride == 0 && CT >= 1 &&
+                              span <= kMfmaMaxSpan && 2 * std::min(K, CT) * L >= 12 /* >= 3/8 of the columns */;
+        const int nct_total = shape_ok ? (K + CT - 1) / CT : 1;
+        int nct = nct_total >= 4 ? 4 : (nct_total >= 2 ? 2 : 1);
+        // kernel choice: 3 / 1 (auto) -> split-bf16 when its tile fits in LDS, 2 -> f32 MFMA
+        int kind = 0, rt = 1, rep_stride_m = 0;
+        if (shape_ok && c->mc_mode != 2 && c->d_code_bits && N % 4 == 0) {
+            rt = (M / 16) % 4 == 0 ? 4 : ((M / 16) % 2 == 0 ? 2 : 1);
+            if (rt == 4 && nct == 1) rt = 2; // <4,1> does not fit the 168-VGPR budget of a 12-wave workgroup
+            for (int n = nct; n >= 1 && !kind; n >>= 1) {
+                const int T = mfma_bf16_tile_samples(rt, n);
+                const int rs = ((T + (int)span + 31) / 32) * 32 + 1; // odd: channel rows land on different banks
+                if (mfma_bf16_lds_bytes(rt, n, CT, rs, c->code_bits_stride) <= 160 * 1024) {
+                    kind = 2;
+                    nct = n;
+                    rep_stride_m = rs;
+                }
+            }
+        }
+        if (shape_ok && !kind && c->mc_mode != 3) {
+            rep_stride_m = ((256 + (int)span + 31) / 32) * 32 + 1;
+            if (mfma_lds_bytes(nct, CT, rep_stride_m, c->code_row_stride, 0) <= 160 * 1024) kind = 1;
+        }
+        if (kind) {
+            const int T = kind == 2 ? mfma_bf16_tile_samples(rt, nct) : 256;
             MfArgs m{};
             m.re = static_cast<const float *>(sig->re);
             m.im = static_cast<const float *>(sig->im);
@@ -147,12 +168,15 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             m.M = M; m.K = K; m.B = B; m.L = L; m.Lc = c->Lc; m.num_prns = c->P; m.code_row_stride = c->code_row_stride;
             m.CT = CT;
             m.chan_groups = (nct_total + nct - 1) / nct;
-            m.ant_tiles = M / 16;
-            m.total_steps = (int)((N + 255) / 256);
+            m.ant_tiles = kind == 2 ? M / (16 * rt) : M / 16;
+            m.total_steps = (int)((N + T - 1) / T);
             const long long groups_m = (long long)B * m.ant_tiles * m.chan_groups;
-            long long sp = std::max<long long>(1, (4ll * c->num_cus + groups_m - 1) / groups_m);
+            // the split-bf16 kernel runs one 8-wave workgroup per CU (its LDS tile): 2 rounds fill the chip
+            const long long want = (kind == 2 ? 2ll : 4ll) * c->num_cus;
+            long long sp = std::max<long long>(1, (want + groups_m - 1) / groups_m);
             sp = std::min<long long>(sp, m.total_steps);
             m.steps_per_split = (int)((m.total_steps + sp - 1) / sp);
+            if (kind == 2) m.steps_per_split = std::min(m.steps_per_split, std::max(1, mfma_bf16_max_chain() / T));
             m.splits = (m.total_steps + m.steps_per_split - 1) / m.steps_per_split;
             m.num_tiles = B * m.ant_tiles * m.splits;
             m.max_abs_shift = (int)max_shift;
@@ -180,25 +204,32 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
                 static unsigned long long *dbg = nullptr;
                 if (!dbg) hipMalloc(reinterpret_cast<void **>(&dbg), 8u << 20);
                 m.dbg = dbg;
-                if (const char *e = std::getenv("GAT_DBG_DUMP")) (void)e;
                 c->dbg_ptr = dbg;
             }
 #endif
-            m.codes_in_lds = 1;
-            if (mfma_lds_bytes(nct, CT, m.rep_stride, c->code_row_stride, 1) > 160 * 1024) m.codes_in_lds = 0;
-            const unsigned lds = (unsigned)mfma_lds_bytes(nct, CT, m.rep_stride, c->code_row_stride, m.codes_in_lds);
-            GAT_HIP(c, launch_mfma(m, nct, (unsigned)grid_m, lds, c->stream));
+            unsigned lds;
+            if (kind == 2) {
+                m.codes_in_lds = 1; // sign-bit tables, always staged
+                m.code_bits = c->d_code_bits;
+                m.code_bits_stride = c->code_bits_stride;
+                lds = (unsigned)mfma_bf16_lds_bytes(rt, nct, CT, m.rep_stride, c->code_bits_stride);
+                GAT_HIP(c, launch_mfma_bf16(m, rt, nct, (unsigned)grid_m, lds, c->stream));
+            } else {
+                m.codes_in_lds = mfma_lds_bytes(nct, CT, m.rep_stride, c->code_row_stride, 1) <= 160 * 1024;
+                lds = (unsigned)mfma_lds_bytes(nct, CT, m.rep_stride, c->code_row_stride, m.codes_in_lds);
+                GAT_HIP(c, launch_mfma(m, nct, (unsigned)grid_m, lds, c->stream));
+            }
             const bool fin_m = !atomic_m && m.splits > 1;
             if (fin_m)
                 GAT_HIP(c, launch_finalize(c->d_partial, out_re, out_im, m.splits, L * M * 2, (long long)B * K, c->stream));
             c->last.workgroups = (int32_t)grid_m;
-            c->last.threads = 2 * kThreads;
+            c->last.threads = kind == 2 ? 768 : 2 * kThreads;
             c->last.splits = m.splits;
-            c->last.ant_tile = 16;
+            c->last.ant_tile = kind == 2 ? 16 * rt : 16;
             c->last.vec = 4;
             c->last.lds_bytes = (int32_t)lds;
             c->last.finalize_launched = fin_m ? 1 : 0;
-            c->last.matrix_core = 1;
+            c->last.matrix_core = kind;
             return GAT_OK;
         }
     }
@@ -336,7 +367,8 @@ GAT_API int32_t gat_create(int32_t device, void *hip_stream, gat_ctx **out_ctx)
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
-    if (const char *e = std::getenv("GAT_NO_MFMA")) c->no_mfma = e[0] == '1';
+    if (const char *e = std::getenv("GAT_NO_MFMA")) c->mc_mode = e[0] == '1' ? 0 : 1;
+    if (const char *e = std::getenv("GAT_MC_MODE")) c->mc_mode = (e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
         delete c;
         return -(int32_t)e;
@@ -351,6 +383,7 @@ GAT_API int32_t gat_destroy(gat_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->d_codes) (void)hipFree(c->d_codes);
+    if (c->d_code_bits) (void)hipFree(c->d_code_bits);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -417,6 +450,10 @@ GAT_API int32_t gat_set_codes(gat_ctx *c, const int8_t *codes_host, int32_t code
         GAT_HIP(c, hipFree(c->d_codes));
         c->d_codes = nullptr;
     }
+    if (c->d_code_bits) {
+        GAT_HIP(c, hipFree(c->d_code_bits));
+        c->d_code_bits = nullptr;
+    }
     const int stride = (code_length + 15) & ~15; // 16-byte rows: dc_kernel stages them with 16-byte copies
     const size_t bytes = (size_t)stride * num_prns;
     GAT_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->d_codes), bytes));
@@ -426,6 +463,19 @@ GAT_API int32_t gat_set_codes(gat_ctx *c, const int8_t *codes_host, int32_t code
     c->code_row_stride = stride;
     c->Lc = code_length;
     c->P = num_prns;
+    // sign-bit tables for the split-bf16 matrix kernel (a chip only flips signs there): 1/8 of the LDS
+    bool pm1 = true;
+    for (size_t i = 0; i < (size_t)code_length * num_prns && pm1; ++i) pm1 = codes_host[i] == 1 || codes_host[i] == -1;
+    if (pm1) {
+        const int bstride = (((code_length + 31) / 32) + 3) & ~3;
+        std::vector<uint32_t> bits((size_t)bstride * num_prns, 0u);
+        for (int p = 0; p < num_prns; ++p)
+            for (int i = 0; i < code_length; ++i)
+                if (codes_host[(size_t)p * code_length + i] < 0) bits[(size_t)p * bstride + (i >> 5)] |= 1u << (i & 31);
+        GAT_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->d_code_bits), bits.size() * sizeof(uint32_t)));
+        GAT_HIP(c, hipMemcpy(c->d_code_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->code_bits_stride = bstride;
+    }
     return GAT_OK;
 }
 
@@ -642,7 +692,8 @@ extern "C" GAT_API int32_t gat_debug_read(gat_ctx *c, unsigned long long *host, 
 GAT_API int32_t gat_set_matrix_core(gat_ctx *c, int32_t enable)
 {
     if (!c) return GAT_ERR_ARG;
-    c->no_mfma = enable == 0;
+    if (enable < GAT_MC_VECTOR || enable > GAT_MC_BF16_SPLIT) return fail(c, GAT_ERR_ARG, "unknown matrix-core mode");
+    c->mc_mode = enable;
     return GAT_OK;
 }
 

@@ -69,6 +69,7 @@ struct MfArgs {
     const float *im;
     const gat_channel_params *params;
     const int8_t *codes;
+    const uint32_t *code_bits; // split-bf16 kernel: sign-bit tables [P][code_bits_stride]
     float *out_re;
     float *out_im;
     float *partial;
@@ -77,9 +78,10 @@ struct MfArgs {
     int M, K, B, L, Lc, num_prns, code_row_stride;
     int CT;              // channels per 32-column tile = 16 / L
     int chan_groups;     // ceil(ceil(K / CT) / NCT)
-    int ant_tiles;       // M / 16
+    int ant_tiles;       // M / 16 (f32 kernel) or M / (16 * rt) (split-bf16 kernel)
     int splits, steps_per_split, total_steps, num_tiles;
     int max_abs_shift, rep_span, rep_stride;
+    int code_bits_stride; // dwords per sign-bit row (multiple of 4)
     int codes_in_lds;    // 1: the workgroup's chip tables are staged in LDS (they fit)
     unsigned long long *dbg; // diagnostic builds only (GAT_MFMA_STAMPS): per-wave cycle sums
     unsigned flags;
@@ -88,6 +90,11 @@ struct MfArgs {
 };
 hipError_t launch_mfma(const MfArgs &a, int nct, unsigned grid, unsigned lds_bytes, hipStream_t s);
 size_t mfma_lds_bytes(int nct, int ct, int rep_stride, int code_row_stride, int codes_in_lds);
+// split-bf16 matrix-core kernel (gat_mfma_bf16.hip): rt = 16-antenna row tiles per workgroup (1, 2, 4)
+hipError_t launch_mfma_bf16(const MfArgs &a, int rt, int nct, unsigned grid, unsigned lds_bytes, hipStream_t s);
+size_t mfma_bf16_lds_bytes(int rt, int nct, int ct, int rep_stride, int code_bits_stride);
+int mfma_bf16_tile_samples(int rt, int nct);
+int mfma_bf16_max_chain(); // samples one accumulation chain may cover
 
 // Launchers implemented in gat_kernels.hip.  All return hipError_t of the launch.
 hipError_t launch_dc(const DcArgs &a, const DcLaunch &cfg, hipStream_t s);

@@ -1,0 +1,571 @@
+// gat_mfma_bf16.hip -- downconvert + correlate on the bf16 matrix pipe with FP32-equivalent
+// accuracy: both GEMM operands are split into three bf16 terms (hi + mid + lo carries all 24
+// mantissa bits of an f32) and the cross products are laid along the MFMA's reduction dimension.
+//
+//   R[m,(k,l)] = sum_n x[n,m] * W[n,(k,l)],   W = conj(carrier_k[n]) * c_k[n + shift_l]
+//
+// as the real GEMM  C[32 x 32] += X^T[32 x 16] * W[16 x 32]  on v_mfma_f32_32x32x16_bf16:
+//   rows    i = 2*m + {x_re, x_im}            (16 antennas per row tile, RT row tiles per wave)
+//   columns j = 2*(kc*L + l) + {w_re = chip*cos, w_im = -chip*sin}   (CT = 16/L channels)
+//   the 16 reduction slots = 2 samples (one per 32-lane half) x 8 cross products:
+//        slot        0    1    2    3    4    5    6    7
+//        x term      hi   mid  hi   mid  hi   mid  lo   lo       = dwords {a, a, a, b}
+//        w term      hi   hi   mid  mid  lo   lo   hi   mid      = dwords {hh, mm, ll, hm}
+//   i.e. every product of the 3 x 3 expansion except lo*lo (2^-32 relative).  bf16 x bf16 is exact
+//   in f32 and the pipe accumulates in f32, so the result carries f32 accuracy at 8/16 of the bf16
+//   MFMA rate -- 8x the FP32 MFMA / vector rate (gat_mfma.hip measured the f32 MFMA at the vector rate,
+//   sharing its issue with the VALU; this pipe runs beside the VALU).
+//
+// x is split once per sample by the producer waves into LDS as {a = hi|mid<<16, b = lo|lo<<16}
+// (8 B per value; the consumer's X fragment is {a, a, a, b}: no arithmetic).  The carrier is split once
+// per (sample, channel) into the four W dwords for w_re and w_im (16 B each); the chip only flips
+// signs: the consumer XORs the fragment with a 0x80008000 / 0 mask from the LDS code replica -- the
+// three taps and the 16*RT antennas of a tile all reuse one carrier split.
+// Code replica: exactly the reference's FP64 expression, unfused (src/algorithms.jl:179), as in the
+// other kernels; per step only the T new entries are evaluated, the tap-span overlap is copied
+// from the previous step's buffer.
+// One accumulation chain covers at most kMaxChain samples (the planner splits longer blocks over
+// workgroups, finalize_kernel adds the partials in a fixed order), so the f32 rounding of a running
+// sum of millions of samples stays far inside 1e-5.
+#include "gat_internal.h"
+
+#include <utility>
+
+namespace gat {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int kMbThreads = 768; // 4 consumer + 8 producer waves
+constexpr int kMaxChain = 8192;  // samples per accumulation chain (f32 rounding of the running sum)
+constexpr int kHeader = 1536; // ChanInfoB[<= 20] (64 B each) + slack, 16-byte aligned
+
+__device__ __forceinline__ void sincos_cycles_b(double theta, float &c, float &s)
+{
+    const double q = __builtin_rint(theta * 4.0);
+    const double r = __builtin_fma(q, -0.25, theta);
+    const float a = (float)r * 6.283185307179586f;
+    const float a2 = a * a;
+    float sp = __builtin_fmaf(a2, 2.7557319e-6f, -1.9841270e-4f);
+    sp = __builtin_fmaf(a2, sp, 8.3333333e-3f);
+    sp = __builtin_fmaf(a2, sp, -1.6666667e-1f);
+    sp = __builtin_fmaf(a2 * a, sp, a);
+    float cp = __builtin_fmaf(a2, 2.4801587e-5f, -1.3888889e-3f);
+    cp = __builtin_fmaf(a2, cp, 4.1666667e-2f);
+    cp = __builtin_fmaf(a2, cp, -0.5f);
+    cp = __builtin_fmaf(a2, cp, 1.0f);
+    const int qi = (int)(long long)q & 3;
+    const float cs = (qi & 1) ? sp : cp;
+    const float sn = (qi & 1) ? cp : sp;
+    c = (qi == 1 || qi == 2) ? -cs : cs;
+    s = (qi >= 2) ? -sn : sn;
+}
+
+// hi/mid/lo bf16 terms of a float by TRUNCATION: hi = top 16 bits of v, mid = top 16 bits of
+// r = v - hi, lo = top 16 bits of r2 = r - mid.  Every residual is exact in f32 and each term takes 8
+// of the 24 mantissa bits, so v == hi + mid + lo exactly (all three carry v's sign).
+struct Split3 {
+    unsigned v, r, r2; // bit patterns whose top halves are the hi / mid / lo terms
+};
+__device__ __forceinline__ Split3 split3(float v)
+{
+    Split3 s;
+    s.v = __float_as_uint(v);
+    const float r = v - __uint_as_float(s.v & 0xffff0000u);
+    s.r = __float_as_uint(r);
+    s.r2 = __float_as_uint(r - __uint_as_float(s.r & 0xffff0000u));
+    return s;
+}
+// The sample prefetch is written as inline assembly with its own s_waitcnt: hipcc's counter
+// insertion over-waits across the two-phase loop (it asked for the NEWEST loads too, i.e. no
+// prefetch distance).  The compiler does not see these loads; every use of the destination goes
+// through wait_loads(), which ties the registers to the wait.
+__device__ __forceinline__ void gload_nt(f32x4_ &dst, const void *p)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int PENDING_NEWER, int XI>
+__device__ __forceinline__ void wait_loads(f32x4_ (&xv)[XI])
+{
+    static_assert(XI == 1 || XI == 2, "prefetch group size");
+    if constexpr (XI == 1)
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xv[0]) : "n"(PENDING_NEWER) : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xv[0]), "+v"(xv[1]) : "n"(PENDING_NEWER) : "memory");
+}
+// __builtin_amdgcn_perm(a, b, sel): result byte i = byte sel[i] of {b: 0-3, a: 4-7}
+#define GAT_PERM(a, b, sel) __builtin_amdgcn_perm((a), (b), (sel))
+
+// ---- consumer fragment fetches -------------------------------------------------------------------
+// All LDS reads of the MFMA loop are inline assembly, issued TWO k-slices ahead of their use into a
+// ring of three register sets, with one explicit counted s_waitcnt per slice (the slice in between may
+// stay in flight): an LDS round trip under this kernel's load is longer than the 32 * RT cycles of a
+// slice.  lgkmcnt holds at most 15 operations, hence one ds_read_b64 per X fragment (2 + RT reads per
+// slice, 2 slices outstanding).  The X fragment {a, a, a, b} is the fetched {a, b} plus ONE
+// v_pk_mov_b32 for the {a, a} half (plain C++ gets three v_mov per MFMA, on the unit that limits
+// this kernel).
+template <int RT>
+struct FragSet {
+    u32x4 w;
+    unsigned m;
+    u32x2 xa[RT];
+};
+template <int J, int RT>
+__device__ __forceinline__ void frag_issue(FragSet<RT> &s, unsigned w_addr, unsigned r_addr, const unsigned (&x_addr)[RT])
+{
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(s.w) : "v"(w_addr), "n"(J * 16));
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(s.m) : "v"(r_addr), "n"(J * 4));
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(s.xa[t]) : "v"(x_addr[t]), "n"(J * 8));
+}
+template <int RT, int NEWER> // NEWER: reads issued after this set's that may stay in flight
+__device__ __forceinline__ void frag_wait(FragSet<RT> &s)
+{
+    static_assert(RT == 1 || RT == 2 || RT == 4, "row tiles");
+    static_assert(NEWER <= 15, "lgkmcnt is a 4-bit counter");
+    if constexpr (RT == 1)
+        asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(s.w), "+v"(s.m), "+v"(s.xa[0]) : "n"(NEWER));
+    else if constexpr (RT == 2)
+        asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(s.w), "+v"(s.m), "+v"(s.xa[0]), "+v"(s.xa[1]) : "n"(NEWER));
+    else
+        asm volatile("s_waitcnt lgkmcnt(%6)"
+                     : "+v"(s.w), "+v"(s.m), "+v"(s.xa[0]), "+v"(s.xa[1]), "+v"(s.xa[2]), "+v"(s.xa[3])
+                     : "n"(NEWER));
+}
+template <int J, int NM, int RT>
+__device__ __forceinline__ void mfma_slice(f32x16 (&acc)[RT], FragSet<RT> (&fs)[3], unsigned w_addr, unsigned r_addr,
+                                           const unsigned (&x_addr)[RT])
+{
+    FragSet<RT> &cur = fs[J % 3];
+    frag_wait<RT, (J + 1 < NM ? 2 + RT : 0)>(cur);
+    if constexpr (J + 2 < NM) frag_issue<J + 2, RT>(fs[(J + 2) % 3], w_addr, r_addr, x_addr);
+    u32x4 w = cur.w;
+    const unsigned mk = cur.m; // chip sign of this column's tap: 0x80008000 or 0
+    w[0] ^= mk;
+    w[1] ^= mk;
+    w[2] ^= mk;
+    w[3] ^= mk;
+    const bf16x8 bw = __builtin_bit_cast(bf16x8, w);
+    // {a, a} halves of the RT fragments.  The trailing s_nop is the VALU-write -> MFMA-read hazard the
+    // compiler would handle itself if it could see inside the asm (it pads its own v_xor the same way).
+    u32x2 aa[RT];
+    if constexpr (RT == 1)
+        asm("v_pk_mov_b32 %0, %1, %1 op_sel:[0,0]\n\ts_nop 1" : "=&v"(aa[0]) : "v"(cur.xa[0]));
+    else if constexpr (RT == 2)
+        asm("v_pk_mov_b32 %0, %2, %2 op_sel:[0,0]\n\tv_pk_mov_b32 %1, %3, %3 op_sel:[0,0]\n\ts_nop 1"
+            : "=&v"(aa[0]), "=&v"(aa[1])
+            : "v"(cur.xa[0]), "v"(cur.xa[1]));
+    else
+        asm("v_pk_mov_b32 %0, %4, %4 op_sel:[0,0]\n\tv_pk_mov_b32 %1, %5, %5 op_sel:[0,0]\n\t"
+            "v_pk_mov_b32 %2, %6, %6 op_sel:[0,0]\n\tv_pk_mov_b32 %3, %7, %7 op_sel:[0,0]\n\ts_nop 1"
+            : "=&v"(aa[0]), "=&v"(aa[1]), "=&v"(aa[2]), "=&v"(aa[3])
+            : "v"(cur.xa[0]), "v"(cur.xa[1]), "v"(cur.xa[2]), "v"(cur.xa[3]));
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        const unsigned a0 = aa[t][0], a1 = aa[t][1], a2 = cur.xa[t][0], b3 = cur.xa[t][1];
+        const u32x4 af = u32x4{a0, a1, a2, b3};
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), bw, acc[t], 0, 0, 0);
+    }
+}
+template <int NM, int RT, int... J>
+__device__ __forceinline__ void mfma_step(f32x16 (&acc)[RT], unsigned w_addr, unsigned r_addr, const unsigned (&x_addr)[RT],
+                                          std::integer_sequence<int, J...>)
+{
+    FragSet<RT> fs[3];
+    frag_issue<0, RT>(fs[0], w_addr, r_addr, x_addr);
+    if constexpr (NM > 1) frag_issue<1, RT>(fs[1], w_addr, r_addr, x_addr);
+    (mfma_slice<J, NM, RT>(acc, fs, w_addr, r_addr, x_addr), ...);
+}
+
+struct ChanInfoB { // per channel slot of the workgroup, in LDS
+    double ratio, tau, step, phi;
+    float wr, wi; // e^{j 2 pi step}: one-sample carrier rotation
+    int prn, valid, bad, pad;
+    int pad2[2];
+};
+static_assert(sizeof(ChanInfoB) == 64, "ChanInfoB layout");
+
+constexpr int tile_samples(int RT, int NCT)
+{
+    const int t = 32 * (4 / NCT), cap = 128 / RT;
+    return t < cap ? t : cap;
+}
+
+} // namespace
+
+// RT: 16-antenna row tiles per workgroup (1, 2, 4); NCT: 32-column channel tiles per workgroup (1, 2, 4).
+// Workgroup = 12 waves, three per SIMD: waves 0-3 consumers (MFMA + fragment fetches), waves 4-11
+// producers (HBM loads two steps ahead, bf16 splits, carriers, code replica) -- their long dependent
+// chains (FP64 code phase, sincos, split) hide behind each other and behind the matrix pipe.
+// Double-buffered LDS, one s_barrier per step of T samples.
+template <int RT, int NCT>
+__global__ void __launch_bounds__(kMbThreads) mfma_bf16_kernel(const MfArgs a)
+{
+    constexpr int T = tile_samples(RT, NCT);
+    constexpr int WPT = 4 / NCT;   // consumer waves per channel tile (they split the step's samples)
+    constexpr int SW = T / WPT;    // samples per consumer wave and step
+    constexpr int NM = SW / 2;     // MFMA k-slices per consumer wave and step (two sample streams)
+    constexpr int XS = T + 1;      // u32x2 per plane row (odd: 32 planes x one sample = 32 distinct bank pairs)
+    constexpr int WS = T + 1;      // u32x4 per carrier row
+    constexpr int QPR = T / 4;     // 4-sample groups per plane row
+    constexpr int PT = kMbThreads - kThreads; // producer threads (512)
+    constexpr int NG = RT * 32 * QPR;         // 4-sample groups per step
+    constexpr int XI = (NG + PT - 1) / PT;    // groups per producer thread and step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int CT = a.CT, L = a.L;
+    const int nslots = NCT * CT;
+    const int wrows = 2 * nslots + 1; // + one row of zeros for dead columns
+    const int RS = a.rep_stride;
+    ChanInfoB *s_chan = reinterpret_cast<ChanInfoB *>(smem);
+    u32x2 *s_x = reinterpret_cast<u32x2 *>(smem + kHeader);                 // [2][RT*32][XS]
+    u32x4 *s_w = reinterpret_cast<u32x4 *>(s_x + 2 * RT * 32 * XS);         // [2][wrows][WS]
+    unsigned *s_rep = reinterpret_cast<unsigned *>(s_w + 2 * wrows * WS);   // [2][nslots][RS]
+    unsigned *s_code = s_rep + ((2 * nslots * RS + 3) & ~3); // [nslots][code_bits_stride] sign-bit tables
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= 4;
+    const int ptid = tid - kThreads;
+
+    // workgroup -> (tile, channel group); blocks id and id+8 share an XCD, so the channel groups of
+    // one sample tile run back to back on one L2 (speed only)
+    const unsigned xcd = blockIdx.x & 7u, jq = blockIdx.x >> 3;
+    const int cg = (int)(jq % (unsigned)a.chan_groups);
+    unsigned tile = (jq / (unsigned)a.chan_groups) * 8u + xcd;
+    if (tile >= (unsigned)a.num_tiles) return;
+    const int split = tile % a.splits;
+    tile /= a.splits;
+    const int at = tile % a.ant_tiles;
+    const int b = tile / a.ant_tiles;
+    const int N = (int)a.N; // a multiple of 4 (planner)
+    const int Lc = a.Lc;
+    const float inv_lc = 1.0f / (float)Lc;
+    const int span = a.rep_span;
+
+    if (tid < nslots) {
+        const int k = (cg * NCT + tid / CT) * CT + tid % CT;
+        ChanInfoB ci{};
+        ci.valid = k < a.K;
+        if (ci.valid) {
+            const gat_channel_params P = a.params[(size_t)b * a.K + k];
+            ci.ratio = P.code_freq_hz / a.fs;
+            ci.step = P.carrier_freq_hz / a.fs;
+            ci.tau = P.code_phase_chips;
+            ci.phi = P.carrier_phase_cycles;
+            const double sp = __builtin_fabs(ci.tau) + __builtin_fabs(ci.ratio) * (double)(N + a.max_abs_shift) + 1.0;
+            ci.bad = P.prn < 0 || P.prn >= a.num_prns || !(sp < 1073741824.0) || !(sp < 2097152.0 * (double)Lc) ||
+                     !(ci.ratio >= 0.0) || !(ci.ratio * 32.0 < (double)Lc) || !(ci.step == ci.step) || !(ci.phi == ci.phi);
+            ci.prn = (P.prn < 0 || P.prn >= a.num_prns) ? 0 : P.prn;
+            if (ci.bad) { ci.ratio = 0.0; ci.tau = 0.0; ci.step = 0.0; ci.phi = 0.0; }
+            sincos_cycles_b(ci.step - __builtin_rint(ci.step), ci.wr, ci.wi);
+        }
+        s_chan[tid] = ci;
+    }
+    // the zero rows of both carrier buffers (read by dead columns, never written again)
+    for (int e = tid; e < 2 * WS; e += kMbThreads)
+        s_w[(e / WS) * wrows * WS + 2 * nslots * WS + e % WS] = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+    { // sign-bit tables of this workgroup's channels (the producers must not touch global memory for chips:
+      // vector-memory returns are in order, a table gather would wait for the sample prefetch in flight)
+        const int vec_per_row = a.code_bits_stride / 4;
+        for (int e = tid; e < nslots * vec_per_row; e += kMbThreads) {
+            const int slot = e / vec_per_row, v = e - slot * vec_per_row;
+            const ChanInfoB c = s_chan[slot];
+            if (c.valid)
+                reinterpret_cast<uint4 *>(s_code)[slot * vec_per_row + v] =
+                    reinterpret_cast<const uint4 *>(a.code_bits + (size_t)c.prn * a.code_bits_stride)[v];
+        }
+        __syncthreads();
+    }
+
+    const size_t base = (size_t)b * a.block_stride + (size_t)(at * 16 * RT) * a.ant_stride;
+    const int s_begin = split * a.steps_per_split;
+    const int s_end = min(s_begin + a.steps_per_split, a.total_steps);
+
+    // ---- producers ---------------------------------------------------------------------------------
+    // Sample loads run two steps ahead of the split/store (xvA / xvB alternate).  Every load is an
+    // unconditional 16-byte load (out-of-range groups read the tile's first group and are zeroed at
+    // the store): straight-line code, so the compiler's s_waitcnt counts only the loads that matter.
+    // (the im plane is addressed as re + im_delta: a lane-dependent choice between the two kernel-argument
+    // pointers would be compiled into a per-lane LOAD of the pointer and a wait for it)
+    const long long im_delta = reinterpret_cast<const char *>(a.im) - reinterpret_cast<const char *>(a.re);
+    const char *re_base = reinterpret_cast<const char *>(a.re + base);
+    f32x4_ xvA[XI], xvB[XI];
+    auto load_x = [&](f32x4_ (&xv)[XI], int st) {
+        const int nb = st * T;
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            const int id = it * PT + ptid;
+            const int plane = id / QPR, q = id % QPR; // row = 2*m_local + comp
+            const int n = nb + 4 * q;
+            const bool ok = (NG % PT == 0 || id < NG) && st < s_end && n < N;
+            const long long off = ((plane & 1) ? im_delta : 0ll) + 4ll * ((long long)(plane >> 1) * a.ant_stride + n);
+            gload_nt(xv[it], re_base + (ok ? off : 0ll));
+        }
+    };
+    auto store_x = [&](f32x4_ (&xv)[XI], int st, int buf) {
+        wait_loads<XI, XI>(xv); // the other register set's XI loads are newer and may stay in flight
+        const int nb = st * T;
+        u32x2 *xb = s_x + buf * RT * 32 * XS;
+#pragma unroll
+        for (int it = 0; it < XI; ++it) {
+            const int id = it * PT + ptid;
+            if (NG % PT != 0 && id >= NG) continue;
+            const int plane = id / QPR, q = id % QPR;
+            const bool ok = nb + 4 * q < N;
+            u32x2 *dst = xb + plane * XS + 4 * q;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { // {a = hi | mid << 16, b = lo | lo << 16}
+                const Split3 sp = split3(ok ? xv[it][u] : 0.f);
+                dst[u] = u32x2{GAT_PERM(sp.r, sp.v, 0x07060302u), GAT_PERM(sp.r2, sp.r2, 0x03020302u)};
+            }
+        }
+    };
+    // replica sign masks for entries e0, e0 + 1 of one slot (entry e <-> code sample nb + shifts[0] + e):
+    // the second entry follows from the exact FP64 floor difference (chips advance monotonically,
+    // at most one wrap: ratio < Lc / 32 or the channel is bad)
+    auto gen_rep2 = [&](const ChanInfoB &c, const unsigned *tab, unsigned *row, int nb, int e0, int e_end) {
+        const int x0 = nb + a.shifts[0] + e0;
+        const double p0 = __dadd_rn(__dmul_rn(c.ratio, (double)x0), c.tau); // src/algorithms.jl:179, unfused
+        const double p1 = __dadd_rn(__dmul_rn(c.ratio, (double)(x0 + 1)), c.tau);
+        const int ip0 = (int)__builtin_floor(p0);
+        const int ip1 = (int)__builtin_floor(p1);
+        const float qf = __builtin_floorf((float)ip0 * inv_lc);
+        int t0 = ip0 - (int)qf * Lc;
+        t0 += (t0 < 0) ? Lc : 0;
+        t0 -= (t0 >= Lc) ? Lc : 0;
+        int t1 = t0 + (ip1 - ip0);
+        t1 -= (t1 >= Lc) ? Lc : 0;
+        const unsigned n0 = (tab[t0 >> 5] >> (t0 & 31)) & 1u; // 1: chip -1
+        const unsigned n1 = (tab[t1 >> 5] >> (t1 & 31)) & 1u;
+        row[e0] = (n0 << 31) | (n0 << 15);
+        if (e0 + 1 < e_end) row[e0 + 1] = (n1 << 31) | (n1 << 15);
+    };
+    auto produce = [&](int st, int buf, bool first) { // everything of step st except the samples
+        const int nb = st * T;
+        u32x4 *wb = s_w + buf * wrows * WS;
+        unsigned *rb = s_rep + buf * nslots * RS;
+        const unsigned *rprev = s_rep + (buf ^ 1) * nslots * RS;
+        if (first) { // entries [0, span): ceil(span / 2) pairs per slot
+            const int gps = (span + 1) >> 1;
+            for (int id = ptid; id < nslots * gps; id += PT) {
+                const int slot = id / gps, g = id - slot * gps;
+                const ChanInfoB c = s_chan[slot];
+                if (!c.valid) continue;
+                gen_rep2(c, s_code + slot * a.code_bits_stride, rb + slot * RS, nb, 2 * g, span);
+            }
+        } else { // the overlap with the previous step is already known
+            const int pw = wave - 4;
+            for (int slot = pw; slot < nslots; slot += 8)
+                for (int e = lane; e < span; e += 64) rb[slot * RS + e] = rprev[slot * RS + e + T];
+        }
+        // one item = (slot, 2 consecutive samples): carrier fragments + the 2 new replica entries
+        for (int id = ptid; id < nslots * (T / 2); id += PT) {
+            const int slot = id / (T / 2), q = id % (T / 2);
+            const ChanInfoB c = s_chan[slot];
+            if (!c.valid) continue;
+            gen_rep2(c, s_code + slot * a.code_bits_stride, rb + slot * RS, nb, span + 2 * q, span + T);
+            const double th = __builtin_fma((double)(nb + 2 * q), c.step, c.phi);
+            float cr, ci;
+            sincos_cycles_b(th - __builtin_rint(th), cr, ci);
+            u32x4 *w_re = wb + (2 * slot) * WS + 2 * q;
+            u32x4 *w_im = w_re + WS;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const Split3 sc = split3(cr), ss = split3(-ci); // w_re = chip * cos, w_im = -chip * sin (conjugate)
+                const unsigned c_hh = GAT_PERM(sc.v, sc.v, 0x03020302u), c_mm = GAT_PERM(sc.r, sc.r, 0x03020302u),
+                               c_ll = GAT_PERM(sc.r2, sc.r2, 0x03020302u), c_hm = GAT_PERM(sc.r, sc.v, 0x07060302u);
+                const unsigned s_hh = GAT_PERM(ss.v, ss.v, 0x03020302u), s_mm = GAT_PERM(ss.r, ss.r, 0x03020302u),
+                               s_ll = GAT_PERM(ss.r2, ss.r2, 0x03020302u), s_hm = GAT_PERM(ss.r, ss.v, 0x07060302u);
+                w_re[u] = u32x4{c_hh, c_mm, c_ll, c_hm};
+                w_im[u] = u32x4{s_hh, s_mm, s_ll, s_hm};
+                const float tr = __builtin_fmaf(cr, c.wr, -(ci * c.wi));
+                ci = __builtin_fmaf(cr, c.wi, ci * c.wr);
+                cr = tr;
+            }
+        }
+    };
+
+    // ---- consumer state: this lane's column of W ------------------------------------------------
+    const int cw = wave & 3;
+    const int ctl = cw / WPT; // channel tile of this consumer wave within the workgroup
+    const int sub = cw % WPT; // sample sub-range of the step
+    const int r = lane & 31, h = lane >> 5;
+    const int kl = r >> 1, comp = r & 1;
+    const int kc = kl / L, l = kl - kc * L;
+    const int slot_c = ctl * CT + (kc < CT ? kc : 0);
+    const ChanInfoB my = s_chan[slot_c];
+    const bool live_col = kc < CT && my.valid;
+    const int col0 = sub * SW + h * NM; // first sample (step-relative) of this lane's stream
+    const int w_off = (live_col ? 2 * slot_c + comp : 2 * nslots) * WS + col0;
+    const int r_off = slot_c * RS + (a.shifts[l < L ? l : 0] - a.shifts[0]) + col0;
+    const int x_off = r * XS + col0;
+
+    f32x16 acc[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    // LDS byte addresses of this lane's streams (the low 32 bits of a flat LDS address are the LDS offset)
+    const unsigned lds_x = (unsigned)(uintptr_t)s_x, lds_w = (unsigned)(uintptr_t)s_w, lds_r = (unsigned)(uintptr_t)s_rep;
+    auto consume = [&](int buf) {
+        unsigned x_addr[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) x_addr[t] = lds_x + 8u * (unsigned)((buf * RT * 32 + t * 32) * XS + x_off);
+        const unsigned w_addr = lds_w + 16u * (unsigned)(buf * wrows * WS + w_off);
+        const unsigned r_addr = lds_r + 4u * (unsigned)(buf * nslots * RS + r_off);
+        mfma_step<NM, RT>(acc, w_addr, r_addr, x_addr, std::make_integer_sequence<int, NM>{});
+    };
+
+    // ---- pipeline ----------------------------------------------------------------------------------
+#ifdef GAT_MFMA_STAMPS // per wave: [0] work, [1] barrier wait, [2] producers: carriers + replica, [3] producers: split/store
+    unsigned long long t_work = 0, t_wait = 0, t_gen = 0, t_st = 0, t0_ = 0, t1_ = 0, t2_ = 0;
+#define GAT_STAMP(v) v = __builtin_amdgcn_s_memtime()
+#define GAT_ACC(dst, a_, b_) dst += (b_) - (a_)
+#else
+#define GAT_STAMP(v)
+#define GAT_ACC(dst, a_, b_)
+#endif
+    if (producer && s_begin < s_end) {
+        load_x(xvA, s_begin);
+        load_x(xvB, s_begin + 1);
+        produce(s_begin, 0, true);
+        store_x(xvA, s_begin, 0);
+        load_x(xvA, s_begin + 2);
+    }
+    __syncthreads();
+    for (int st = s_begin; st < s_end; st += 2) {
+        // even phase: consumers on buffer 0, producers fill buffer 1 with step st+1 (samples in xvB)
+        GAT_STAMP(t0_);
+        if (producer) {
+            if (st + 1 < s_end) {
+                produce(st + 1, 1, false);
+                GAT_STAMP(t2_);
+                store_x(xvB, st + 1, 1);
+                load_x(xvB, st + 3);
+                GAT_STAMP(t1_);
+                GAT_ACC(t_gen, t0_, t2_);
+                GAT_ACC(t_st, t2_, t1_);
+            }
+        } else {
+            consume(0);
+        }
+        GAT_STAMP(t1_);
+        __syncthreads();
+        GAT_STAMP(t2_);
+        GAT_ACC(t_work, t0_, t1_);
+        GAT_ACC(t_wait, t1_, t2_);
+        if (st + 1 >= s_end) break;
+        // odd phase
+        GAT_STAMP(t0_);
+        if (producer) {
+            if (st + 2 < s_end) {
+                produce(st + 2, 0, false);
+                GAT_STAMP(t2_);
+                store_x(xvA, st + 2, 0);
+                load_x(xvA, st + 4);
+                GAT_STAMP(t1_);
+                GAT_ACC(t_gen, t0_, t2_);
+                GAT_ACC(t_st, t2_, t1_);
+            }
+        } else {
+            consume(1);
+        }
+        GAT_STAMP(t1_);
+        __syncthreads();
+        GAT_STAMP(t2_);
+        GAT_ACC(t_work, t0_, t1_);
+        GAT_ACC(t_wait, t1_, t2_);
+    }
+#ifdef GAT_MFMA_STAMPS
+    if (lane == 0 && a.dbg) { // [workgroup][wave][4]
+        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * 12 + wave) * 4;
+        d[0] = t_work; d[1] = t_wait; d[2] = t_gen; d[3] = t_st;
+    }
+#endif
+
+    // ---- epilogue ------------------------------------------------------------------------------------
+    if constexpr (WPT > 1) { // sum the consumer waves that shared a channel tile (the x staging area is free now)
+        float *s_red = reinterpret_cast<float *>(s_x); // [4 waves][RT*16][64] floats = RT * 16 KB <= 2*RT*32*XS*8 B
+        if (!producer) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s_red[((cw * RT + t) * 16 + i) * 64 + lane] = acc[t][i];
+        }
+        __syncthreads();
+        if (!producer && sub == 0) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float s = 0.f;
+                    for (int qq = 0; qq < WPT; ++qq) s += s_red[(((ctl * WPT + qq) * RT + t) * 16 + i) * 64 + lane];
+                    acc[t][i] = s;
+                }
+        }
+    }
+    if (producer || sub != 0) return;
+    // C[row][col]: col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5).  Rows 2m / 2m+1 are
+    // registers i / i+1 of one lane; columns w_re / w_im are lanes c / c^1.
+    const int k = (cg * NCT + ctl) * CT + kc;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            const float v0 = acc[t][i], v1 = acc[t][i + 1]; // x_re * w_comp, x_im * w_comp
+            const float o1 = __shfl_xor(v1, 1, 64);         // partner column's x_im product
+            float val = comp ? (v0 + o1) : (v0 - o1); // comp 0: R_re = xr*wr - xi*wi ; comp 1: R_im = xr*wi + xi*wr
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * h;
+            const int m = (at * RT + t) * 16 + (row >> 1);
+            if (live_col) {
+                if (my.bad) val = __builtin_nanf("");
+                const int lo = a.tap_index[l];
+                const size_t bk = (size_t)b * a.K + k;
+                const size_t o = (bk * a.L + lo) * a.M + m;
+                float *dst = comp ? a.out_im : a.out_re;
+                if (a.flags & GAT_FLAG_ATOMIC) {
+                    atomicAdd(dst + o, val);
+                } else if (a.splits == 1) {
+                    dst[o] = val;
+                } else {
+                    const size_t elems = (size_t)a.L * a.M * 2;
+                    a.partial[(bk * a.splits + split) * elems + ((size_t)lo * a.M + m) * 2 + comp] = val;
+                }
+            }
+        }
+    }
+}
+
+int mfma_bf16_tile_samples(int rt, int nct) { return tile_samples(rt, nct); }
+int mfma_bf16_max_chain() { return kMaxChain; }
+
+size_t mfma_bf16_lds_bytes(int rt, int nct, int ct, int rep_stride, int code_bits_stride)
+{
+    static_assert(sizeof(ChanInfoB) * 20 <= kHeader, "channel table must fit the header");
+    const int T = tile_samples(rt, nct);
+    const int nslots = nct * ct;
+    return (size_t)kHeader + (size_t)2 * rt * 32 * (T + 1) * 8 + (size_t)2 * (2 * nslots + 1) * (T + 1) * 16 +
+           (size_t)((2 * nslots * rep_stride + 3) & ~3) * 4 + (size_t)nslots * code_bits_stride * 4;
+}
+
+hipError_t launch_mfma_bf16(const MfArgs &a, int rt, int nct, unsigned grid, unsigned lds_bytes, hipStream_t s)
+{
+    const dim3 g(grid), blk(kMbThreads);
+#define GAT_MB(RT_, NCT_) \
+    case RT_ * 8 + NCT_: hipLaunchKernelGGL((mfma_bf16_kernel<RT_, NCT_>), g, blk, lds_bytes, s, a); break;
+    switch (rt * 8 + nct) {
+        GAT_MB(1, 1) GAT_MB(1, 2) GAT_MB(1, 4) GAT_MB(2, 1) GAT_MB(2, 2) GAT_MB(2, 4) GAT_MB(4, 2) GAT_MB(4, 4)
+    default: return hipErrorInvalidValue;
+    }
+#undef GAT_MB
+    return hipGetLastError();
+}
+
+} // namespace gat

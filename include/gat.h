@@ -250,15 +250,22 @@ GAT_API int32_t gat_memset(gat_ctx *ctx, void *dst_dev, int32_t value, size_t by
 GAT_API int32_t gat_timer_start(gat_ctx *ctx);
 GAT_API int32_t gat_timer_stop(gat_ctx *ctx, float *elapsed_ms);
 
-/* Kernel selection: by default antenna-rich shapes (M % 16 == 0, enough (channel, tap) columns)
- * run on the matrix cores (gat_mfma.hip), everything else on the vector kernel.  enable = 0 forces
- * the vector kernel (A/B measurements, bit-comparisons); enable = 1 restores the default. */
+/* Kernel selection.  By default (GAT_MC_AUTO) antenna-rich shapes (M % 16 == 0, planar f32, enough
+ * (channel, tap) columns) run on the matrix cores with the split-bf16 kernel (gat_mfma_bf16.hip: both
+ * operands as hi+mid+lo bf16 terms, f32-equivalent accuracy), everything else on the vector kernel.
+ * GAT_MC_VECTOR forces the vector kernel (A/B measurements, bit-comparisons), GAT_MC_F32 the
+ * f32-MFMA kernel (gat_mfma.hip), GAT_MC_BF16_SPLIT the split-bf16 kernel only (shapes neither
+ * matrix kernel takes fall through to the vector kernel in every mode). */
+#define GAT_MC_VECTOR 0
+#define GAT_MC_AUTO 1
+#define GAT_MC_F32 2
+#define GAT_MC_BF16_SPLIT 3
 GAT_API int32_t gat_set_matrix_core(gat_ctx *ctx, int32_t enable);
 
 /* Launch geometry chosen for the last correlate call (diagnostics / DESIGN.md tables). */
 typedef struct gat_launch_info {
     int32_t workgroups, threads, splits, ant_tile, vec, lds_bytes, finalize_launched;
-    int32_t matrix_core; /* 1: the MFMA kernel ran (antenna-rich shapes), 0: the vector kernel */
+    int32_t matrix_core; /* 0: the vector kernel ran, 1: the f32-MFMA kernel, 2: the split-bf16 MFMA kernel */
 } gat_launch_info;
 GAT_API int32_t gat_last_launch_info(const gat_ctx *ctx, gat_launch_info *out);
 

@@ -1,6 +1,7 @@
-"""GPU tests of the matrix-core kernel (gat_mfma.hip; antenna-rich shapes, M % 16 == 0): parity with
-the FP64 oracle, agreement with the vector kernel on the same inputs, and that the planner picks it
-exactly for the shapes it is meant for."""
+"""GPU tests of the matrix-core kernels (antenna-rich shapes, M % 16 == 0) -- the split-bf16 kernel
+(gat_mfma_bf16.hip, the default) and the f32-MFMA kernel (gat_mfma.hip): parity with the FP64 oracle,
+agreement with the vector kernel on the same inputs, and that the planner picks them exactly for the
+shapes they are meant for."""
 import zlib
 
 import numpy as np
@@ -18,7 +19,7 @@ def g():
     return g
 
 
-def run(g, case, matrix_core=True, flags=0):
+def run(g, case, matrix_core=1, flags=0):
     import torch
     sysobj = g.GNSSDICT[case["system"]](use_gpu=True)
     ctx = g.get_context()
@@ -32,7 +33,7 @@ def run(g, case, matrix_core=True, flags=0):
         op(torch.from_numpy(case["re"]).to(dev), torch.from_numpy(case["im"]).to(dev))
         return op.result(), ctx.last_launch_info()
     finally:
-        ctx.set_matrix_core(True)
+        ctx.set_matrix_core(1)
 
 
 GRID = [
@@ -43,26 +44,35 @@ GRID = [
     ("GPSL1", 5000, 16, 3, 6, 1),     # CT + 1 channels: second tile nearly empty
     ("GPSL1", 3004, 32, 3, 21, 1),    # 5 channel tiles -> two channel groups, ragged tile
     ("GPSL5", 8192, 16, 5, 7, 2),     # L = 5 -> CT = 3
-    ("GPSL1", 776, 16, 1, 16, 2),     # L = 1 -> CT = 16
+    ("GPSL1", 776, 16, 1, 16, 2, 1),  # L = 1 -> CT = 16: 16 carrier rows per tile do not fit the split-bf16 LDS tile -> f32 MFMA
     ("GPSL1", 260, 16, 16, 2, 1),     # L = 16 -> CT = 1 (one channel per tile)
     ("GPSL1", 100, 16, 3, 4, 4),      # shorter than one tile
     ("GPSL1", 200000, 16, 3, 4, 1),   # many steps, split over workgroups + finalize
+    ("GPSL1", 9000, 32, 3, 7, 2),     # 2 row tiles per workgroup, 2 channel tiles
+    ("GPSL1", 9000, 64, 3, 3, 1),     # 4 row tiles, one partial channel tile
+    ("GPSL1", 70004, 48, 3, 10, 1),   # 3 antenna tiles of one row tile each, ragged last step
+    ("GPSL5", 30000, 64, 5, 12, 1),   # L5: 12 channels x 5 taps = 4 channel tiles of CT = 3
 ]
 
 
 @pytest.mark.parametrize("cfg", GRID, ids=lambda c: f"{c[0]}-N{c[1]}-M{c[2]}-L{c[3]}-K{c[4]}-B{c[5]}")
 def test_mfma_parity(g, cfg):
-    system, N, M, L, K, B = cfg
+    system, N, M, L, K, B = cfg[:6]
+    auto_kind = cfg[6] if len(cfg) > 6 else 2
     fs = {"GPSL1": 8e6, "GPSL5": 25e6}[system] if L <= 5 else 2.5e6
     case = make_case(zlib.crc32(repr(cfg).encode()), system=system, N=N, M=M, L=L, K=K, B=B, fs=fs, if_hz=1.1e6)
     ref = oracle_result(case)
-    got, info = run(g, case)
-    assert info["matrix_core"] == 1, info
-    check_close(got, ref, what=f"mfma {cfg}")
-    vec, info_v = run(g, case, matrix_core=False)
+    got, info = run(g, case)  # auto: the split-bf16 kernel
+    assert info["matrix_core"] == auto_kind, info
+    check_close(got, ref, what=f"auto (kind {auto_kind}) mfma {cfg}")
+    f32, info_f = run(g, case, matrix_core=g.GAT_MC_F32)
+    assert info_f["matrix_core"] == 1, info_f
+    check_close(f32, ref, what=f"f32 mfma {cfg}")
+    vec, info_v = run(g, case, matrix_core=g.GAT_MC_VECTOR)
     assert info_v["matrix_core"] == 0
     check_close(vec, ref, what=f"vector {cfg}")
-    # the two kernels agree far inside the tolerance (same FP32 products, different sum order)
+    # the kernels agree far inside the tolerance (f32 products / 8 of the 9 split products, different sum order)
+    assert np.abs(f32 - vec).max() <= 3e-6 * np.abs(ref).max()
     assert np.abs(got - vec).max() <= 3e-6 * np.abs(ref).max()
 
 
@@ -71,13 +81,14 @@ def test_mfma_unsorted_taps_atomic_and_determinism(g):
     case["shifts"] = np.array([4, -4, 0, 9, -120], dtype=np.int32)
     case["L"] = 5
     ref = oracle_result(case)
-    got, info = run(g, case)
-    assert info["matrix_core"] == 1 and info["splits"] > 1
-    check_close(got, ref, what="unsorted taps")
-    got2, _ = run(g, case)
-    assert np.array_equal(got.view(np.float32), got2.view(np.float32))
-    gota, _ = run(g, case, flags=g.GAT_FLAG_ATOMIC)
-    check_close(gota, ref, what="atomic")
+    for mode, kind in ((g.GAT_MC_AUTO, 2), (g.GAT_MC_F32, 1)):
+        got, info = run(g, case, matrix_core=mode)
+        assert info["matrix_core"] == kind and info["splits"] > 1, info
+        check_close(got, ref, what="unsorted taps")
+        got2, _ = run(g, case, matrix_core=mode)
+        assert np.array_equal(got.view(np.float32), got2.view(np.float32))
+        gota, _ = run(g, case, matrix_core=mode, flags=g.GAT_FLAG_ATOMIC)
+        check_close(gota, ref, what="atomic")
 
 
 def test_planner_keeps_vector_kernel_for_other_shapes(g):
@@ -101,7 +112,28 @@ def test_mfma_bad_prn_poisons_output(g):
     bad["prn"][0, 2] = 77  # bypass set_params' host check: write the device copy directly
     op.params_dev = ctx.params_to_device(bad)
     op._prepared = None
-    op(re, im)
-    out = op.result()
-    assert ctx.last_launch_info()["matrix_core"] == 1
-    assert np.isnan(out[0, 2].view(np.float32)).all() and np.isfinite(out[0, [0, 1, 3]].view(np.float32)).all()
+    try:
+        for mode, kind in ((g.GAT_MC_AUTO, 2), (g.GAT_MC_F32, 1)):
+            ctx.set_matrix_core(mode)
+            op(re, im)
+            out = op.result()
+            assert ctx.last_launch_info()["matrix_core"] == kind
+            assert np.isnan(out[0, 2].view(np.float32)).all() and np.isfinite(out[0, [0, 1, 3]].view(np.float32)).all()
+    finally:
+        ctx.set_matrix_core(1)
+
+
+def test_split_bf16_extreme_dynamic_range(g):
+    """hi + mid + lo carries all 24 mantissa bits whatever the scale: antennas with gains from 1e-12 to
+    1e+12 next to each other (the matrix instruction never mixes rows) keep the f32-level agreement."""
+    case = make_case(5, N=12000, M=16, L=3, K=5, B=1, fs=6e6)
+    gains = (10.0 ** np.linspace(-12, 12, 16)).astype(np.float32)
+    case["re"] = (case["re"].reshape(16, -1) * gains[:, None]).reshape(case["re"].shape)
+    case["im"] = (case["im"].reshape(16, -1) * gains[:, None]).reshape(case["im"].shape)
+    ref = oracle_result(case)
+    got, info = run(g, case)
+    assert info["matrix_core"] == 2
+    vec, _ = run(g, case, matrix_core=g.GAT_MC_VECTOR)
+    scale = np.abs(ref).max(axis=(2,), keepdims=True)  # per (block, channel, antenna): max over taps
+    assert (np.abs(got - ref) / scale).max() <= 1e-5
+    assert (np.abs(vec - ref) / scale).max() <= 1e-5
