@@ -133,14 +133,16 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
                               span <= kMfmaMaxSpan && 2 * std::min(K, CT) * L >= 12 /* >= 3/8 of the columns */;
         const int nct_total = shape_ok ? (K + CT - 1) / CT : 1;
         int nct = nct_total >= 4 ? 4 : (nct_total >= 2 ? 2 : 1);
+        while (nct > 1 && nct * CT > 20) nct >>= 1; // both kernels keep at most 20 channel slots per workgroup
         // kernel choice: 3 / 1 (auto) -> split-bf16 when its tile fits in LDS, 2 -> f32 MFMA
         int kind = 0, rt = 1, rep_stride_m = 0;
         if (shape_ok && c->mc_mode != 2 && c->d_code_bits && N % 4 == 0) {
-            rt = (M / 16) % 4 == 0 ? 4 : ((M / 16) % 2 == 0 ? 2 : 1);
-            if (rt == 4 && nct == 1) rt = 2; // <4,1> does not fit the 168-VGPR budget of a 12-wave workgroup
+            const int rt_max = (M / 16) % 4 == 0 ? 4 : ((M / 16) % 2 == 0 ? 2 : 1);
             for (int n = nct; n >= 1 && !kind; n >>= 1) {
+                rt = (rt_max == 4 && n == 1) ? 2 : rt_max; // <4,1> does not fit the 168-VGPR budget of a 12-wave workgroup
                 const int T = mfma_bf16_tile_samples(rt, n);
                 const int rs = ((T + (int)span + 31) / 32) * 32 + 1; // odd: channel rows land on different banks
+                if (n * CT * T / 2 > 512 || n * CT > 20) continue; // one (slot, sample pair) item per producer thread
                 if (mfma_bf16_lds_bytes(rt, n, CT, rs, c->code_bits_stride) <= 160 * 1024) {
                     kind = 2;
                     nct = n;

@@ -43,6 +43,7 @@ namespace {
 
 constexpr int kMbThreads = 768; // 4 consumer + 8 producer waves
 constexpr int kMaxChain = 8192;  // samples per accumulation chain (f32 rounding of the running sum)
+constexpr int kReanchor = 16;   // steps between FP64 re-anchors of the producers' carried phasor / code index
 constexpr int kHeader = 1536; // ChanInfoB[<= 20] (64 B each) + slack, 16-byte aligned
 
 __device__ __forceinline__ void sincos_cycles_b(double theta, float &c, float &s)
@@ -84,19 +85,24 @@ __device__ __forceinline__ Split3 split3(float v)
 // The sample prefetch is written as inline assembly with its own s_waitcnt: hipcc's counter
 // insertion over-waits across the two-phase loop (it asked for the NEWEST loads too, i.e. no
 // prefetch distance).  The compiler does not see these loads; every use of the destination goes
-// through wait_loads(), which ties the registers to the wait.
+// through wait_loads(), which ties the registers to the wait -- in straight-line code only: a branch
+// around the wait makes the register allocator COPY the registers before it, i.e. before the data is there.
 __device__ __forceinline__ void gload_nt(f32x4_ &dst, const void *p)
 {
     asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
 }
-template <int PENDING_NEWER, int XI>
+template <int XI> // XI loads per register set; the other set's XI loads are newer and may stay in flight
 __device__ __forceinline__ void wait_loads(f32x4_ (&xv)[XI])
 {
-    static_assert(XI == 1 || XI == 2, "prefetch group size");
+    static_assert(XI >= 1 && XI <= 4, "prefetch group size");
     if constexpr (XI == 1)
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xv[0]) : "n"(PENDING_NEWER) : "memory");
+        asm volatile("s_waitcnt vmcnt(1)" : "+v"(xv[0]) : : "memory");
+    else if constexpr (XI == 2)
+        asm volatile("s_waitcnt vmcnt(2)" : "+v"(xv[0]), "+v"(xv[1]) : : "memory");
+    else if constexpr (XI == 3)
+        asm volatile("s_waitcnt vmcnt(3)" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]) : : "memory");
     else
-        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xv[0]), "+v"(xv[1]) : "n"(PENDING_NEWER) : "memory");
+        asm volatile("s_waitcnt vmcnt(4)" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]) : : "memory");
 }
 // __builtin_amdgcn_perm(a, b, sel): result byte i = byte sel[i] of {b: 0-3, a: 4-7}
 #define GAT_PERM(a, b, sel) __builtin_amdgcn_perm((a), (b), (sel))
@@ -185,9 +191,10 @@ __device__ __forceinline__ void mfma_step(f32x16 (&acc)[RT], unsigned w_addr, un
 
 struct ChanInfoB { // per channel slot of the workgroup, in LDS
     double ratio, tau, step, phi;
-    float wr, wi; // e^{j 2 pi step}: one-sample carrier rotation
-    int prn, valid, bad, pad;
-    int pad2[2];
+    float wr, wi;   // e^{j 2 pi step}: one-sample carrier rotation
+    float wTr, wTi; // e^{j 2 pi T step}: one-step carrier rotation
+    int prn, valid, bad;
+    int inc_ok;     // fewer than Lc chips per step: the code index can be advanced by floor differences
 };
 static_assert(sizeof(ChanInfoB) == 64, "ChanInfoB layout");
 
@@ -216,7 +223,6 @@ __global__ void __launch_bounds__(kMbThreads) mfma_bf16_kernel(const MfArgs a)
     constexpr int QPR = T / 4;     // 4-sample groups per plane row
     constexpr int PT = kMbThreads - kThreads; // producer threads (512)
     constexpr int NG = RT * 32 * QPR;         // 4-sample groups per step
-    constexpr int XI = (NG + PT - 1) / PT;    // groups per producer thread and step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int CT = a.CT, L = a.L;
     const int nslots = NCT * CT;
@@ -263,6 +269,9 @@ __global__ void __launch_bounds__(kMbThreads) mfma_bf16_kernel(const MfArgs a)
             ci.prn = (P.prn < 0 || P.prn >= a.num_prns) ? 0 : P.prn;
             if (ci.bad) { ci.ratio = 0.0; ci.tau = 0.0; ci.step = 0.0; ci.phi = 0.0; }
             sincos_cycles_b(ci.step - __builtin_rint(ci.step), ci.wr, ci.wi);
+            const double st_T = ci.step * (double)T;
+            sincos_cycles_b(st_T - __builtin_rint(st_T), ci.wTr, ci.wTi);
+            ci.inc_ok = ci.ratio * (double)(T + 2) < (double)Lc;
         }
         s_chan[tid] = ci;
     }
@@ -295,29 +304,43 @@ __global__ void __launch_bounds__(kMbThreads) mfma_bf16_kernel(const MfArgs a)
     // pointers would be compiled into a per-lane LOAD of the pointer and a wait for it)
     const long long im_delta = reinterpret_cast<const char *>(a.im) - reinterpret_cast<const char *>(a.re);
     const char *re_base = reinterpret_cast<const char *>(a.re + base);
-    f32x4_ xvA[XI], xvB[XI];
-    auto load_x = [&](f32x4_ (&xv)[XI], int st) {
+    // Groups per thread are weighted by role so that all producer waves finish together: the waves that
+    // own a carrier / replica item (the first item_waves ones) take few sample groups, the others up to 4.
+    const int n_items = nslots * (T / 2);
+    const int item_waves = (n_items + 63) >> 6;
+    const int niw = item_waves * 64, tn = PT - niw;            // item / non-item producer threads
+    const int xi_other = tn > 0 ? min(4, (NG + tn - 1) / tn) : 0;
+    const int rem = NG - xi_other * tn;                          // groups left for the item waves
+    const int xi_item = rem > 0 ? (rem + niw - 1) / niw : 0;     // <= 4 (planner)
+    const bool item_wave = (wave - 4) < item_waves;
+    const int my_xi = __builtin_amdgcn_readfirstlane(item_wave ? xi_item : xi_other); // wave-uniform, in an SGPR
+    const int g_first = item_wave ? xi_other * tn + ptid : ptid - niw;
+    const int g_stride = item_wave ? niw : tn;
+    auto load_x = [&](auto &xv, int st) {
+        constexpr int XI = sizeof(xv) / sizeof(xv[0]);
         const int nb = st * T;
 #pragma unroll
         for (int it = 0; it < XI; ++it) {
-            const int id = it * PT + ptid;
+            const int id = g_first + it * g_stride;
             const int plane = id / QPR, q = id % QPR; // row = 2*m_local + comp
             const int n = nb + 4 * q;
-            const bool ok = (NG % PT == 0 || id < NG) && st < s_end && n < N;
+            const bool ok = id < NG && st < s_end && n < N;
             const long long off = ((plane & 1) ? im_delta : 0ll) + 4ll * ((long long)(plane >> 1) * a.ant_stride + n);
             gload_nt(xv[it], re_base + (ok ? off : 0ll));
         }
     };
-    auto store_x = [&](f32x4_ (&xv)[XI], int st, int buf) {
-        wait_loads<XI, XI>(xv); // the other register set's XI loads are newer and may stay in flight
+    auto store_x = [&](auto &xv, int st, int buf) {
+        constexpr int XI = sizeof(xv) / sizeof(xv[0]);
+        wait_loads<XI>(xv);
         const int nb = st * T;
         u32x2 *xb = s_x + buf * RT * 32 * XS;
+        const bool full = nb + T <= N; // wave-uniform: only a block's last step can be ragged
 #pragma unroll
         for (int it = 0; it < XI; ++it) {
-            const int id = it * PT + ptid;
-            if (NG % PT != 0 && id >= NG) continue;
+            const int id = g_first + it * g_stride;
+            if (id >= NG) continue;
             const int plane = id / QPR, q = id % QPR;
-            const bool ok = nb + 4 * q < N;
+            const bool ok = full || nb + 4 * q < N;
             u32x2 *dst = xb + plane * XS + 4 * q;
 #pragma unroll
             for (int u = 0; u < 4; ++u) { // {a = hi | mid << 16, b = lo | lo << 16}
@@ -326,26 +349,46 @@ __global__ void __launch_bounds__(kMbThreads) mfma_bf16_kernel(const MfArgs a)
             }
         }
     };
-    // replica sign masks for entries e0, e0 + 1 of one slot (entry e <-> code sample nb + shifts[0] + e):
-    // the second entry follows from the exact FP64 floor difference (chips advance monotonically,
-    // at most one wrap: ratio < Lc / 32 or the channel is bad)
-    auto gen_rep2 = [&](const ChanInfoB &c, const unsigned *tab, unsigned *row, int nb, int e0, int e_end) {
+    // replica sign masks for entries e0, e0 + 1 of one slot (entry e <-> code sample nb + shifts[0] + e).
+    // Every entry is the reference's FP64 expression, unfused (src/algorithms.jl:179).  Table index: the
+    // full floored modulo only when `anchor`; otherwise it follows from the exact floor differences
+    // (chips advance monotonically): ip - ip_prev chips on from the index of T samples ago
+    // (c.inc_ok: fewer than Lc chips per step), and the pair's second entry at most one wrap on.
+    auto chip_mask = [&](const unsigned *tab, int t) {
+        return (unsigned)__builtin_amdgcn_sbfe(tab[t >> 5], t & 31, 1) & 0x80008000u; // bit set: chip -1
+    };
+    auto gen_rep2 = [&](const ChanInfoB &c, const unsigned *tab, unsigned *row, int nb, int e0, int e_end, bool anchor,
+                        int &ip_state, int &t_state) {
         const int x0 = nb + a.shifts[0] + e0;
-        const double p0 = __dadd_rn(__dmul_rn(c.ratio, (double)x0), c.tau); // src/algorithms.jl:179, unfused
+        const double p0 = __dadd_rn(__dmul_rn(c.ratio, (double)x0), c.tau);
         const double p1 = __dadd_rn(__dmul_rn(c.ratio, (double)(x0 + 1)), c.tau);
         const int ip0 = (int)__builtin_floor(p0);
         const int ip1 = (int)__builtin_floor(p1);
-        const float qf = __builtin_floorf((float)ip0 * inv_lc);
-        int t0 = ip0 - (int)qf * Lc;
-        t0 += (t0 < 0) ? Lc : 0;
-        t0 -= (t0 >= Lc) ? Lc : 0;
+        int t0;
+        if (anchor) {
+            const float qf = __builtin_floorf((float)ip0 * inv_lc);
+            t0 = ip0 - (int)qf * Lc;
+            t0 += (t0 < 0) ? Lc : 0;
+            t0 -= (t0 >= Lc) ? Lc : 0;
+        } else {
+            t0 = t_state + (ip0 - ip_state);
+            t0 -= (t0 >= Lc) ? Lc : 0;
+        }
+        ip_state = ip0;
+        t_state = t0;
         int t1 = t0 + (ip1 - ip0);
         t1 -= (t1 >= Lc) ? Lc : 0;
-        const unsigned n0 = (tab[t0 >> 5] >> (t0 & 31)) & 1u; // 1: chip -1
-        const unsigned n1 = (tab[t1 >> 5] >> (t1 & 31)) & 1u;
-        row[e0] = (n0 << 31) | (n0 << 15);
-        if (e0 + 1 < e_end) row[e0 + 1] = (n1 << 31) | (n1 << 15);
+        row[e0] = chip_mask(tab, t0);
+        if (e0 + 1 < e_end) row[e0 + 1] = chip_mask(tab, t1);
     };
+    // one item = (slot, 2 consecutive samples): carrier fragments + the 2 new replica entries.  A producer
+    // thread owns the same item in every step (at most one: the planner keeps nslots * T / 2 <= 512) and
+    // carries its phasor and code index from step to step: one complex rotation by e^{j 2 pi T step}
+    // instead of an FP64 range reduction + sincos; re-anchored in FP64 every kReanchor steps.
+    float car_r = 0.f, car_i = 0.f;
+    int rep_ip = 0, rep_t = 0;
+    const int item_slot = ptid / (T / 2), item_q = ptid % (T / 2);
+    const bool have_item = producer && item_slot < nslots;
     auto produce = [&](int st, int buf, bool first) { // everything of step st except the samples
         const int nb = st * T;
         u32x4 *wb = s_w + buf * wrows * WS;
@@ -357,33 +400,42 @@ __global__ void __launch_bounds__(kMbThreads) mfma_bf16_kernel(const MfArgs a)
                 const int slot = id / gps, g = id - slot * gps;
                 const ChanInfoB c = s_chan[slot];
                 if (!c.valid) continue;
-                gen_rep2(c, s_code + slot * a.code_bits_stride, rb + slot * RS, nb, 2 * g, span);
+                int ip_unused, t_unused;
+                gen_rep2(c, s_code + slot * a.code_bits_stride, rb + slot * RS, nb, 2 * g, span, true, ip_unused, t_unused);
             }
         } else { // the overlap with the previous step is already known
             const int pw = wave - 4;
             for (int slot = pw; slot < nslots; slot += 8)
                 for (int e = lane; e < span; e += 64) rb[slot * RS + e] = rprev[slot * RS + e + T];
         }
-        // one item = (slot, 2 consecutive samples): carrier fragments + the 2 new replica entries
-        for (int id = ptid; id < nslots * (T / 2); id += PT) {
-            const int slot = id / (T / 2), q = id % (T / 2);
-            const ChanInfoB c = s_chan[slot];
-            if (!c.valid) continue;
-            gen_rep2(c, s_code + slot * a.code_bits_stride, rb + slot * RS, nb, span + 2 * q, span + T);
-            const double th = __builtin_fma((double)(nb + 2 * q), c.step, c.phi);
-            float cr, ci;
+        if (!have_item) return;
+        const ChanInfoB c = s_chan[item_slot];
+        if (!c.valid) return;
+        const bool anchor = first || ((st - s_begin) % kReanchor) == 0; // wave-uniform
+        gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, nb, span + 2 * item_q, span + T,
+                 anchor || !c.inc_ok, rep_ip, rep_t);
+        float cr, ci;
+        if (anchor) {
+            const double th = __builtin_fma((double)(nb + 2 * item_q), c.step, c.phi);
             sincos_cycles_b(th - __builtin_rint(th), cr, ci);
-            u32x4 *w_re = wb + (2 * slot) * WS + 2 * q;
-            u32x4 *w_im = w_re + WS;
+        } else { // T samples on from the previous step's first sample
+            cr = __builtin_fmaf(car_r, c.wTr, -(car_i * c.wTi));
+            ci = __builtin_fmaf(car_r, c.wTi, car_i * c.wTr);
+        }
+        car_r = cr;
+        car_i = ci;
+        u32x4 *w_re = wb + (2 * item_slot) * WS + 2 * item_q;
+        u32x4 *w_im = w_re + WS;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const Split3 sc = split3(cr), ss = split3(-ci); // w_re = chip * cos, w_im = -chip * sin (conjugate)
-                const unsigned c_hh = GAT_PERM(sc.v, sc.v, 0x03020302u), c_mm = GAT_PERM(sc.r, sc.r, 0x03020302u),
-                               c_ll = GAT_PERM(sc.r2, sc.r2, 0x03020302u), c_hm = GAT_PERM(sc.r, sc.v, 0x07060302u);
-                const unsigned s_hh = GAT_PERM(ss.v, ss.v, 0x03020302u), s_mm = GAT_PERM(ss.r, ss.r, 0x03020302u),
-                               s_ll = GAT_PERM(ss.r2, ss.r2, 0x03020302u), s_hm = GAT_PERM(ss.r, ss.v, 0x07060302u);
-                w_re[u] = u32x4{c_hh, c_mm, c_ll, c_hm};
-                w_im[u] = u32x4{s_hh, s_mm, s_ll, s_hm};
+        for (int u = 0; u < 2; ++u) {
+            const Split3 sc = split3(cr), ss = split3(-ci); // w_re = chip * cos, w_im = -chip * sin (conjugate)
+            const unsigned c_hh = GAT_PERM(sc.v, sc.v, 0x03020302u), c_mm = GAT_PERM(sc.r, sc.r, 0x03020302u),
+                           c_ll = GAT_PERM(sc.r2, sc.r2, 0x03020302u), c_hm = GAT_PERM(sc.r, sc.v, 0x07060302u);
+            const unsigned s_hh = GAT_PERM(ss.v, ss.v, 0x03020302u), s_mm = GAT_PERM(ss.r, ss.r, 0x03020302u),
+                           s_ll = GAT_PERM(ss.r2, ss.r2, 0x03020302u), s_hm = GAT_PERM(ss.r, ss.v, 0x07060302u);
+            w_re[u] = u32x4{c_hh, c_mm, c_ll, c_hm};
+            w_im[u] = u32x4{s_hh, s_mm, s_ll, s_hm};
+            if (u == 0) {
                 const float tr = __builtin_fmaf(cr, c.wr, -(ci * c.wi));
                 ci = __builtin_fmaf(cr, c.wi, ci * c.wr);
                 cr = tr;
@@ -405,6 +457,9 @@ __global__ void __launch_bounds__(kMbThreads) mfma_bf16_kernel(const MfArgs a)
     const int w_off = (live_col ? 2 * slot_c + comp : 2 * nslots) * WS + col0;
     const int r_off = slot_c * RS + (a.shifts[l < L ? l : 0] - a.shifts[0]) + col0;
     const int x_off = r * XS + col0;
+
+    // the consumers' few vector instructions per slice must not queue behind the producers' streams
+    if (!producer) __builtin_amdgcn_s_setprio(3);
 
     f32x16 acc[RT];
 #pragma unroll
@@ -432,56 +487,91 @@ __global__ void __launch_bounds__(kMbThreads) mfma_bf16_kernel(const MfArgs a)
 #define GAT_STAMP(v)
 #define GAT_ACC(dst, a_, b_)
 #endif
-    if (producer && s_begin < s_end) {
-        load_x(xvA, s_begin);
-        load_x(xvB, s_begin + 1);
-        produce(s_begin, 0, true);
-        store_x(xvA, s_begin, 0);
-        load_x(xvA, s_begin + 2);
-    }
-    __syncthreads();
-    for (int st = s_begin; st < s_end; st += 2) {
-        // even phase: consumers on buffer 0, producers fill buffer 1 with step st+1 (samples in xvB)
-        GAT_STAMP(t0_);
-        if (producer) {
+    // one instance of the producer loop per prefetch-group size: the counted waits need straight-line code
+    auto producer_loop = [&](auto xi_tag) {
+        constexpr int XI = decltype(xi_tag)::value;
+        f32x4_ xvA[XI ? XI : 1], xvB[XI ? XI : 1];
+        if (s_begin < s_end) {
+            if constexpr (XI > 0) {
+                load_x(xvA, s_begin);
+                load_x(xvB, s_begin + 1);
+            }
+            produce(s_begin, 0, true);
+            if constexpr (XI > 0) {
+                store_x(xvA, s_begin, 0);
+                load_x(xvA, s_begin + 2);
+            }
+        }
+        __syncthreads();
+        for (int st = s_begin; st < s_end; st += 2) {
+            // even phase: consumers on buffer 0, producers fill buffer 1 with step st+1 (samples in xvB)
+            GAT_STAMP(t0_);
             if (st + 1 < s_end) {
                 produce(st + 1, 1, false);
                 GAT_STAMP(t2_);
-                store_x(xvB, st + 1, 1);
-                load_x(xvB, st + 3);
+                if constexpr (XI > 0) {
+                    store_x(xvB, st + 1, 1);
+                    load_x(xvB, st + 3);
+                }
                 GAT_STAMP(t1_);
                 GAT_ACC(t_gen, t0_, t2_);
                 GAT_ACC(t_st, t2_, t1_);
             }
-        } else {
-            consume(0);
-        }
-        GAT_STAMP(t1_);
-        __syncthreads();
-        GAT_STAMP(t2_);
-        GAT_ACC(t_work, t0_, t1_);
-        GAT_ACC(t_wait, t1_, t2_);
-        if (st + 1 >= s_end) break;
-        // odd phase
-        GAT_STAMP(t0_);
-        if (producer) {
+            GAT_STAMP(t1_);
+            __syncthreads();
+            GAT_STAMP(t2_);
+            GAT_ACC(t_work, t0_, t1_);
+            GAT_ACC(t_wait, t1_, t2_);
+            if (st + 1 >= s_end) break;
+            // odd phase
+            GAT_STAMP(t0_);
             if (st + 2 < s_end) {
                 produce(st + 2, 0, false);
                 GAT_STAMP(t2_);
-                store_x(xvA, st + 2, 0);
-                load_x(xvA, st + 4);
+                if constexpr (XI > 0) {
+                    store_x(xvA, st + 2, 0);
+                    load_x(xvA, st + 4);
+                }
                 GAT_STAMP(t1_);
                 GAT_ACC(t_gen, t0_, t2_);
                 GAT_ACC(t_st, t2_, t1_);
             }
-        } else {
-            consume(1);
+            GAT_STAMP(t1_);
+            __syncthreads();
+            GAT_STAMP(t2_);
+            GAT_ACC(t_work, t0_, t1_);
+            GAT_ACC(t_wait, t1_, t2_);
         }
-        GAT_STAMP(t1_);
+    };
+    // Role-specific loops (same barrier count): a shared loop would keep the producers' prefetch
+    // registers alive in the consumers and the accumulators alive in the producers.
+    if (__builtin_amdgcn_readfirstlane(wave) >= 4) {
+        switch (my_xi) {
+        case 0: producer_loop(std::integral_constant<int, 0>{}); break;
+        case 1: producer_loop(std::integral_constant<int, 1>{}); break;
+        case 2: producer_loop(std::integral_constant<int, 2>{}); break;
+        case 3: producer_loop(std::integral_constant<int, 3>{}); break;
+        default: producer_loop(std::integral_constant<int, 4>{}); break;
+        }
+    } else {
         __syncthreads();
-        GAT_STAMP(t2_);
-        GAT_ACC(t_work, t0_, t1_);
-        GAT_ACC(t_wait, t1_, t2_);
+        for (int st = s_begin; st < s_end; st += 2) {
+            GAT_STAMP(t0_);
+            consume(0);
+            GAT_STAMP(t1_);
+            __syncthreads();
+            GAT_STAMP(t2_);
+            GAT_ACC(t_work, t0_, t1_);
+            GAT_ACC(t_wait, t1_, t2_);
+            if (st + 1 >= s_end) break;
+            GAT_STAMP(t0_);
+            consume(1);
+            GAT_STAMP(t1_);
+            __syncthreads();
+            GAT_STAMP(t2_);
+            GAT_ACC(t_work, t0_, t1_);
+            GAT_ACC(t_wait, t1_, t2_);
+        }
     }
 #ifdef GAT_MFMA_STAMPS
     if (lane == 0 && a.dbg) { // [workgroup][wave][4]
@@ -493,22 +583,22 @@ __global__ void __launch_bounds__(kMbThreads) mfma_bf16_kernel(const MfArgs a)
     // ---- epilogue ------------------------------------------------------------------------------------
     if constexpr (WPT > 1) { // sum the consumer waves that shared a channel tile (the x staging area is free now)
         float *s_red = reinterpret_cast<float *>(s_x); // [4 waves][RT*16][64] floats = RT * 16 KB <= 2*RT*32*XS*8 B
-        if (!producer) {
+        if (!producer && sub != 0) {
 #pragma unroll
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) s_red[((cw * RT + t) * 16 + i) * 64 + lane] = acc[t][i];
         }
         __syncthreads();
-        if (!producer && sub == 0) {
+        if (!producer && sub == 0) { // fixed order: own samples first, then sub-ranges 1 .. WPT-1 (deterministic)
 #pragma unroll
-            for (int t = 0; t < RT; ++t)
+            for (int t = 0; t < RT; ++t) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float s = 0.f;
-                    for (int qq = 0; qq < WPT; ++qq) s += s_red[(((ctl * WPT + qq) * RT + t) * 16 + i) * 64 + lane];
-                    acc[t][i] = s;
-                }
+                for (int qq = 1; qq < WPT; ++qq)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[t][i] += s_red[(((cw + qq) * RT + t) * 16 + i) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0); // one row tile at a time: 16 loads in flight, not 64 * WPT
+            }
         }
     }
     if (producer || sub != 0) return;

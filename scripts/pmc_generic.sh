@@ -14,7 +14,7 @@ out = sys.argv[1]
 acc = {}
 for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "dc_kernel" in r["Kernel_Name"] or "mfma_kernel" in r["Kernel_Name"]:
+        if "dc_kernel" in r["Kernel_Name"] or "mfma_" in r["Kernel_Name"]:
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
             acc.setdefault("_dur_ns", []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 for k in sorted(acc):
