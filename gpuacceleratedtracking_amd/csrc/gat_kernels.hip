@@ -25,6 +25,8 @@
 
 namespace gat {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // ------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------
@@ -141,6 +143,11 @@ __device__ __forceinline__ float wave_sum(float v)
 // interleaved int16 pairs, interleaved int8 pairs.  VEC = 4: one 16-byte non-temporal load per
 // lane, plane and group (4 / 2 / 4 / 8 complex samples); VEC = 1: scalar loads (unaligned input).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+#ifdef GAT_NO_NT // experiment: plain loads instead of non-temporal ones
+#define GAT_NT_LOAD(p) (*(p))
+#else
+#define GAT_NT_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 
 template <int FMT>
 struct SampleIO {
@@ -153,10 +160,10 @@ struct SampleIO {
     static __device__ __forceinline__ void load16(i32x4 (&raw)[NV], const void *re, const void *im, size_t e)
     {
         if constexpr (FMT == GAT_LAYOUT_PLANAR) {
-            raw[0] = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(static_cast<const float *>(re) + e));
-            raw[1] = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(static_cast<const float *>(im) + e));
+            raw[0] = GAT_NT_LOAD(reinterpret_cast<const i32x4 *>(static_cast<const float *>(re) + e));
+            raw[1] = GAT_NT_LOAD(reinterpret_cast<const i32x4 *>(static_cast<const float *>(im) + e));
         } else {
-            raw[0] = __builtin_nontemporal_load(
+            raw[0] = GAT_NT_LOAD(
                 reinterpret_cast<const i32x4 *>(static_cast<const unsigned char *>(re) + e * BYTES));
         }
     }
@@ -258,11 +265,11 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
     float wr, wi; // one-sample rotation exp(+j*2*pi*step)
     sincos_cycles(step - __builtin_rint(step), wr, wi);
 
-    float acc_re[MT][L], acc_im[MT][L];
+    f32x2 acc[MT][L]; // (re, im) pairs: one v_pk_fma_f32 per antenna, tap and sample
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int l = 0; l < L; ++l) acc_re[m][l] = acc_im[m][l] = 0.f;
+        for (int l = 0; l < L; ++l) acc[m][l] = f32x2{0.f, 0.f};
 
     const size_t base = (size_t)b * a.block_stride + (size_t)k * a.chan_stride +
                         (size_t)(at * MT) * a.ant_stride;
@@ -287,15 +294,15 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
             chip[l] = rep[(i & 3) * rep_ps + (i >> 2)];
         }
     };
-    // one sample of one antenna: conj(carrier) wipe-off (src/algorithms.jl:175-176), L taps
+    // one sample of one antenna: conj(carrier) wipe-off (src/algorithms.jl:175-176), L taps.
+    // (re, im) += chip * (dr, di) written on 2-vectors: ONE v_pk_fma_f32 with the chip broadcast by
+    // op_sel_hi.  (With separate re / im accumulator arrays the vectoriser also gets to v_pk_fma_f32 but
+    // pairs its operands with v_mov first -- more moves than FMAs; with several channels per signal
+    // byte this kernel is bound by vector issue.)
     auto accumulate = [&](int m, float xr, float xi, float cr, float ci, const float (&chip)[L]) {
-        const float dr = __builtin_fmaf(xr, cr, xi * ci);
-        const float di = __builtin_fmaf(xi, cr, -(xr * ci));
+        const f32x2 dw = {__builtin_fmaf(xr, cr, xi * ci), __builtin_fmaf(xi, cr, -(xr * ci))};
 #pragma unroll
-        for (int l = 0; l < L; ++l) {
-            acc_re[m][l] = __builtin_fmaf(chip[l], dr, acc_re[m][l]);
-            acc_im[m][l] = __builtin_fmaf(chip[l], di, acc_im[m][l]);
-        }
+        for (int l = 0; l < L; ++l) acc[m][l] = __builtin_elementwise_fma(f32x2{chip[l], chip[l]}, dw, acc[m][l]);
     };
     auto load_group = [&](i32x4 (&raw)[MT][IO::NV], int n) {
 #pragma unroll
@@ -339,13 +346,29 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
         }
     };
     // this step's replica segment: entry i <-> sample c*CHUNK + shift0 + i (src/algorithms.jl:753-757)
+    // A lane generates E consecutive entries: every code phase is the reference's FP64 expression
+    // (unfused), but only the first needs the full floored modulo -- the others follow from the exact
+    // floor differences (chips advance monotonically; bad channels have ratio = 0 here).
+    const int rep_e = (rep_cnt + kThreads - 1) / kThreads;
     auto fill_replica = [&](float *rep, int c) {
         const int x0 = c * CHUNK + shift0;
-        // not unrolled on purpose: the FP64 temporaries of 4-5 unrolled iterations cost ~30 VGPRs,
-        // i.e. one wave per SIMD of occupancy, and this loop runs in the shadow of the sample loads
+        const int i0 = tid * rep_e;
+        if (i0 >= rep_cnt) return;
+        const int i1 = min(i0 + rep_e, rep_cnt);
+        int ip_prev = (int)__builtin_floor(__dadd_rn(__dmul_rn(ratio, (double)(x0 + i0)), tau));
+        int idx = floormod_fast(ip_prev, Lc, inv_lc);
+        rep[(i0 & 3) * rep_ps + (i0 >> 2)] = (float)s_code[idx];
+        // not unrolled on purpose: the FP64 temporaries of unrolled iterations cost VGPRs, i.e. occupancy
 #pragma unroll 1
-        for (int i = tid; i < rep_cnt; i += kThreads)
-            rep[(i & 3) * rep_ps + (i >> 2)] = (float)s_code[chip_index(ratio, tau, x0 + i, Lc, inv_lc)];
+        for (int i = i0 + 1; i < i1; ++i) {
+            const int ip = (int)__builtin_floor(__dadd_rn(__dmul_rn(ratio, (double)(x0 + i)), tau));
+            const int adv = ip - ip_prev; // >= 0: ratio >= 0 and FP64 rounding is monotonic
+            ip_prev = ip;
+            idx += adv;
+            idx -= (idx >= Lc) ? Lc : 0;
+            if (adv >= Lc) idx = floormod_fast(ip, Lc, inv_lc); // more than a code period per sample
+            rep[(i & 3) * rep_ps + (i >> 2)] = (float)s_code[idx];
+        }
     };
 
     for (int c = c_begin; c < c_end; ++c) {
@@ -385,8 +408,8 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
     for (int l = 0; l < L; ++l)
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            v[(l * MT + m) * 2 + 0] = acc_re[m][l];
-            v[(l * MT + m) * 2 + 1] = acc_im[m][l];
+            v[(l * MT + m) * 2 + 0] = acc[m][l][0];
+            v[(l * MT + m) * 2 + 1] = acc[m][l][1];
         }
     Butterfly<NV, 32>::run(v, lane);
     s_part[wave * 64 + Butterfly<NV, 32>::index(lane)] = v[0]; // lanes sharing an index hold bit-identical sums

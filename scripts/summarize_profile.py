@@ -37,7 +37,7 @@ def main():
             for r in csv.DictReader(fh):
                 k = r["Kernel_Name"]
                 durs.setdefault(k, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    hot = {k: v for k, v in durs.items() if "dc_kernel" in k} or durs
+    hot = {k: v for k, v in durs.items() if "dc_kernel" in k or "mfma_" in k} or durs
     dom = max(hot, key=lambda k: sum(hot[k])) if hot else None
     if dom:
         d = durs[dom]
