@@ -35,6 +35,7 @@ struct gat_ctx {
     bool timer_running = false;
     int num_cus = 256;
     unsigned long long *dbg_ptr = nullptr; // diagnostic builds only
+    int max_ant_tile = kMaxAntTile; // env GAT_MAX_ANT_TILE (experiments)
     int mc_mode = 1; // GAT_MC_* kernel selection (gat_set_matrix_core); env GAT_NO_MFMA=1 starts at 0
     std::string err;
     gat_launch_info last{};
@@ -103,7 +104,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
 
     const int M = sig->num_ants;
     int MT = 1;
-    for (int mt = kMaxAntTile; mt >= 1; --mt)
+    for (int mt = c->max_ant_tile; mt >= 1; --mt)
         if (M % mt == 0) {
             MT = mt;
             break;
@@ -370,6 +371,7 @@ GAT_API int32_t gat_create(int32_t device, void *hip_stream, gat_ctx **out_ctx)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
     if (const char *e = std::getenv("GAT_NO_MFMA")) c->mc_mode = e[0] == '1' ? 0 : 1;
+    if (const char *e = std::getenv("GAT_MAX_ANT_TILE")) c->max_ant_tile = std::min(kMaxAntTile, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("GAT_MC_MODE")) c->mc_mode = (e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
         delete c;
