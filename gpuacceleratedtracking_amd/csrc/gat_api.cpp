@@ -137,16 +137,21 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         while (nct > 1 && nct * CT > 20) nct >>= 1; // both kernels keep at most 20 channel slots per workgroup
         // kernel choice: 3 / 1 (auto) -> split-bf16 when its tile fits in LDS, 2 -> f32 MFMA
         int kind = 0, rt = 1, rep_stride_m = 0;
+        int nslots_b = 0, tiles_b = 0, nct_b = 1;
         if (shape_ok && c->mc_mode != 2 && c->d_code_bits && N % 4 == 0) {
+            // split-bf16 kernel: columns packed flat (2 L per channel), 32 per tile
+            tiles_b = (2 * L * K + 31) / 32;
             const int rt_max = (M / 16) % 4 == 0 ? 4 : ((M / 16) % 2 == 0 ? 2 : 1);
-            for (int n = nct; n >= 1 && !kind; n >>= 1) {
-                rt = (rt_max == 4 && n == 1) ? 2 : rt_max; // <4,1> does not fit the 168-VGPR budget of a 12-wave workgroup
+            for (int n = tiles_b >= 4 ? 4 : (tiles_b >= 2 ? 2 : 1); n >= 1 && !kind; n >>= 1) {
+                rt = (rt_max == 4 && n == 1) ? 2 : rt_max; // <4,1> does not fit the VGPR budget of a 12-wave workgroup
                 const int T = mfma_bf16_tile_samples(rt, n);
                 const int rs = ((T + (int)span + 31) / 32) * 32 + 1; // odd: channel rows land on different banks
-                if (n * CT * T / 2 > 512 || n * CT > 20) continue; // one (slot, sample pair) item per producer thread
-                if (mfma_bf16_lds_bytes(rt, n, CT, rs, c->code_bits_stride) <= 160 * 1024) {
+                const int ns = mfma_bf16_slots(n, L, K);
+                if (ns * T / 2 > 512 || ns > mfma_bf16_max_slots()) continue; // one (slot, sample pair) item per producer thread
+                if (mfma_bf16_lds_bytes(rt, n, ns, rs, c->code_bits_stride) <= 160 * 1024) {
                     kind = 2;
-                    nct = n;
+                    nct_b = n;
+                    nslots_b = ns;
                     rep_stride_m = rs;
                 }
             }
@@ -156,6 +161,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             if (mfma_lds_bytes(nct, CT, rep_stride_m, c->code_row_stride, 0) <= 160 * 1024) kind = 1;
         }
         if (kind) {
+            if (kind == 2) nct = nct_b;
             const int T = kind == 2 ? mfma_bf16_tile_samples(rt, nct) : 256;
             MfArgs m{};
             m.re = static_cast<const float *>(sig->re);
@@ -170,7 +176,8 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             m.fs = fs;
             m.M = M; m.K = K; m.B = B; m.L = L; m.Lc = c->Lc; m.num_prns = c->P; m.code_row_stride = c->code_row_stride;
             m.CT = CT;
-            m.chan_groups = (nct_total + nct - 1) / nct;
+            m.chan_groups = kind == 2 ? (tiles_b + nct - 1) / nct : (nct_total + nct - 1) / nct;
+            m.nslots = nslots_b;
             m.ant_tiles = kind == 2 ? M / (16 * rt) : M / 16;
             m.total_steps = (int)((N + T - 1) / T);
             const long long groups_m = (long long)B * m.ant_tiles * m.chan_groups;
@@ -215,7 +222,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
                 m.codes_in_lds = 1; // sign-bit tables, always staged
                 m.code_bits = c->d_code_bits;
                 m.code_bits_stride = c->code_bits_stride;
-                lds = (unsigned)mfma_bf16_lds_bytes(rt, nct, CT, m.rep_stride, c->code_bits_stride);
+                lds = (unsigned)mfma_bf16_lds_bytes(rt, nct, m.nslots, m.rep_stride, c->code_bits_stride);
                 GAT_HIP(c, launch_mfma_bf16(m, rt, nct, (unsigned)grid_m, lds, c->stream));
             } else {
                 m.codes_in_lds = mfma_lds_bytes(nct, CT, m.rep_stride, c->code_row_stride, 1) <= 160 * 1024;
@@ -226,7 +233,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             if (fin_m)
                 GAT_HIP(c, launch_finalize(c->d_partial, out_re, out_im, m.splits, L * M * 2, (long long)B * K, c->stream));
             c->last.workgroups = (int32_t)grid_m;
-            c->last.threads = kind == 2 ? 768 : 2 * kThreads;
+            c->last.threads = kind == 2 ? mfma_bf16_threads(rt, nct) : 2 * kThreads;
             c->last.splits = m.splits;
             c->last.ant_tile = kind == 2 ? 16 * rt : 16;
             c->last.vec = 4;

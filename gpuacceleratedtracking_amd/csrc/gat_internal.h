@@ -76,7 +76,8 @@ struct MfArgs {
     long long N, ant_stride, block_stride;
     double fs;
     int M, K, B, L, Lc, num_prns, code_row_stride;
-    int CT;              // channels per 32-column tile = 16 / L
+    int CT;              // f32 kernel: channels per 32-column tile = 16 / L
+    int nslots;          // split-bf16 kernel: channel slots per workgroup (columns packed flat)
     int chan_groups;     // ceil(ceil(K / CT) / NCT)
     int ant_tiles;       // M / 16 (f32 kernel) or M / (16 * rt) (split-bf16 kernel)
     int splits, steps_per_split, total_steps, num_tiles;
@@ -92,9 +93,12 @@ hipError_t launch_mfma(const MfArgs &a, int nct, unsigned grid, unsigned lds_byt
 size_t mfma_lds_bytes(int nct, int ct, int rep_stride, int code_row_stride, int codes_in_lds);
 // split-bf16 matrix-core kernel (gat_mfma_bf16.hip): rt = 16-antenna row tiles per workgroup (1, 2, 4)
 hipError_t launch_mfma_bf16(const MfArgs &a, int rt, int nct, unsigned grid, unsigned lds_bytes, hipStream_t s);
-size_t mfma_bf16_lds_bytes(int rt, int nct, int ct, int rep_stride, int code_bits_stride);
+size_t mfma_bf16_lds_bytes(int rt, int nct, int nslots, int rep_stride, int code_bits_stride);
+int mfma_bf16_slots(int nct, int L, int K); // channel slots per workgroup (flat column packing)
+int mfma_bf16_max_slots();
 int mfma_bf16_tile_samples(int rt, int nct);
 int mfma_bf16_max_chain(); // samples one accumulation chain may cover
+int mfma_bf16_threads(int rt, int nct); // workgroup size of the instance
 
 // Launchers implemented in gat_kernels.hip.  All return hipError_t of the launch.
 hipError_t launch_dc(const DcArgs &a, const DcLaunch &cfg, hipStream_t s);

@@ -6,7 +6,7 @@
 //
 // as the real GEMM  C[32 x 32] += X^T[32 x 16] * W[16 x 32]  on v_mfma_f32_32x32x16_bf16:
 //   rows    i = 2*m + {x_re, x_im}            (16 antennas per row tile, RT row tiles per wave)
-//   columns j = 2*(kc*L + l) + {w_re = chip*cos, w_im = -chip*sin}   (CT = 16/L channels)
+//   columns j = 2*(k*L + l) + {w_re = chip*cos, w_im = -chip*sin}, packed flat over all channels
 //   the 16 reduction slots = 2 samples (one per 32-lane half) x 8 cross products:
 //        slot        0    1    2    3    4    5    6    7
 //        x term      hi   mid  hi   mid  hi   mid  lo   lo       = dwords {a, a, a, b}
@@ -41,9 +41,12 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int kMbThreads = 768; // 4 consumer + 8 producer waves
+// workgroup size: 4 consumer waves + 12 producer waves (4 per SIMD, 128 VGPRs) where the instance fits that
+// register budget, otherwise + 8 producer waves (3 per SIMD, 168 VGPRs)
+constexpr int mb_threads(int RT, int NCT) { return ((RT == 2 && NCT == 1) || (RT == 4 && NCT == 2)) ? 768 : 1024; }
 constexpr int kMaxChain = 8192;  // samples per accumulation chain (f32 rounding of the running sum)
 constexpr int kReanchor = 16;   // steps between FP64 re-anchors of the producers' carried phasor / code index
+constexpr int kMbMaxSlots = 24;  // channel slots per workgroup (header size)
 constexpr int kHeader = 1536; // ChanInfoB[<= 20] (64 B each) + slack, 16-byte aligned
 
 __device__ __forceinline__ void sincos_cycles_b(double theta, float &c, float &s)
@@ -108,8 +111,8 @@ __device__ __forceinline__ void wait_loads(f32x4_ (&xv)[XI])
 #define GAT_PERM(a, b, sel) __builtin_amdgcn_perm((a), (b), (sel))
 
 // ---- consumer fragment fetches -------------------------------------------------------------------
-// All LDS reads of the MFMA loop are inline assembly, issued TWO k-slices ahead of their use into a
-// ring of three register sets, with one explicit counted s_waitcnt per slice (the slice in between may
+// All LDS reads of the MFMA loop are inline assembly, issued D = 2..4 k-slices ahead of their use into a
+// ring of D + 1 register sets, with one explicit counted s_waitcnt per slice (the slice in between may
 // stay in flight): an LDS round trip under this kernel's load is longer than the 32 * RT cycles of a
 // slice.  lgkmcnt holds at most 15 operations, hence one ds_read_b64 per X fragment (2 + RT reads per
 // slice, 2 slices outstanding).  The X fragment {a, a, a, b} is the fetched {a, b} plus ONE
@@ -144,13 +147,20 @@ __device__ __forceinline__ void frag_wait(FragSet<RT> &s)
                      : "+v"(s.w), "+v"(s.m), "+v"(s.xa[0]), "+v"(s.xa[1]), "+v"(s.xa[2]), "+v"(s.xa[3])
                      : "n"(NEWER));
 }
+// fetch distance in slices: as deep as the 4-bit lgkmcnt allows (2 + RT reads per slice), at most 4
+template <int RT>
+constexpr int frag_depth() { return (15 / (2 + RT)) < 4 ? (15 / (2 + RT)) : 4; }
+
 template <int J, int NM, int RT>
-__device__ __forceinline__ void mfma_slice(f32x16 (&acc)[RT], FragSet<RT> (&fs)[3], unsigned w_addr, unsigned r_addr,
-                                           const unsigned (&x_addr)[RT])
+__device__ __forceinline__ void mfma_slice(f32x16 (&acc)[RT], FragSet<RT> (&fs)[frag_depth<RT>() + 1], unsigned w_addr,
+                                           unsigned r_addr, const unsigned (&x_addr)[RT])
 {
-    FragSet<RT> &cur = fs[J % 3];
-    frag_wait<RT, (J + 1 < NM ? 2 + RT : 0)>(cur);
-    if constexpr (J + 2 < NM) frag_issue<J + 2, RT>(fs[(J + 2) % 3], w_addr, r_addr, x_addr);
+    constexpr int D = frag_depth<RT>();
+    FragSet<RT> &cur = fs[J % (D + 1)];
+    // slices J+1 .. J+D-1 (those that exist) were issued after this one and may stay in flight
+    constexpr int newer = (NM - 1 - J) < (D - 1) ? (NM - 1 - J) : (D - 1);
+    frag_wait<RT, newer *(2 + RT)>(cur);
+    if constexpr (J + D < NM) frag_issue<J + D, RT>(fs[(J + D) % (D + 1)], w_addr, r_addr, x_addr);
     u32x4 w = cur.w;
     const unsigned mk = cur.m; // chip sign of this column's tap: 0x80008000 or 0
     w[0] ^= mk;
@@ -183,9 +193,12 @@ template <int NM, int RT, int... J>
 __device__ __forceinline__ void mfma_step(f32x16 (&acc)[RT], unsigned w_addr, unsigned r_addr, const unsigned (&x_addr)[RT],
                                           std::integer_sequence<int, J...>)
 {
-    FragSet<RT> fs[3];
+    constexpr int D = frag_depth<RT>();
+    FragSet<RT> fs[D + 1];
     frag_issue<0, RT>(fs[0], w_addr, r_addr, x_addr);
-    if constexpr (NM > 1) frag_issue<1, RT>(fs[1], w_addr, r_addr, x_addr);
+    if constexpr (NM > 1 && D > 1) frag_issue<1, RT>(fs[1], w_addr, r_addr, x_addr);
+    if constexpr (NM > 2 && D > 2) frag_issue<2, RT>(fs[2], w_addr, r_addr, x_addr);
+    if constexpr (NM > 3 && D > 3) frag_issue<3, RT>(fs[3], w_addr, r_addr, x_addr);
     (mfma_slice<J, NM, RT>(acc, fs, w_addr, r_addr, x_addr), ...);
 }
 
@@ -207,13 +220,14 @@ constexpr int tile_samples(int RT, int NCT)
 } // namespace
 
 // RT: 16-antenna row tiles per workgroup (1, 2, 4); NCT: 32-column channel tiles per workgroup (1, 2, 4).
-// Workgroup = 12 waves, three per SIMD: waves 0-3 consumers (MFMA + fragment fetches), waves 4-11
+// Workgroup = 16 (or 12) waves, four (three) per SIMD: waves 0-3 consumers (MFMA + fragment fetches), waves 4-15 (4-11)
 // producers (HBM loads two steps ahead, bf16 splits, carriers, code replica) -- their long dependent
 // chains (FP64 code phase, sincos, split) hide behind each other and behind the matrix pipe.
 // Double-buffered LDS, one s_barrier per step of T samples.
 template <int RT, int NCT>
-__global__ void __launch_bounds__(kMbThreads) mfma_bf16_kernel(const MfArgs a)
+__global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const MfArgs a)
 {
+    constexpr int kMbThreads = mb_threads(RT, NCT);
     constexpr int T = tile_samples(RT, NCT);
     constexpr int WPT = 4 / NCT;   // consumer waves per channel tile (they split the step's samples)
     constexpr int SW = T / WPT;    // samples per consumer wave and step
@@ -221,11 +235,15 @@ __global__ void __launch_bounds__(kMbThreads) mfma_bf16_kernel(const MfArgs a)
     constexpr int XS = T + 1;      // u32x2 per plane row (odd: 32 planes x one sample = 32 distinct bank pairs)
     constexpr int WS = T + 1;      // u32x4 per carrier row
     constexpr int QPR = T / 4;     // 4-sample groups per plane row
-    constexpr int PT = kMbThreads - kThreads; // producer threads (512)
+    constexpr int PT = kMbThreads - kThreads; // producer threads (768 or 512)
     constexpr int NG = RT * 32 * QPR;         // 4-sample groups per step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int CT = a.CT, L = a.L;
-    const int nslots = NCT * CT;
+    // Columns are packed flat: column c = 2*L*k + 2*l + comp, a workgroup owns columns [32*NCT*cg, 32*NCT*(cg+1))
+    // -- a channel may straddle two tiles (or two workgroups: both generate its carrier), no column is
+    // wasted on alignment (64 channels x 3 taps = 12 tiles, not 13).  Channel slots of the workgroup:
+    // k_first .. k_first + nslots - 1 (nslots = the host's upper bound, LDS is laid out for it).
+    const int L = a.L;
+    const int nslots = a.nslots;
     const int wrows = 2 * nslots + 1; // + one row of zeros for dead columns
     const int RS = a.rep_stride;
     ChanInfoB *s_chan = reinterpret_cast<ChanInfoB *>(smem);
@@ -253,8 +271,9 @@ __global__ void __launch_bounds__(kMbThreads) mfma_bf16_kernel(const MfArgs a)
     const float inv_lc = 1.0f / (float)Lc;
     const int span = a.rep_span;
 
+    const int k_first = (32 * NCT * cg) / (2 * L);
     if (tid < nslots) {
-        const int k = (cg * NCT + tid / CT) * CT + tid % CT;
+        const int k = k_first + tid;
         ChanInfoB ci{};
         ci.valid = k < a.K;
         if (ci.valid) {
@@ -405,7 +424,7 @@ __global__ void __launch_bounds__(kMbThreads) mfma_bf16_kernel(const MfArgs a)
             }
         } else { // the overlap with the previous step is already known
             const int pw = wave - 4;
-            for (int slot = pw; slot < nslots; slot += 8)
+            for (int slot = pw; slot < nslots; slot += PT / 64)
                 for (int e = lane; e < span; e += 64) rb[slot * RS + e] = rprev[slot * RS + e + T];
         }
         if (!have_item) return;
@@ -448,14 +467,16 @@ __global__ void __launch_bounds__(kMbThreads) mfma_bf16_kernel(const MfArgs a)
     const int ctl = cw / WPT; // channel tile of this consumer wave within the workgroup
     const int sub = cw % WPT; // sample sub-range of the step
     const int r = lane & 31, h = lane >> 5;
-    const int kl = r >> 1, comp = r & 1;
-    const int kc = kl / L, l = kl - kc * L;
-    const int slot_c = ctl * CT + (kc < CT ? kc : 0);
+    const int col = 32 * (NCT * cg + ctl) + r;           // flat column of this lane
+    const int k_col = col / (2 * L), rem_col = col - 2 * L * k_col;
+    const int l = rem_col >> 1, comp = rem_col & 1;      // (2L is even: comp == r & 1, partner column = lane ^ 1)
+    const bool in_range = k_col < a.K && k_col - k_first < nslots;
+    const int slot_c = in_range ? k_col - k_first : 0;
     const ChanInfoB my = s_chan[slot_c];
-    const bool live_col = kc < CT && my.valid;
+    const bool live_col = in_range && my.valid;
     const int col0 = sub * SW + h * NM; // first sample (step-relative) of this lane's stream
     const int w_off = (live_col ? 2 * slot_c + comp : 2 * nslots) * WS + col0;
-    const int r_off = slot_c * RS + (a.shifts[l < L ? l : 0] - a.shifts[0]) + col0;
+    const int r_off = slot_c * RS + (a.shifts[l] - a.shifts[0]) + col0;
     const int x_off = r * XS + col0;
 
     // the consumers' few vector instructions per slice must not queue behind the producers' streams
@@ -575,7 +596,7 @@ __global__ void __launch_bounds__(kMbThreads) mfma_bf16_kernel(const MfArgs a)
     }
 #ifdef GAT_MFMA_STAMPS
     if (lane == 0 && a.dbg) { // [workgroup][wave][4]
-        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * 12 + wave) * 4;
+        unsigned long long *d = a.dbg + ((size_t)blockIdx.x * 16 + wave) * 4;
         d[0] = t_work; d[1] = t_wait; d[2] = t_gen; d[3] = t_st;
     }
 #endif
@@ -604,7 +625,7 @@ __global__ void __launch_bounds__(kMbThreads) mfma_bf16_kernel(const MfArgs a)
     if (producer || sub != 0) return;
     // C[row][col]: col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5).  Rows 2m / 2m+1 are
     // registers i / i+1 of one lane; columns w_re / w_im are lanes c / c^1.
-    const int k = (cg * NCT + ctl) * CT + kc;
+    const int k = k_col;
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
 #pragma unroll
@@ -635,19 +656,26 @@ __global__ void __launch_bounds__(kMbThreads) mfma_bf16_kernel(const MfArgs a)
 
 int mfma_bf16_tile_samples(int rt, int nct) { return tile_samples(rt, nct); }
 int mfma_bf16_max_chain() { return kMaxChain; }
+int mfma_bf16_max_slots() { return kMbMaxSlots; }
+int mfma_bf16_threads(int rt, int nct) { return mb_threads(rt, nct); }
 
-size_t mfma_bf16_lds_bytes(int rt, int nct, int ct, int rep_stride, int code_bits_stride)
+int mfma_bf16_slots(int nct, int L, int K)
+{ // upper bound of the channels a workgroup's 32 * nct flat columns touch
+    const int s = (32 * nct + 2 * L - 1) / (2 * L) + 1;
+    return s < K ? s : K;
+}
+
+size_t mfma_bf16_lds_bytes(int rt, int nct, int nslots, int rep_stride, int code_bits_stride)
 {
-    static_assert(sizeof(ChanInfoB) * 20 <= kHeader, "channel table must fit the header");
+    static_assert(sizeof(ChanInfoB) * kMbMaxSlots <= kHeader, "channel table must fit the header");
     const int T = tile_samples(rt, nct);
-    const int nslots = nct * ct;
     return (size_t)kHeader + (size_t)2 * rt * 32 * (T + 1) * 8 + (size_t)2 * (2 * nslots + 1) * (T + 1) * 16 +
            (size_t)((2 * nslots * rep_stride + 3) & ~3) * 4 + (size_t)nslots * code_bits_stride * 4;
 }
 
 hipError_t launch_mfma_bf16(const MfArgs &a, int rt, int nct, unsigned grid, unsigned lds_bytes, hipStream_t s)
 {
-    const dim3 g(grid), blk(kMbThreads);
+    const dim3 g(grid), blk(mb_threads(rt, nct));
 #define GAT_MB(RT_, NCT_) \
     case RT_ * 8 + NCT_: hipLaunchKernelGGL((mfma_bf16_kernel<RT_, NCT_>), g, blk, lds_bytes, s, a); break;
     switch (rt * 8 + nct) {

@@ -18,10 +18,10 @@ for N, M, L, K, B, bs in SHAPES:
     ctx.sync(); ctx.timer_start(); op.launch(desc); ms = ctx.timer_stop()
     info = ctx.last_launch_info()
     nwg = info["workgroups"]
-    buf = np.zeros(nwg * 12 * 4, dtype=np.uint64)
+    buf = np.zeros(nwg * 16 * 4, dtype=np.uint64)
     fn = ctx.lib.gat_debug_read; fn.restype = C.c_int32; fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     assert fn(ctx._h, buf.ctypes.data, buf.size) == 0
-    d = buf.reshape(nwg, 12, 4).astype(np.float64)
+    d = buf.reshape(nwg, 16, 4).astype(np.float64)
     rt = info["ant_tile"] // 16
     print(f"N={N} M={M} K={K} B={B}: {ms:.3f} ms, {nwg} wgs, splits {info['splits']}, lds {info['lds_bytes']}, mc {info['matrix_core']}")
     tot = (d[:, :, 0] + d[:, :, 1]).mean()
