@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         if (e0 + 1 < e_end) row[e0 + 1] = chip_mask(tab, t1);
     };
     // one item = (slot, 2 consecutive samples): carrier fragments + the 2 new replica entries.  A producer
-    // thread owns the same item in every step (at most one: the planner keeps nslots * T / 2 <= 512) and
+    // thread owns the same item in every step (at most one: the planner keeps nslots * T / 2 <= PT) and
     // carries its phasor and code index from step to step: one complex rotation by e^{j 2 pi T step}
     // instead of an FP64 range reduction + sincos; re-anchored in FP64 every kReanchor steps.
     float car_r = 0.f, car_i = 0.f;

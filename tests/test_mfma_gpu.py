@@ -98,6 +98,48 @@ def test_planner_keeps_vector_kernel_for_other_shapes(g):
         assert info["matrix_core"] == 0, (M, K, L, info)
 
 
+def test_planner_fallbacks_of_the_split_bf16_kernel(g):
+    """Shapes the split-bf16 kernel does not take run on the f32-MFMA or the vector kernel -- same results."""
+    # odd sample count: no 16-byte loads -> vector kernel
+    case = make_case(11, N=4002, M=16, L=3, K=5, B=1)
+    got, info = run(g, case)
+    assert info["matrix_core"] == 0, info
+    check_close(got, oracle_result(case), what="N % 4 != 0")
+    # two taps: 8 channels per f32 tile; 20 channels pack flat into 80 columns = 3 split-bf16 tiles
+    case = make_case(12, N=6000, M=16, L=2, K=20, B=2, fs=4e6)
+    ref = oracle_result(case)
+    for mode, kind in ((g.GAT_MC_AUTO, 2), (g.GAT_MC_F32, 1), (g.GAT_MC_VECTOR, 0)):
+        got, info = run(g, case, matrix_core=mode)
+        assert info["matrix_core"] == kind, (mode, info)
+        check_close(got, ref, what=f"L=2 K=20 mode {mode}")
+
+
+def test_non_pm1_code_table_takes_the_f32_kernel(g):
+    """A caller-supplied table with blanked (0) chips has no sign-bit form: auto selection must use the
+    f32-MFMA kernel (which multiplies by the chip value) and still match the oracle."""
+    import torch
+    case = make_case(21, N=8000, M=16, L=3, K=5, B=1, fs=5e6)
+    codes = case["codes"].copy()
+    codes[:, ::7] = 0  # every 7th chip blanked
+    case["codes"] = codes
+    ref = oracle_result(case)
+    ctx = g.get_context()
+    sysobj = g.GPSL1(codes=codes, code_frequency=case["fc"])
+    try:
+        for mode, kind in ((g.GAT_MC_AUTO, 1), (g.GAT_MC_BF16_SPLIT, 0), (g.GAT_MC_VECTOR, 0)):
+            ctx.set_matrix_core(mode)
+            op = g.StreamCorrelator(sysobj, case["N"], case["M"], case["B"], case["K"], case["shifts"], case["fs"])
+            p = case["prm"]
+            op.set_params(g.make_params(p["prn0"], p["code_freq_hz"], p["carrier_freq_hz"], p["code_phase_chips"],
+                                        p["carrier_phase_cycles"]))
+            op(torch.from_numpy(case["re"]).to(ctx.device), torch.from_numpy(case["im"]).to(ctx.device))
+            assert ctx.last_launch_info()["matrix_core"] == kind, (mode, ctx.last_launch_info())
+            check_close(op.result(), ref, what=f"blanked chips, mode {mode}")
+    finally:
+        ctx.set_matrix_core(1)
+        g.StreamCorrelator(g.GPSL1(), 64, 1, 1, 1, case["shifts"], case["fs"])  # restore the standard table
+
+
 def test_mfma_bad_prn_poisons_output(g):
     import torch
     system = g.GPSL1()
