@@ -13,7 +13,7 @@ import time
 import numpy as np
 
 from . import _lib
-from .algorithms import ALGODICT, ALGODICTINV, KernelAlgorithm, algorithm_flags
+from .algorithms import ALGODICT, ALGODICTINV, MEMDICT, REDDICT, KernelAlgorithm, algorithm_flags
 from .context import get_context
 from .correlator import EarlyPromptLateCorrelator, NumAccumulators, NumAnts, get_correlator_sample_shifts
 from .gen_signal import gen_signal, gen_signal_stream, make_params
@@ -103,6 +103,95 @@ def run_kernel_benchmark(benchmark_params: dict, seconds: float = 1.0, device=No
     add_metadata(p, processor, algorithm, ctx)
     p["accumulators"] = op.result()[0, 0]
     return p
+
+
+def _time_calls(fn, ctx, seconds: float, max_samples: int = 10000) -> np.ndarray:
+    """BenchmarkTools-style sampling of ``CUDA.@sync fn()``: sync-inclusive wall time per call in ns."""
+    for _ in range(3):
+        fn()
+    ctx.sync()
+    times = []
+    t_end = time.perf_counter() + seconds
+    while len(times) < max_samples and (time.perf_counter() < t_end or len(times) < 10):
+        t0 = time.perf_counter_ns()
+        fn()
+        ctx.sync()
+        times.append(time.perf_counter_ns() - t0)
+    return np.asarray(times, dtype=np.float64)
+
+
+def _stats(d: dict, times: np.ndarray) -> dict:
+    d = dict(d)
+    d["Minimum"], d["Mean"], d["Median"] = float(times.min()), float(times.mean()), float(np.median(times))
+    d["Std"] = float(times.std(ddof=1)) if times.size > 1 else 0.0
+    d["samples"] = int(times.size)
+    return d
+
+
+def run_reduction_benchmark(benchmark_params: dict, seconds: float = 0.5, device=None) -> dict:
+    """``run_reduction_benchmark(d)`` (src/benchmarks.jl:1137-1148; grid scripts/benchmark_reduction.jl:5-10).
+    Input ones + 0im of size (num_samples, num_ants, num_correlators); the three algorithms differ in how
+    many launches the column sums take (src/benchmarks.jl:981-1135): "pure" reduces every real plane by
+    itself (2 M L launch sequences), "cplx" every (antenna, correlator) complex column (M L), "cplx_multi"
+    all columns at once (1).  Each sequence is libgat's two-stage ``gat_reduce_cplx_multi``."""
+    import torch
+
+    p = dict(benchmark_params)
+    n, m, l = int(p["num_samples"]), int(p["num_ants"]), int(p["num_correlators"])
+    alg = REDDICT[p["algorithm"]]
+    ctx = get_context(device)
+    re = torch.ones((l, m, n), dtype=torch.float32, device=ctx.device)
+    im = torch.zeros_like(re)
+    out_re = torch.empty((l, m), dtype=torch.float32, device=ctx.device)
+    out_im = torch.empty_like(out_re)
+    if alg.id == 3:
+        def fn():
+            ctx.reduce_cplx_multi(re, im, n, m * l, out_re, out_im)
+    elif alg.id == 2:
+        cols = [(re[i, j], im[i, j], out_re[i, j:j + 1], out_im[i, j:j + 1]) for i in range(l) for j in range(m)]
+
+        def fn():
+            for r_, i_, o_r, o_i in cols:
+                ctx.reduce_cplx_multi(r_, i_, n, 1, o_r, o_i)
+    else:
+        scratch = torch.empty((1,), dtype=torch.float32, device=ctx.device)
+        planes = [(pl[i, j], out[i, j:j + 1]) for pl, out in ((re, out_re), (im, out_im)) for i in range(l)
+                  for j in range(m)]
+
+        def fn():  # one real plane per sequence (its own plane doubles as the unused imaginary input)
+            for pl, o in planes:
+                ctx.reduce_cplx_multi(pl, pl, n, 1, o, scratch)
+    times = _time_calls(fn, ctx, seconds)
+    ctx.sync()
+    got = (out_re.cpu().numpy(), out_im.cpu().numpy())
+    assert np.all(got[0] == n) and np.all(got[1] == 0), "all-ones reduction must give [N N N] (test/reduction.jl:51-52)"
+    return _stats(p, times)
+
+
+def run_replica_benchmark(benchmark_params: dict, seconds: float = 0.5, device=None) -> dict:
+    """``run_replica_benchmark(d)`` (src/replica_benchmarks.jl:137-147; grid scripts/benchmark_textmem.jl:4-7):
+    stand-alone code replica of num_samples + num_of_shifts entries, GPS L1 prn 1, code phase 0, E/P/L
+    shifts at fs = num_samples / 1 ms.  "gmem": exact FP64 floor / mod lookup; "textmem": the Float32
+    normalised-coordinate addressing of the reference's texture kernels (there is no texture unit in this
+    build: same memory path, different index arithmetic)."""
+    import torch
+
+    p = dict(benchmark_params)
+    n = int(p["num_samples"])
+    alg = MEMDICT[p["algorithm"]]
+    ctx = get_context(device)
+    system = GNSSDICT["GPSL1"](use_gpu=True)
+    ctx.set_codes(system.codes)
+    fs = n / 1e-3
+    shifts = get_correlator_sample_shifts(system, EarlyPromptLateCorrelator(NumAnts(1), NumAccumulators(3)), fs, 0.5)
+    count = n + int(shifts[-1] - shifts[0])
+    rep = torch.zeros(count, dtype=torch.float32, device=ctx.device)
+
+    def fn():
+        ctx.gen_code_replica(rep, count, 0, get_code_frequency(system), fs, 0.0, int(shifts[0]),
+                             f32_coordinates=alg.id == 2)
+    times = _time_calls(fn, ctx, seconds)
+    return _stats(p, times)
 
 
 # ------------------------------------------------------------------------------------------
