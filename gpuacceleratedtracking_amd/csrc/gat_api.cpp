@@ -130,15 +130,16 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         std::stable_sort(order, order + L, [&](int x, int y) { return shifts[x] < shifts[y]; });
         const long long span = (long long)shifts[order[L - 1]] - shifts[order[0]];
         const int CT = L <= kMfmaMaxTaps ? 16 / L : 0;
-        const bool shape_ok = c->mc_mode != 0 && planar && vec == 4 && M % 16 == 0 && sig->chan_stride == 0 && CT >= 1 &&
+        const bool shape_any = c->mc_mode != 0 && vec == 4 && M % 16 == 0 && sig->chan_stride == 0 && CT >= 1 &&
                               span <= kMfmaMaxSpan && 2 * std::min(K, CT) * L >= 12 /* >= 3/8 of the columns */;
+        const bool shape_ok = shape_any && planar; // the f32-MFMA kernel reads planar f32 only
         const int nct_total = shape_ok ? (K + CT - 1) / CT : 1;
         int nct = nct_total >= 4 ? 4 : (nct_total >= 2 ? 2 : 1);
         while (nct > 1 && nct * CT > 20) nct >>= 1; // both kernels keep at most 20 channel slots per workgroup
         // kernel choice: 3 / 1 (auto) -> split-bf16 when its tile fits in LDS, 2 -> f32 MFMA
         int kind = 0, rt = 1, rep_stride_m = 0;
         int nslots_b = 0, tiles_b = 0, nct_b = 1;
-        if (shape_ok && c->mc_mode != 2 && c->d_code_bits && N % 4 == 0) {
+        if (shape_any && c->mc_mode != 2 && c->d_code_bits && N % spv == 0 && spv <= 8) {
             // split-bf16 kernel: columns packed flat (2 L per channel), 32 per tile
             tiles_b = (2 * L * K + 31) / 32;
             const int rt_max = (M / 16) % 4 == 0 ? 4 : ((M / 16) % 2 == 0 ? 2 : 1);
@@ -165,8 +166,8 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             if (kind == 2) nct = nct_b;
             const int T = kind == 2 ? mfma_bf16_tile_samples(rt, nct) : 256;
             MfArgs m{};
-            m.re = static_cast<const float *>(sig->re);
-            m.im = static_cast<const float *>(sig->im);
+            m.re = sig->re;
+            m.im = sig->im;
             m.params = params_dev;
             m.codes = c->d_codes;
             m.out_re = out_re;
@@ -224,7 +225,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
                 m.code_bits = c->d_code_bits;
                 m.code_bits_stride = c->code_bits_stride;
                 lds = (unsigned)mfma_bf16_lds_bytes(rt, nct, m.nslots, m.rep_stride, c->code_bits_stride);
-                GAT_HIP(c, launch_mfma_bf16(m, rt, nct, (unsigned)grid_m, lds, c->stream));
+                GAT_HIP(c, launch_mfma_bf16(m, rt, nct, fmt, (unsigned)grid_m, lds, c->stream));
             } else {
                 m.codes_in_lds = mfma_lds_bytes(nct, CT, m.rep_stride, c->code_row_stride, 1) <= 160 * 1024;
                 lds = (unsigned)mfma_lds_bytes(nct, CT, m.rep_stride, c->code_row_stride, m.codes_in_lds);

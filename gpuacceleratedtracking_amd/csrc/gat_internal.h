@@ -65,8 +65,8 @@ struct DcLaunch {
 constexpr int kMfmaMaxTaps = 16;     // 2 * CT * L <= 32 columns with CT >= 1
 constexpr int kMfmaMaxSpan = 768;    // replica halo served per 256-sample step
 struct MfArgs {
-    const float *re;
-    const float *im;
+    const void *re; // planar f32: re plane; interleaved formats (split-bf16 kernel only): base pointer
+    const void *im; // planar f32: im plane; otherwise null
     const gat_channel_params *params;
     const int8_t *codes;
     const uint32_t *code_bits; // split-bf16 kernel: sign-bit tables [P][code_bits_stride]
@@ -92,7 +92,7 @@ struct MfArgs {
 hipError_t launch_mfma(const MfArgs &a, int nct, unsigned grid, unsigned lds_bytes, hipStream_t s);
 size_t mfma_lds_bytes(int nct, int ct, int rep_stride, int code_row_stride, int codes_in_lds);
 // split-bf16 matrix-core kernel (gat_mfma_bf16.hip): rt = 16-antenna row tiles per workgroup (1, 2, 4)
-hipError_t launch_mfma_bf16(const MfArgs &a, int rt, int nct, unsigned grid, unsigned lds_bytes, hipStream_t s);
+hipError_t launch_mfma_bf16(const MfArgs &a, int rt, int nct, int fmt, unsigned grid, unsigned lds_bytes, hipStream_t s);
 size_t mfma_bf16_lds_bytes(int rt, int nct, int nslots, int rep_stride, int code_bits_stride);
 int mfma_bf16_slots(int nct, int L, int K); // channel slots per workgroup (flat column packing)
 int mfma_bf16_max_slots();

@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(2 * kThreads) mfma_kernel(const MfArgs a)
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             const int plane = pw * 8 + p; // row = 2*m_local + comp
-            const float *src = ((plane & 1) ? a.im : a.re) + base + (size_t)(plane >> 1) * a.ant_stride + nb + 4 * lane;
+            const float *src = static_cast<const float *>((plane & 1) ? a.im : a.re) + base + (size_t)(plane >> 1) * a.ant_stride + nb + 4 * lane;
             if (nb + 4 * lane + 4 <= N) {
                 xv[p] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ *>(src));
             } else {

@@ -224,7 +224,7 @@ constexpr int tile_samples(int RT, int NCT)
 // producers (HBM loads two steps ahead, bf16 splits, carriers, code replica) -- their long dependent
 // chains (FP64 code phase, sincos, split) hide behind each other and behind the matrix pipe.
 // Double-buffered LDS, one s_barrier per step of T samples.
-template <int RT, int NCT>
+template <int RT, int NCT, int FMT>
 __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const MfArgs a)
 {
     constexpr int kMbThreads = mb_threads(RT, NCT);
@@ -234,9 +234,14 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     constexpr int NM = SW / 2;     // MFMA k-slices per consumer wave and step (two sample streams)
     constexpr int XS = T + 1;      // u32x2 per plane row (odd: 32 planes x one sample = 32 distinct bank pairs)
     constexpr int WS = T + 1;      // u32x4 per carrier row
-    constexpr int QPR = T / 4;     // 4-sample groups per plane row
+    // one producer "group" = one 16-byte load: GS consecutive complex samples of one plane (planar f32) or of
+    // one antenna (interleaved ComplexF32 / int16 / int8 pairs)
+    constexpr bool PLANAR = FMT == GAT_LAYOUT_PLANAR;
+    constexpr int GS = PLANAR ? 4 : FMT == GAT_LAYOUT_INTERLEAVED ? 2 : FMT == GAT_LAYOUT_INTERLEAVED_I16 ? 4 : 8;
+    constexpr int BYTES = FMT == GAT_LAYOUT_INTERLEAVED_I16 ? 4 : FMT == GAT_LAYOUT_INTERLEAVED_I8 ? 2 : 8; // per complex sample
+    constexpr int QPR = T / GS;    // groups per row
     constexpr int PT = kMbThreads - kThreads; // producer threads (768 or 512)
-    constexpr int NG = RT * 32 * QPR;         // 4-sample groups per step
+    constexpr int NG = (PLANAR ? RT * 32 : RT * 16) * QPR; // groups per step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // Columns are packed flat: column c = 2*L*k + 2*l + comp, a workgroup owns columns [32*NCT*cg, 32*NCT*(cg+1))
     // -- a channel may straddle two tiles (or two workgroups: both generate its carrier), no column is
@@ -311,7 +316,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         __syncthreads();
     }
 
-    const size_t base = (size_t)b * a.block_stride + (size_t)(at * 16 * RT) * a.ant_stride;
+    const size_t base = (size_t)b * a.block_stride + (size_t)(at * 16 * RT) * a.ant_stride; // in (complex) samples
     const int s_begin = split * a.steps_per_split;
     const int s_end = min(s_begin + a.steps_per_split, a.total_steps);
 
@@ -321,8 +326,8 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     // the store): straight-line code, so the compiler's s_waitcnt counts only the loads that matter.
     // (the im plane is addressed as re + im_delta: a lane-dependent choice between the two kernel-argument
     // pointers would be compiled into a per-lane LOAD of the pointer and a wait for it)
-    const long long im_delta = reinterpret_cast<const char *>(a.im) - reinterpret_cast<const char *>(a.re);
-    const char *re_base = reinterpret_cast<const char *>(a.re + base);
+    const long long im_delta = PLANAR ? reinterpret_cast<const char *>(a.im) - reinterpret_cast<const char *>(a.re) : 0ll;
+    const char *re_base = reinterpret_cast<const char *>(a.re) + (PLANAR ? 4ll : (long long)BYTES) * (long long)base;
     // Groups per thread are weighted by role so that all producer waves finish together: the waves that
     // own a carrier / replica item (the first item_waves ones) take few sample groups, the others up to 4.
     const int n_items = nslots * (T / 2);
@@ -341,10 +346,11 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
 #pragma unroll
         for (int it = 0; it < XI; ++it) {
             const int id = g_first + it * g_stride;
-            const int plane = id / QPR, q = id % QPR; // row = 2*m_local + comp
-            const int n = nb + 4 * q;
+            const int row = id / QPR, q = id % QPR; // planar: plane 2*m_local + comp; interleaved: antenna m_local
+            const int n = nb + GS * q;
             const bool ok = id < NG && st < s_end && n < N;
-            const long long off = ((plane & 1) ? im_delta : 0ll) + 4ll * ((long long)(plane >> 1) * a.ant_stride + n);
+            const long long off = PLANAR ? ((row & 1) ? im_delta : 0ll) + 4ll * ((long long)(row >> 1) * a.ant_stride + n)
+                                         : (long long)BYTES * ((long long)row * a.ant_stride + n);
             gload_nt(xv[it], re_base + (ok ? off : 0ll));
         }
     };
@@ -358,13 +364,37 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         for (int it = 0; it < XI; ++it) {
             const int id = g_first + it * g_stride;
             if (id >= NG) continue;
-            const int plane = id / QPR, q = id % QPR;
-            const bool ok = full || nb + 4 * q < N;
-            u32x2 *dst = xb + plane * XS + 4 * q;
+            const int row = id / QPR, q = id % QPR;
+            const bool ok = full || nb + GS * q < N;
+            // {a = hi | mid << 16, b = lo | lo << 16} of one value into the LDS row of its plane
+            auto put = [&](int plane, int rel, float v) {
+                const Split3 sp = split3(ok ? v : 0.f);
+                xb[plane * XS + rel] = u32x2{GAT_PERM(sp.r, sp.v, 0x07060302u), GAT_PERM(sp.r2, sp.r2, 0x03020302u)};
+            };
+            if constexpr (PLANAR) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { // {a = hi | mid << 16, b = lo | lo << 16}
-                const Split3 sp = split3(ok ? xv[it][u] : 0.f);
-                dst[u] = u32x2{GAT_PERM(sp.r, sp.v, 0x07060302u), GAT_PERM(sp.r2, sp.r2, 0x03020302u)};
+                for (int u = 0; u < 4; ++u) put(row, 4 * q + u, xv[it][u]);
+            } else if constexpr (FMT == GAT_LAYOUT_INTERLEAVED) { // (re0, im0, re1, im1)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) put(2 * row + (u & 1), 2 * q + (u >> 1), xv[it][u]);
+            } else if constexpr (FMT == GAT_LAYOUT_INTERLEAVED_I16) { // dword u = sample u: {re: low half, im: high half}
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float f = xv[it][u];
+                    const int w = (int)__float_as_uint(f);
+                    put(2 * row, 4 * q + u, (float)(short)(w & 0xffff));
+                    put(2 * row + 1, 4 * q + u, (float)(w >> 16));
+                }
+            } else { // int8: dword u = samples 2u, 2u+1: bytes (re0, im0, re1, im1)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float f = xv[it][u];
+                    const int w = (int)__float_as_uint(f);
+                    put(2 * row, 8 * q + 2 * u, (float)(signed char)(w & 0xff));
+                    put(2 * row + 1, 8 * q + 2 * u, (float)(signed char)((w >> 8) & 0xff));
+                    put(2 * row, 8 * q + 2 * u + 1, (float)(signed char)((w >> 16) & 0xff));
+                    put(2 * row + 1, 8 * q + 2 * u + 1, (float)(w >> 24));
+                }
             }
         }
     };
@@ -673,16 +703,23 @@ size_t mfma_bf16_lds_bytes(int rt, int nct, int nslots, int rep_stride, int code
            (size_t)((2 * nslots * rep_stride + 3) & ~3) * 4 + (size_t)nslots * code_bits_stride * 4;
 }
 
-hipError_t launch_mfma_bf16(const MfArgs &a, int rt, int nct, unsigned grid, unsigned lds_bytes, hipStream_t s)
+hipError_t launch_mfma_bf16(const MfArgs &a, int rt, int nct, int fmt, unsigned grid, unsigned lds_bytes, hipStream_t s)
 {
     const dim3 g(grid), blk(mb_threads(rt, nct));
-#define GAT_MB(RT_, NCT_) \
-    case RT_ * 8 + NCT_: hipLaunchKernelGGL((mfma_bf16_kernel<RT_, NCT_>), g, blk, lds_bytes, s, a); break;
-    switch (rt * 8 + nct) {
-        GAT_MB(1, 1) GAT_MB(1, 2) GAT_MB(1, 4) GAT_MB(2, 1) GAT_MB(2, 2) GAT_MB(2, 4) GAT_MB(4, 2) GAT_MB(4, 4)
+#define GAT_MB1(RT_, NCT_, F_) \
+    case (F_ * 8 + RT_) * 8 + NCT_: hipLaunchKernelGGL((mfma_bf16_kernel<RT_, NCT_, F_>), g, blk, lds_bytes, s, a); break;
+#define GAT_MB(F_)                                                                                                    \
+    GAT_MB1(1, 1, F_) GAT_MB1(1, 2, F_) GAT_MB1(1, 4, F_) GAT_MB1(2, 1, F_) GAT_MB1(2, 2, F_) GAT_MB1(2, 4, F_) GAT_MB1(4, 2, F_) \
+        GAT_MB1(4, 4, F_)
+    switch ((fmt * 8 + rt) * 8 + nct) {
+        GAT_MB(GAT_LAYOUT_PLANAR)
+        GAT_MB(GAT_LAYOUT_INTERLEAVED)
+        GAT_MB(GAT_LAYOUT_INTERLEAVED_I16)
+        GAT_MB(GAT_LAYOUT_INTERLEAVED_I8)
     default: return hipErrorInvalidValue;
     }
 #undef GAT_MB
+#undef GAT_MB1
     return hipGetLastError();
 }
 

@@ -98,6 +98,46 @@ def test_planner_keeps_vector_kernel_for_other_shapes(g):
         assert info["matrix_core"] == 0, (M, K, L, info)
 
 
+@pytest.mark.parametrize("fmt", ["interleaved", "int16", "int8"])
+@pytest.mark.parametrize("cfg", [("GPSL1", 20000, 16, 3, 4, 2), ("GPSL1", 6000, 64, 3, 7, 1), ("GPSL5", 12000, 32, 5, 3, 1)],
+                         ids=lambda c: f"{c[0]}-N{c[1]}-M{c[2]}-L{c[3]}-K{c[4]}-B{c[5]}")
+def test_split_bf16_ingest_formats(g, cfg, fmt):
+    """The split-bf16 kernel reads interleaved ComplexF32 / int16 / int8 pairs directly (an ADC delivers these; an
+    int8 or int16 sample is exact in one or two bf16 terms): parity with the oracle on the exactly-converted integers
+    and agreement with the vector kernel on the same device buffer."""
+    import torch
+    system, N, M, L, K, B = cfg
+    case = make_case(zlib.crc32(repr((cfg, fmt)).encode()), system=system, N=N, M=M, L=L, K=K, B=B, fs=10e6, if_hz=2e5)
+    if fmt == "interleaved":
+        x = np.stack([case["re"], case["im"]], axis=-1)  # [M, B*N, 2] float32
+    else:
+        dtype, amp = (np.int16, 3000.0 / K) if fmt == "int16" else (np.int8, 25.0 / K)
+        lim = np.iinfo(dtype)
+        q_re = np.clip(np.rint(case["re"] * amp), lim.min, lim.max).astype(dtype)
+        q_im = np.clip(np.rint(case["im"] * amp), lim.min, lim.max).astype(dtype)
+        case["re"], case["im"] = q_re.astype(np.float32), q_im.astype(np.float32)  # what the oracle sees (exact)
+        x = np.stack([q_re, q_im], axis=-1)
+    ref = oracle_result(case)
+    ctx = g.get_context()
+    sysobj = g.GNSSDICT[system](use_gpu=True)
+    p = case["prm"]
+    prm = g.make_params(p["prn0"], p["code_freq_hz"], p["carrier_freq_hz"], p["code_phase_chips"], p["carrier_phase_cycles"])
+    xd = torch.from_numpy(x).to(ctx.device)
+    res = {}
+    try:
+        for mode, kind in ((g.GAT_MC_AUTO, 2), (g.GAT_MC_VECTOR, 0)):
+            ctx.set_matrix_core(mode)
+            op = g.StreamCorrelator(sysobj, N, M, B, K, case["shifts"], case["fs"])
+            op.set_params(prm)
+            op(xd, None)
+            assert ctx.last_launch_info()["matrix_core"] == kind, (mode, ctx.last_launch_info())
+            res[kind] = op.result()
+            check_close(res[kind], ref, what=f"{fmt} {cfg} kernel {kind}")
+    finally:
+        ctx.set_matrix_core(1)
+    assert np.abs(res[2] - res[0]).max() <= 3e-6 * np.abs(ref).max()
+
+
 def test_planner_fallbacks_of_the_split_bf16_kernel(g):
     """Shapes the split-bf16 kernel does not take run on the f32-MFMA or the vector kernel -- same results."""
     # odd sample count: no 16-byte loads -> vector kernel
