@@ -150,7 +150,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
                 const int ns = mfma_bf16_slots(n, L, K);
                 // at most one (slot, sample pair) item per producer thread
                 if (ns * T / 2 > mfma_bf16_threads(rt, n) - kThreads || ns > mfma_bf16_max_slots()) continue;
-                if (mfma_bf16_lds_bytes(rt, n, ns, rs, c->code_bits_stride) <= 160 * 1024) {
+                if (mfma_bf16_lds_bytes(rt, n, fmt, ns, rs, c->code_bits_stride) <= 160 * 1024) {
                     kind = 2;
                     nct_b = n;
                     nslots_b = ns;
@@ -224,7 +224,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
                 m.codes_in_lds = 1; // sign-bit tables, always staged
                 m.code_bits = c->d_code_bits;
                 m.code_bits_stride = c->code_bits_stride;
-                lds = (unsigned)mfma_bf16_lds_bytes(rt, nct, m.nslots, m.rep_stride, c->code_bits_stride);
+                lds = (unsigned)mfma_bf16_lds_bytes(rt, nct, fmt, m.nslots, m.rep_stride, c->code_bits_stride);
                 GAT_HIP(c, launch_mfma_bf16(m, rt, nct, fmt, (unsigned)grid_m, lds, c->stream));
             } else {
                 m.codes_in_lds = mfma_lds_bytes(nct, CT, m.rep_stride, c->code_row_stride, 1) <= 160 * 1024;

@@ -93,7 +93,7 @@ hipError_t launch_mfma(const MfArgs &a, int nct, unsigned grid, unsigned lds_byt
 size_t mfma_lds_bytes(int nct, int ct, int rep_stride, int code_row_stride, int codes_in_lds);
 // split-bf16 matrix-core kernel (gat_mfma_bf16.hip): rt = 16-antenna row tiles per workgroup (1, 2, 4)
 hipError_t launch_mfma_bf16(const MfArgs &a, int rt, int nct, int fmt, unsigned grid, unsigned lds_bytes, hipStream_t s);
-size_t mfma_bf16_lds_bytes(int rt, int nct, int nslots, int rep_stride, int code_bits_stride);
+size_t mfma_bf16_lds_bytes(int rt, int nct, int fmt, int nslots, int rep_stride, int code_bits_stride);
 int mfma_bf16_slots(int nct, int L, int K); // channel slots per workgroup (flat column packing)
 int mfma_bf16_max_slots();
 int mfma_bf16_tile_samples(int rt, int nct);

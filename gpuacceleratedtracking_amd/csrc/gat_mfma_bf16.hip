@@ -118,23 +118,40 @@ __device__ __forceinline__ void wait_loads(f32x4_ (&xv)[XI])
 // slice, 2 slices outstanding).  The X fragment {a, a, a, b} is the fetched {a, b} plus ONE
 // v_pk_mov_b32 for the {a, a} half (plain C++ gets three v_mov per MFMA, on the unit that limits
 // this kernel).
-template <int RT>
+// X1 = true: single-term samples (int8 input is exact in ONE bf16 term): 4 k-slots per sample
+// {x*hi, x*mid, x*lo, 0}, a slice covers 4 samples (two adjacent ones per 32-lane half) -- half the MFMAs, and
+// the fragments come ready-made from LDS: X = {x|x, x|0} per sample, W = {hi|mid, lo|0} per sample, one 16-byte read
+// fetches a sample pair; the chip signs of the two samples come as two mask dwords.
+template <int RT, bool X1>
 struct FragSet {
     u32x4 w;
     unsigned m;
     u32x2 xa[RT];
 };
-template <int J, int RT>
-__device__ __forceinline__ void frag_issue(FragSet<RT> &s, unsigned w_addr, unsigned r_addr, const unsigned (&x_addr)[RT])
+template <int RT>
+struct FragSet<RT, true> {
+    u32x4 w;
+    u32x2 m;
+    u32x4 xa[RT];
+};
+template <int J, int RT, bool X1>
+__device__ __forceinline__ void frag_issue(FragSet<RT, X1> &s, unsigned w_addr, unsigned r_addr, const unsigned (&x_addr)[RT])
 {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(s.w) : "v"(w_addr), "n"(J * 16));
-    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(s.m) : "v"(r_addr), "n"(J * 4));
+    if constexpr (X1) {
+        asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(s.m) : "v"(r_addr), "n"(2 * J), "n"(2 * J + 1));
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(s.xa[t]) : "v"(x_addr[t]), "n"(J * 8));
+        for (int t = 0; t < RT; ++t)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(s.xa[t]) : "v"(x_addr[t]), "n"(J * 16));
+    } else {
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(s.m) : "v"(r_addr), "n"(J * 4));
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(s.xa[t]) : "v"(x_addr[t]), "n"(J * 8));
+    }
 }
-template <int RT, int NEWER> // NEWER: reads issued after this set's that may stay in flight
-__device__ __forceinline__ void frag_wait(FragSet<RT> &s)
+template <int RT, bool X1, int NEWER> // NEWER: reads issued after this set's that may stay in flight
+__device__ __forceinline__ void frag_wait(FragSet<RT, X1> &s)
 {
     static_assert(RT == 1 || RT == 2 || RT == 4, "row tiles");
     static_assert(NEWER <= 15, "lgkmcnt is a 4-bit counter");
@@ -151,55 +168,67 @@ __device__ __forceinline__ void frag_wait(FragSet<RT> &s)
 template <int RT>
 constexpr int frag_depth() { return (15 / (2 + RT)) < 4 ? (15 / (2 + RT)) : 4; }
 
-template <int J, int NM, int RT>
-__device__ __forceinline__ void mfma_slice(f32x16 (&acc)[RT], FragSet<RT> (&fs)[frag_depth<RT>() + 1], unsigned w_addr,
+template <int J, int NM, int RT, bool X1>
+__device__ __forceinline__ void mfma_slice(f32x16 (&acc)[RT], FragSet<RT, X1> (&fs)[frag_depth<RT>() + 1], unsigned w_addr,
                                            unsigned r_addr, const unsigned (&x_addr)[RT])
 {
     constexpr int D = frag_depth<RT>();
-    FragSet<RT> &cur = fs[J % (D + 1)];
+    FragSet<RT, X1> &cur = fs[J % (D + 1)];
     // slices J+1 .. J+D-1 (those that exist) were issued after this one and may stay in flight
     constexpr int newer = (NM - 1 - J) < (D - 1) ? (NM - 1 - J) : (D - 1);
-    frag_wait<RT, newer *(2 + RT)>(cur);
-    if constexpr (J + D < NM) frag_issue<J + D, RT>(fs[(J + D) % (D + 1)], w_addr, r_addr, x_addr);
+    frag_wait<RT, X1, newer *(2 + RT)>(cur);
+    if constexpr (J + D < NM) frag_issue<J + D, RT, X1>(fs[(J + D) % (D + 1)], w_addr, r_addr, x_addr);
     u32x4 w = cur.w;
-    const unsigned mk = cur.m; // chip sign of this column's tap: 0x80008000 or 0
-    w[0] ^= mk;
-    w[1] ^= mk;
-    w[2] ^= mk;
-    w[3] ^= mk;
-    const bf16x8 bw = __builtin_bit_cast(bf16x8, w);
-    // {a, a} halves of the RT fragments.  The trailing s_nop is the VALU-write -> MFMA-read hazard the
-    // compiler would handle itself if it could see inside the asm (it pads its own v_xor the same way).
-    u32x2 aa[RT];
-    if constexpr (RT == 1)
-        asm("v_pk_mov_b32 %0, %1, %1 op_sel:[0,0]\n\ts_nop 1" : "=&v"(aa[0]) : "v"(cur.xa[0]));
-    else if constexpr (RT == 2)
-        asm("v_pk_mov_b32 %0, %2, %2 op_sel:[0,0]\n\tv_pk_mov_b32 %1, %3, %3 op_sel:[0,0]\n\ts_nop 1"
-            : "=&v"(aa[0]), "=&v"(aa[1])
-            : "v"(cur.xa[0]), "v"(cur.xa[1]));
-    else
-        asm("v_pk_mov_b32 %0, %4, %4 op_sel:[0,0]\n\tv_pk_mov_b32 %1, %5, %5 op_sel:[0,0]\n\t"
-            "v_pk_mov_b32 %2, %6, %6 op_sel:[0,0]\n\tv_pk_mov_b32 %3, %7, %7 op_sel:[0,0]\n\ts_nop 1"
-            : "=&v"(aa[0]), "=&v"(aa[1]), "=&v"(aa[2]), "=&v"(aa[3])
-            : "v"(cur.xa[0]), "v"(cur.xa[1]), "v"(cur.xa[2]), "v"(cur.xa[3]));
+    if constexpr (X1) { // chip signs of the lane's two samples
+        const unsigned m0 = cur.m[0], m1 = cur.m[1];
+        w[0] ^= m0;
+        w[1] ^= m0;
+        w[2] ^= m1;
+        w[3] ^= m1;
+        const bf16x8 bw = __builtin_bit_cast(bf16x8, w);
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
-        const unsigned a0 = aa[t][0], a1 = aa[t][1], a2 = cur.xa[t][0], b3 = cur.xa[t][1];
-        const u32x4 af = u32x4{a0, a1, a2, b3};
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), bw, acc[t], 0, 0, 0);
+        for (int t = 0; t < RT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.xa[t]), bw, acc[t], 0, 0, 0);
+    } else {
+        const unsigned mk = cur.m; // chip sign of this column's tap: 0x80008000 or 0
+        w[0] ^= mk;
+        w[1] ^= mk;
+        w[2] ^= mk;
+        w[3] ^= mk;
+        const bf16x8 bw = __builtin_bit_cast(bf16x8, w);
+        // {a, a} halves of the RT fragments.  The trailing s_nop is the VALU-write -> MFMA-read hazard the
+        // compiler would handle itself if it could see inside the asm (it pads its own v_xor the same way).
+        u32x2 aa[RT];
+        if constexpr (RT == 1)
+            asm("v_pk_mov_b32 %0, %1, %1 op_sel:[0,0]\n\ts_nop 1" : "=&v"(aa[0]) : "v"(cur.xa[0]));
+        else if constexpr (RT == 2)
+            asm("v_pk_mov_b32 %0, %2, %2 op_sel:[0,0]\n\tv_pk_mov_b32 %1, %3, %3 op_sel:[0,0]\n\ts_nop 1"
+                : "=&v"(aa[0]), "=&v"(aa[1])
+                : "v"(cur.xa[0]), "v"(cur.xa[1]));
+        else
+            asm("v_pk_mov_b32 %0, %4, %4 op_sel:[0,0]\n\tv_pk_mov_b32 %1, %5, %5 op_sel:[0,0]\n\t"
+                "v_pk_mov_b32 %2, %6, %6 op_sel:[0,0]\n\tv_pk_mov_b32 %3, %7, %7 op_sel:[0,0]\n\ts_nop 1"
+                : "=&v"(aa[0]), "=&v"(aa[1]), "=&v"(aa[2]), "=&v"(aa[3])
+                : "v"(cur.xa[0]), "v"(cur.xa[1]), "v"(cur.xa[2]), "v"(cur.xa[3]));
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const unsigned a0 = aa[t][0], a1 = aa[t][1], a2 = cur.xa[t][0], b3 = cur.xa[t][1];
+            const u32x4 af = u32x4{a0, a1, a2, b3};
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), bw, acc[t], 0, 0, 0);
+        }
     }
 }
-template <int NM, int RT, int... J>
+template <int NM, int RT, bool X1, int... J>
 __device__ __forceinline__ void mfma_step(f32x16 (&acc)[RT], unsigned w_addr, unsigned r_addr, const unsigned (&x_addr)[RT],
                                           std::integer_sequence<int, J...>)
 {
     constexpr int D = frag_depth<RT>();
-    FragSet<RT> fs[D + 1];
-    frag_issue<0, RT>(fs[0], w_addr, r_addr, x_addr);
-    if constexpr (NM > 1 && D > 1) frag_issue<1, RT>(fs[1], w_addr, r_addr, x_addr);
-    if constexpr (NM > 2 && D > 2) frag_issue<2, RT>(fs[2], w_addr, r_addr, x_addr);
-    if constexpr (NM > 3 && D > 3) frag_issue<3, RT>(fs[3], w_addr, r_addr, x_addr);
-    (mfma_slice<J, NM, RT>(acc, fs, w_addr, r_addr, x_addr), ...);
+    FragSet<RT, X1> fs[D + 1];
+    frag_issue<0, RT, X1>(fs[0], w_addr, r_addr, x_addr);
+    if constexpr (NM > 1 && D > 1) frag_issue<1, RT, X1>(fs[1], w_addr, r_addr, x_addr);
+    if constexpr (NM > 2 && D > 2) frag_issue<2, RT, X1>(fs[2], w_addr, r_addr, x_addr);
+    if constexpr (NM > 3 && D > 3) frag_issue<3, RT, X1>(fs[3], w_addr, r_addr, x_addr);
+    (mfma_slice<J, NM, RT, X1>(acc, fs, w_addr, r_addr, x_addr), ...);
 }
 
 struct ChanInfoB { // per channel slot of the workgroup, in LDS
@@ -231,9 +260,14 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     constexpr int T = tile_samples(RT, NCT);
     constexpr int WPT = 4 / NCT;   // consumer waves per channel tile (they split the step's samples)
     constexpr int SW = T / WPT;    // samples per consumer wave and step
-    constexpr int NM = SW / 2;     // MFMA k-slices per consumer wave and step (two sample streams)
-    constexpr int XS = T + 1;      // u32x2 per plane row (odd: 32 planes x one sample = 32 distinct bank pairs)
-    constexpr int WS = T + 1;      // u32x4 per carrier row
+    constexpr bool X1 = FMT == GAT_LAYOUT_INTERLEAVED_I8; // samples exact in one bf16 term: 4 samples per MFMA
+    constexpr int SPS = X1 ? 4 : 2; // samples per k-slice
+    constexpr int NM = SW / SPS;   // MFMA k-slices per consumer wave and step (two sample streams)
+    // LDS row strides in entries.  3-term: X 8 B / W 16 B per sample, odd (32 planes x one sample = 32 distinct
+    // bank pairs).  1-term: X 8 B / W 8 B per sample, read in 16-byte pairs: even, rows 4 banks apart.
+    constexpr int XS = X1 ? T + 2 : T + 1;
+    constexpr int WS = X1 ? T + 2 : T + 1;
+    constexpr int WE = X1 ? 1 : 2; // u32x2 units per W entry
     // one producer "group" = one 16-byte load: GS consecutive complex samples of one plane (planar f32) or of
     // one antenna (interleaved ComplexF32 / int16 / int8 pairs)
     constexpr bool PLANAR = FMT == GAT_LAYOUT_PLANAR;
@@ -253,8 +287,8 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     const int RS = a.rep_stride;
     ChanInfoB *s_chan = reinterpret_cast<ChanInfoB *>(smem);
     u32x2 *s_x = reinterpret_cast<u32x2 *>(smem + kHeader);                 // [2][RT*32][XS]
-    u32x4 *s_w = reinterpret_cast<u32x4 *>(s_x + 2 * RT * 32 * XS);         // [2][wrows][WS]
-    unsigned *s_rep = reinterpret_cast<unsigned *>(s_w + 2 * wrows * WS);   // [2][nslots][RS]
+    u32x2 *s_w = s_x + 2 * RT * 32 * XS;                                    // [2][wrows][WS] entries of WE u32x2
+    unsigned *s_rep = reinterpret_cast<unsigned *>(s_w + 2 * wrows * WS * WE); // [2][nslots][RS]
     unsigned *s_code = s_rep + ((2 * nslots * RS + 3) & ~3); // [nslots][code_bits_stride] sign-bit tables
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -300,8 +334,8 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         s_chan[tid] = ci;
     }
     // the zero rows of both carrier buffers (read by dead columns, never written again)
-    for (int e = tid; e < 2 * WS; e += kMbThreads)
-        s_w[(e / WS) * wrows * WS + 2 * nslots * WS + e % WS] = u32x4{0u, 0u, 0u, 0u};
+    for (int e = tid; e < 2 * WS * WE; e += kMbThreads)
+        s_w[((e / (WS * WE)) * wrows * WS + 2 * nslots * WS) * WE + e % (WS * WE)] = u32x2{0u, 0u};
     __syncthreads();
     { // sign-bit tables of this workgroup's channels (the producers must not touch global memory for chips:
       // vector-memory returns are in order, a table gather would wait for the sample prefetch in flight)
@@ -368,8 +402,13 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
             const bool ok = full || nb + GS * q < N;
             // {a = hi | mid << 16, b = lo | lo << 16} of one value into the LDS row of its plane
             auto put = [&](int plane, int rel, float v) {
-                const Split3 sp = split3(ok ? v : 0.f);
-                xb[plane * XS + rel] = u32x2{GAT_PERM(sp.r, sp.v, 0x07060302u), GAT_PERM(sp.r2, sp.r2, 0x03020302u)};
+                if constexpr (X1) { // an int8 value is exact in bf16: {x|x, x|0}
+                    const unsigned fb = __float_as_uint(ok ? v : 0.f);
+                    xb[plane * XS + rel] = u32x2{GAT_PERM(fb, fb, 0x03020302u), fb >> 16};
+                } else {
+                    const Split3 sp = split3(ok ? v : 0.f);
+                    xb[plane * XS + rel] = u32x2{GAT_PERM(sp.r, sp.v, 0x07060302u), GAT_PERM(sp.r2, sp.r2, 0x03020302u)};
+                }
             };
             if constexpr (PLANAR) {
 #pragma unroll
@@ -440,7 +479,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     const bool have_item = producer && item_slot < nslots;
     auto produce = [&](int st, int buf, bool first) { // everything of step st except the samples
         const int nb = st * T;
-        u32x4 *wb = s_w + buf * wrows * WS;
+        u32x2 *wb = s_w + buf * wrows * WS * WE;
         unsigned *rb = s_rep + buf * nslots * RS;
         const unsigned *rprev = s_rep + (buf ^ 1) * nslots * RS;
         if (first) { // entries [0, span): ceil(span / 2) pairs per slot
@@ -473,17 +512,22 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         }
         car_r = cr;
         car_i = ci;
-        u32x4 *w_re = wb + (2 * item_slot) * WS + 2 * item_q;
-        u32x4 *w_im = w_re + WS;
+        u32x2 *w_re = wb + ((2 * item_slot) * WS + 2 * item_q) * WE;
+        u32x2 *w_im = w_re + WS * WE;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const Split3 sc = split3(cr), ss = split3(-ci); // w_re = chip * cos, w_im = -chip * sin (conjugate)
-            const unsigned c_hh = GAT_PERM(sc.v, sc.v, 0x03020302u), c_mm = GAT_PERM(sc.r, sc.r, 0x03020302u),
-                           c_ll = GAT_PERM(sc.r2, sc.r2, 0x03020302u), c_hm = GAT_PERM(sc.r, sc.v, 0x07060302u);
-            const unsigned s_hh = GAT_PERM(ss.v, ss.v, 0x03020302u), s_mm = GAT_PERM(ss.r, ss.r, 0x03020302u),
-                           s_ll = GAT_PERM(ss.r2, ss.r2, 0x03020302u), s_hm = GAT_PERM(ss.r, ss.v, 0x07060302u);
-            w_re[u] = u32x4{c_hh, c_mm, c_ll, c_hm};
-            w_im[u] = u32x4{s_hh, s_mm, s_ll, s_hm};
+            if constexpr (X1) { // {hi|mid, lo|0}
+                w_re[u] = u32x2{GAT_PERM(sc.r, sc.v, 0x07060302u), sc.r2 >> 16};
+                w_im[u] = u32x2{GAT_PERM(ss.r, ss.v, 0x07060302u), ss.r2 >> 16};
+            } else { // {hh, mm, ll, hm}
+                const unsigned c_hh = GAT_PERM(sc.v, sc.v, 0x03020302u), c_mm = GAT_PERM(sc.r, sc.r, 0x03020302u),
+                               c_ll = GAT_PERM(sc.r2, sc.r2, 0x03020302u), c_hm = GAT_PERM(sc.r, sc.v, 0x07060302u);
+                const unsigned s_hh = GAT_PERM(ss.v, ss.v, 0x03020302u), s_mm = GAT_PERM(ss.r, ss.r, 0x03020302u),
+                               s_ll = GAT_PERM(ss.r2, ss.r2, 0x03020302u), s_hm = GAT_PERM(ss.r, ss.v, 0x07060302u);
+                *reinterpret_cast<u32x4 *>(w_re + 2 * u) = u32x4{c_hh, c_mm, c_ll, c_hm};
+                *reinterpret_cast<u32x4 *>(w_im + 2 * u) = u32x4{s_hh, s_mm, s_ll, s_hm};
+            }
             if (u == 0) {
                 const float tr = __builtin_fmaf(cr, c.wr, -(ci * c.wi));
                 ci = __builtin_fmaf(cr, c.wi, ci * c.wr);
@@ -504,7 +548,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     const int slot_c = in_range ? k_col - k_first : 0;
     const ChanInfoB my = s_chan[slot_c];
     const bool live_col = in_range && my.valid;
-    const int col0 = sub * SW + h * NM; // first sample (step-relative) of this lane's stream
+    const int col0 = sub * SW + h * (SW / 2); // first sample (step-relative) of this lane's stream
     const int w_off = (live_col ? 2 * slot_c + comp : 2 * nslots) * WS + col0;
     const int r_off = slot_c * RS + (a.shifts[l] - a.shifts[0]) + col0;
     const int x_off = r * XS + col0;
@@ -524,9 +568,9 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         unsigned x_addr[RT];
 #pragma unroll
         for (int t = 0; t < RT; ++t) x_addr[t] = lds_x + 8u * (unsigned)((buf * RT * 32 + t * 32) * XS + x_off);
-        const unsigned w_addr = lds_w + 16u * (unsigned)(buf * wrows * WS + w_off);
+        const unsigned w_addr = lds_w + 8u * WE * (unsigned)(buf * wrows * WS + w_off);
         const unsigned r_addr = lds_r + 4u * (unsigned)(buf * nslots * RS + r_off);
-        mfma_step<NM, RT>(acc, w_addr, r_addr, x_addr, std::make_integer_sequence<int, NM>{});
+        mfma_step<NM, RT, X1>(acc, w_addr, r_addr, x_addr, std::make_integer_sequence<int, NM>{});
     };
 
     // ---- pipeline ----------------------------------------------------------------------------------
@@ -695,11 +739,13 @@ int mfma_bf16_slots(int nct, int L, int K)
     return s < K ? s : K;
 }
 
-size_t mfma_bf16_lds_bytes(int rt, int nct, int nslots, int rep_stride, int code_bits_stride)
+size_t mfma_bf16_lds_bytes(int rt, int nct, int fmt, int nslots, int rep_stride, int code_bits_stride)
 {
+    const bool x1 = fmt == GAT_LAYOUT_INTERLEAVED_I8;
     static_assert(sizeof(ChanInfoB) * kMbMaxSlots <= kHeader, "channel table must fit the header");
     const int T = tile_samples(rt, nct);
-    return (size_t)kHeader + (size_t)2 * rt * 32 * (T + 1) * 8 + (size_t)2 * (2 * nslots + 1) * (T + 1) * 16 +
+    const int xs = x1 ? T + 2 : T + 1, wbytes = x1 ? 8 : 16;
+    return (size_t)kHeader + (size_t)2 * rt * 32 * xs * 8 + (size_t)2 * (2 * nslots + 1) * xs * wbytes +
            (size_t)((2 * nslots * rep_stride + 3) & ~3) * 4 + (size_t)nslots * code_bits_stride * 4;
 }
 
