@@ -11,7 +11,8 @@ SHAPES = [  # N, M, L, K, B, block_seconds
     (400000, 64, 3, 64, 2, 4e-3),      # C5-like (shorter)
 ]
 for N, M, L, K, B, bs in SHAPES:
-    op, desc, sig, prm = g.build_stream("GPSL1", N, M, L, K, B, block_seconds=bs)
+    layout = {"planar": 0, "interleaved": 1, "i16": 2, "i8": 3}[os.environ.get("GAT_STAMP_LAYOUT", "planar")]
+    op, desc, sig, prm = g.build_stream("GPSL1", N, M, L, K, B, block_seconds=bs, layout=layout)
     ctx = op.ctx
     ctx.set_matrix_core(3)
     for _ in range(2): op.launch(desc)
