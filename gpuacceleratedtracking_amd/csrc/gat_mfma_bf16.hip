@@ -169,7 +169,7 @@ template <int RT>
 constexpr int frag_depth() { return (15 / (2 + RT)) < 4 ? (15 / (2 + RT)) : 4; }
 
 template <int J, int NM, int RT, bool X1>
-__device__ __forceinline__ void mfma_slice(f32x16 (&acc)[RT], FragSet<RT, X1> (&fs)[frag_depth<RT>() + 1], unsigned w_addr,
+__device__ __forceinline__ void mfma_slice(f32x16 (&acc)[RT == 1 ? 2 : RT], FragSet<RT, X1> (&fs)[frag_depth<RT>() + 1], unsigned w_addr,
                                            unsigned r_addr, const unsigned (&x_addr)[RT])
 {
     constexpr int D = frag_depth<RT>();
@@ -188,7 +188,8 @@ __device__ __forceinline__ void mfma_slice(f32x16 (&acc)[RT], FragSet<RT, X1> (&
         const bf16x8 bw = __builtin_bit_cast(bf16x8, w);
 #pragma unroll
         for (int t = 0; t < RT; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.xa[t]), bw, acc[t], 0, 0, 0);
+            acc[RT == 1 ? (J & 1) : t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.xa[t]), bw,
+                                                                             acc[RT == 1 ? (J & 1) : t], 0, 0, 0);
     } else {
         const unsigned mk = cur.m; // chip sign of this column's tap: 0x80008000 or 0
         w[0] ^= mk;
@@ -214,12 +215,15 @@ __device__ __forceinline__ void mfma_slice(f32x16 (&acc)[RT], FragSet<RT, X1> (&
         for (int t = 0; t < RT; ++t) {
             const unsigned a0 = aa[t][0], a1 = aa[t][1], a2 = cur.xa[t][0], b3 = cur.xa[t][1];
             const u32x4 af = u32x4{a0, a1, a2, b3};
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), bw, acc[t], 0, 0, 0);
+            // (one row tile: two accumulators take the slices in turn -- a dependent chain of this MFMA issues
+            // every 52 cycles, independent ones every 32: scripts/mfma_bf16_probe.hip)
+            acc[RT == 1 ? (J & 1) : t] =
+                __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), bw, acc[RT == 1 ? (J & 1) : t], 0, 0, 0);
         }
     }
 }
 template <int NM, int RT, bool X1, int... J>
-__device__ __forceinline__ void mfma_step(f32x16 (&acc)[RT], unsigned w_addr, unsigned r_addr, const unsigned (&x_addr)[RT],
+__device__ __forceinline__ void mfma_step(f32x16 (&acc)[RT == 1 ? 2 : RT], unsigned w_addr, unsigned r_addr, const unsigned (&x_addr)[RT],
                                           std::integer_sequence<int, J...>)
 {
     constexpr int D = frag_depth<RT>();
@@ -385,12 +389,21 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
             const bool ok = id < NG && st < s_end && n < N;
             const long long off = PLANAR ? ((row & 1) ? im_delta : 0ll) + 4ll * ((long long)(row >> 1) * a.ant_stride + n)
                                          : (long long)BYTES * ((long long)row * a.ant_stride + n);
+#if defined(GAT_ABLATE) && (GAT_ABLATE & 16) // diagnostic: no sample loads at all
+            (void)ok; (void)off; xv[it] = f32x4_{1.f, 1.f, 1.f, 1.f};
+#else
             gload_nt(xv[it], re_base + (ok ? off : 0ll));
+#endif
         }
     };
     auto store_x = [&](auto &xv, int st, int buf) {
         constexpr int XI = sizeof(xv) / sizeof(xv[0]);
+#if !(defined(GAT_ABLATE) && (GAT_ABLATE & 16))
         wait_loads<XI>(xv);
+#endif
+#if defined(GAT_ABLATE) && (GAT_ABLATE & 4) // diagnostic: samples are split / stored only for the first two steps
+        if (st >= s_begin + 2) return;
+#endif
         const int nb = st * T;
         u32x2 *xb = s_x + buf * RT * 32 * XS;
         const bool full = nb + T <= N; // wave-uniform: only a block's last step can be ragged
@@ -500,8 +513,14 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         const ChanInfoB c = s_chan[item_slot];
         if (!c.valid) return;
         const bool anchor = first || ((st - s_begin) % kReanchor) == 0; // wave-uniform
+#if defined(GAT_ABLATE) && (GAT_ABLATE & 1) // diagnostic builds (scripts/ablate_mfma_bf16.sh; results wrong on purpose): no replica
+        if (first)
+#endif
         gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, nb, span + 2 * item_q, span + T,
                  anchor || !c.inc_ok, rep_ip, rep_t);
+#if defined(GAT_ABLATE) && (GAT_ABLATE & 2) // diagnostic: carrier fragments only in the first step
+        if (!first) return;
+#endif
         float cr, ci;
         if (anchor) {
             const double th = __builtin_fma((double)(nb + 2 * item_q), c.step, c.phi);
@@ -556,15 +575,19 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     // the consumers' few vector instructions per slice must not queue behind the producers' streams
     if (!producer) __builtin_amdgcn_s_setprio(3);
 
-    f32x16 acc[RT];
+    constexpr int NA = RT == 1 ? 2 : RT; // accumulators (one row tile: two, summed at the end)
+    f32x16 acc[NA];
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
+    for (int t = 0; t < NA; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
     // LDS byte addresses of this lane's streams (the low 32 bits of a flat LDS address are the LDS offset)
     const unsigned lds_x = (unsigned)(uintptr_t)s_x, lds_w = (unsigned)(uintptr_t)s_w, lds_r = (unsigned)(uintptr_t)s_rep;
     auto consume = [&](int buf) {
+#if defined(GAT_ABLATE) && (GAT_ABLATE & 8) // diagnostic: no MFMA work
+        return;
+#endif
         unsigned x_addr[RT];
 #pragma unroll
         for (int t = 0; t < RT; ++t) x_addr[t] = lds_x + 8u * (unsigned)((buf * RT * 32 + t * 32) * XS + x_off);
@@ -674,6 +697,8 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         d[0] = t_work; d[1] = t_wait; d[2] = t_gen; d[3] = t_st;
     }
 #endif
+
+    if constexpr (RT == 1) acc[0] += acc[1];
 
     // ---- epilogue ------------------------------------------------------------------------------------
     if constexpr (WPT > 1) { // sum the consumer waves that shared a channel tile (the x staging area is free now)
