@@ -24,6 +24,7 @@ struct gat_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int8_t *d_codes = nullptr;
+    void *d_zeros = nullptr;         // 64 zero bytes (out-of-range sample loads of the split-bf16 kernel read these)
     uint32_t *d_code_bits = nullptr; // bit i of row p = (chip i of PRN p is -1); only when every chip is +-1
     int code_bits_stride = 0;        // dwords per row, a multiple of 4
     int Lc = 0, P = 0, code_row_stride = 0; // rows padded to a multiple of 16 bytes
@@ -139,7 +140,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         // kernel choice: 3 / 1 (auto) -> split-bf16 when its tile fits in LDS, 2 -> f32 MFMA
         int kind = 0, rt = 1, rep_stride_m = 0;
         int nslots_b = 0, tiles_b = 0, nct_b = 1;
-        if (shape_any && c->mc_mode != 2 && c->d_code_bits && N % spv == 0 && spv <= 8) {
+        if (shape_any && c->mc_mode != 2 && c->d_code_bits && c->d_zeros && N % spv == 0 && spv <= 8) {
             // split-bf16 kernel: columns packed flat (2 L per channel), 32 per tile
             tiles_b = (2 * L * K + 31) / 32;
             const int rt_max = (M / 16) % 4 == 0 ? 4 : ((M / 16) % 2 == 0 ? 2 : 1);
@@ -223,6 +224,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             if (kind == 2) {
                 m.codes_in_lds = 1; // sign-bit tables, always staged
                 m.code_bits = c->d_code_bits;
+                m.zeros = c->d_zeros;
                 m.code_bits_stride = c->code_bits_stride;
                 lds = (unsigned)mfma_bf16_lds_bytes(rt, nct, fmt, m.nslots, m.rep_stride, c->code_bits_stride);
                 GAT_HIP(c, launch_mfma_bf16(m, rt, nct, fmt, (unsigned)grid_m, lds, c->stream));
@@ -379,6 +381,7 @@ GAT_API int32_t gat_create(int32_t device, void *hip_stream, gat_ctx **out_ctx)
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    if (hipMalloc(&c->d_zeros, 64) == hipSuccess) (void)hipMemset(c->d_zeros, 0, 64);
     if (const char *e = std::getenv("GAT_NO_MFMA")) c->mc_mode = e[0] == '1' ? 0 : 1;
     if (const char *e = std::getenv("GAT_MAX_ANT_TILE")) c->max_ant_tile = std::min(kMaxAntTile, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("GAT_MC_MODE")) c->mc_mode = (e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
@@ -397,6 +400,7 @@ GAT_API int32_t gat_destroy(gat_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     if (c->d_codes) (void)hipFree(c->d_codes);
     if (c->d_code_bits) (void)hipFree(c->d_code_bits);
+    if (c->d_zeros) (void)hipFree(c->d_zeros);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->ev0) (void)hipEventDestroy(c->ev0);

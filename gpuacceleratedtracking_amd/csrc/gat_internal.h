@@ -70,6 +70,7 @@ struct MfArgs {
     const gat_channel_params *params;
     const int8_t *codes;
     const uint32_t *code_bits; // split-bf16 kernel: sign-bit tables [P][code_bits_stride]
+    const void *zeros;         // split-bf16 kernel: 16 zero bytes (target of out-of-range sample loads)
     float *out_re;
     float *out_im;
     float *partial;

@@ -360,8 +360,8 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
 
     // ---- producers ---------------------------------------------------------------------------------
     // Sample loads run two steps ahead of the split/store (xvA / xvB alternate).  Every load is an
-    // unconditional 16-byte load (out-of-range groups read the tile's first group and are zeroed at
-    // the store): straight-line code, so the compiler's s_waitcnt counts only the loads that matter.
+    // unconditional 16-byte load (out-of-range groups read 16 zero bytes the context keeps for this):
+    // straight-line code, no selects, and the compiler's s_waitcnt counts only the loads that matter.
     // (the im plane is addressed as re + im_delta: a lane-dependent choice between the two kernel-argument
     // pointers would be compiled into a per-lane LOAD of the pointer and a wait for it)
     const long long im_delta = PLANAR ? reinterpret_cast<const char *>(a.im) - reinterpret_cast<const char *>(a.re) : 0ll;
@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
 #if defined(GAT_ABLATE) && (GAT_ABLATE & 16) // diagnostic: no sample loads at all
             (void)ok; (void)off; xv[it] = f32x4_{1.f, 1.f, 1.f, 1.f};
 #else
-            gload_nt(xv[it], re_base + (ok ? off : 0ll));
+            gload_nt(xv[it], ok ? re_base + off : reinterpret_cast<const char *>(a.zeros));
 #endif
         }
     };
@@ -406,20 +406,18 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
 #endif
         const int nb = st * T;
         u32x2 *xb = s_x + buf * RT * 32 * XS;
-        const bool full = nb + T <= N; // wave-uniform: only a block's last step can be ragged
 #pragma unroll
         for (int it = 0; it < XI; ++it) {
             const int id = g_first + it * g_stride;
             if (id >= NG) continue;
             const int row = id / QPR, q = id % QPR;
-            const bool ok = full || nb + GS * q < N;
             // {a = hi | mid << 16, b = lo | lo << 16} of one value into the LDS row of its plane
             auto put = [&](int plane, int rel, float v) {
                 if constexpr (X1) { // an int8 value is exact in bf16: {x|x, x|0}
-                    const unsigned fb = __float_as_uint(ok ? v : 0.f);
+                    const unsigned fb = __float_as_uint(v);
                     xb[plane * XS + rel] = u32x2{GAT_PERM(fb, fb, 0x03020302u), fb >> 16};
                 } else {
-                    const Split3 sp = split3(ok ? v : 0.f);
+                    const Split3 sp = split3(v);
                     xb[plane * XS + rel] = u32x2{GAT_PERM(sp.r, sp.v, 0x07060302u), GAT_PERM(sp.r2, sp.r2, 0x03020302u)};
                 }
             };
