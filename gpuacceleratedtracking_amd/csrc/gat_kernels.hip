@@ -346,29 +346,13 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
         }
     };
     // this step's replica segment: entry i <-> sample c*CHUNK + shift0 + i (src/algorithms.jl:753-757)
-    // A lane generates E consecutive entries: every code phase is the reference's FP64 expression
-    // (unfused), but only the first needs the full floored modulo -- the others follow from the exact
-    // floor differences (chips advance monotonically; bad channels have ratio = 0 here).
-    const int rep_e = (rep_cnt + kThreads - 1) / kThreads;
     auto fill_replica = [&](float *rep, int c) {
         const int x0 = c * CHUNK + shift0;
-        const int i0 = tid * rep_e;
-        if (i0 >= rep_cnt) return;
-        const int i1 = min(i0 + rep_e, rep_cnt);
-        int ip_prev = (int)__builtin_floor(__dadd_rn(__dmul_rn(ratio, (double)(x0 + i0)), tau));
-        int idx = floormod_fast(ip_prev, Lc, inv_lc);
-        rep[(i0 & 3) * rep_ps + (i0 >> 2)] = (float)s_code[idx];
-        // not unrolled on purpose: the FP64 temporaries of unrolled iterations cost VGPRs, i.e. occupancy
+        // not unrolled on purpose: the FP64 temporaries of 4-5 unrolled iterations cost ~30 VGPRs,
+        // i.e. one wave per SIMD of occupancy, and this loop runs in the shadow of the sample loads
 #pragma unroll 1
-        for (int i = i0 + 1; i < i1; ++i) {
-            const int ip = (int)__builtin_floor(__dadd_rn(__dmul_rn(ratio, (double)(x0 + i)), tau));
-            const int adv = ip - ip_prev; // >= 0: ratio >= 0 and FP64 rounding is monotonic
-            ip_prev = ip;
-            idx += adv;
-            idx -= (idx >= Lc) ? Lc : 0;
-            if (adv >= Lc) idx = floormod_fast(ip, Lc, inv_lc); // more than a code period per sample
-            rep[(i & 3) * rep_ps + (i >> 2)] = (float)s_code[idx];
-        }
+        for (int i = tid; i < rep_cnt; i += kThreads)
+            rep[(i & 3) * rep_ps + (i >> 2)] = (float)s_code[chip_index(ratio, tau, x0 + i, Lc, inv_lc)];
     };
 
     for (int c = c_begin; c < c_end; ++c) {
