@@ -23,6 +23,10 @@ const GAT_OK = Int32(0)
 const GAT_FLAG_ATOMIC = UInt32(1)
 const GAT_LAYOUT_PLANAR = Int32(0)
 const GAT_LAYOUT_INTERLEAVED = Int32(1)
+const GAT_LAYOUT_INTERLEAVED_I16 = Int32(2)
+const GAT_LAYOUT_INTERLEAVED_I8 = Int32(3)
+# kernel selection (gat_set_matrix_core): vector kernel / automatic / f32 MFMA / split-bf16 MFMA
+const GAT_MC_VECTOR, GAT_MC_AUTO, GAT_MC_F32, GAT_MC_BF16_SPLIT = Int32(0), Int32(1), Int32(2), Int32(3)
 
 # struct gat_channel_params (40 bytes)
 struct ChannelParams
@@ -70,6 +74,8 @@ function check(ctx::Context, rc::Int32)
 end
 
 sync(ctx::Context) = check(ctx, ccall((:gat_sync, libgat), Int32, (Ptr{Cvoid},), ctx.handle))
+set_matrix_core(ctx::Context, mode::Integer) =
+    check(ctx, ccall((:gat_set_matrix_core, libgat), Int32, (Ptr{Cvoid}, Int32), ctx.handle, Int32(mode)))
 
 # ---- device memory (for hosts without AMDGPU.jl; with AMDGPU.jl pass ROCArray pointers instead)
 function dmalloc(ctx::Context, bytes::Integer)
