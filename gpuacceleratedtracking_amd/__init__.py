@@ -6,7 +6,7 @@ compute runs in libgat.so (hand-written HIP for gfx950) through the C ABI of inc
 Importing this package never touches the test oracle and there is no CPU fallback: without the
 HIP library / a HIP device the operators raise.
 """
-from ._lib import GAT_MC_AUTO, GAT_MC_BF16_SPLIT, GAT_MC_F32, GAT_MC_VECTOR  # noqa: F401
+from ._lib import GAT_FLAG_GRAPH, GAT_MC_AUTO, GAT_MC_BF16_SPLIT, GAT_MC_F32, GAT_MC_VECTOR  # noqa: F401
 from ._lib import (GAT_FLAG_ATOMIC, GAT_LAYOUT_INTERLEAVED, GAT_LAYOUT_INTERLEAVED_I8,  # noqa: F401
                    GAT_LAYOUT_INTERLEAVED_I16, GAT_LAYOUT_PLANAR, SAMPLE_BYTES, GatError,
                    library_path, load as load_library)

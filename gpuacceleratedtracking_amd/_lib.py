@@ -13,6 +13,7 @@ from . import build as _build
 
 GAT_OK = 0
 GAT_FLAG_ATOMIC = 1
+GAT_FLAG_GRAPH = 2
 GAT_LAYOUT_PLANAR = 0
 GAT_LAYOUT_INTERLEAVED = 1
 GAT_LAYOUT_INTERLEAVED_I16 = 2
@@ -29,7 +30,7 @@ EXPORTS = [
     "gat_downconvert_and_correlate", "gat_downconvert_and_correlate_dev", "gat_gen_code_replica",
     "gat_gen_code_replica_f32coord",
     "gat_gen_signal", "gat_reduce_cplx_multi", "gat_tracking_update", "gat_malloc", "gat_free", "gat_memcpy_h2d",
-    "gat_memcpy_d2h", "gat_memset", "gat_timer_start", "gat_timer_stop", "gat_last_launch_info", "gat_set_matrix_core",
+    "gat_memcpy_d2h", "gat_memset", "gat_timer_start", "gat_timer_stop", "gat_last_launch_info", "gat_set_matrix_core", "gat_tracking_run",
 ]
 
 
@@ -129,6 +130,8 @@ def load(build_if_missing: bool = True):
         "gat_gen_signal": (i32, [vp, vp, vp, i32, i64, i32, i64, i64, i32, i32, vp, dbl, dbl]),
         "gat_reduce_cplx_multi": (i32, [vp, vp, vp, i64, i32, vp, vp]),
         "gat_tracking_update": (i32, [vp, vp, vp, i32, i32, C.POINTER(LoopConfig), vp, vp, vp]),
+        "gat_tracking_run": (i32, [vp, C.POINTER(SignalDesc), i32, i32, i32, C.POINTER(C.c_int32), dbl,
+                                   C.POINTER(LoopConfig), vp, vp, vp, vp, vp, i64, C.c_uint32, C.POINTER(C.c_int32)]),
         "gat_malloc": (i32, [vp, C.c_size_t, C.POINTER(vp)]),
         "gat_free": (i32, [vp, vp]),
         "gat_memcpy_h2d": (i32, [vp, vp, vp, C.c_size_t]),

@@ -24,6 +24,10 @@ struct gat_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int8_t *d_codes = nullptr;
+    // gat_tracking_run with GAT_FLAG_GRAPH: the launch sequence of the last such call, instantiated (replayed when the
+    // next call has the same arguments: a receiver cycling through one ring buffer)
+    hipGraphExec_t loop_graph = nullptr;
+    std::vector<unsigned char> loop_graph_key;
     void *d_zeros = nullptr;         // 64 zero bytes (out-of-range sample loads of the split-bf16 kernel read these)
     uint32_t *d_code_bits = nullptr; // bit i of row p = (chip i of PRN p is -1); only when every chip is +-1
     int code_bits_stride = 0;        // dwords per row, a multiple of 4
@@ -351,6 +355,41 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
 
 } // namespace
 
+namespace {
+
+int32_t tracking_run_enqueue(gat_ctx *c, const gat_signal_desc *sig, int32_t num_blocks, int32_t K, int32_t L,
+                             const int32_t *shifts, double fs, const gat_loop_config *cfg, gat_loop_state *state,
+                             gat_channel_params *params_a, gat_channel_params *params_b, float *acc_re, float *acc_im,
+                             int64_t acc_block_stride, uint32_t flags, int32_t *current_is_b)
+{
+    const size_t sample_bytes = sig->layout == GAT_LAYOUT_PLANAR ? 4 : sig->layout == GAT_LAYOUT_INTERLEAVED ? 8
+                              : sig->layout == GAT_LAYOUT_INTERLEAVED_I16 ? 4 : 2;
+    gat_channel_params *cur = params_a, *nxt = params_b;
+    for (int32_t b = 0; b < num_blocks; ++b) { // everything is enqueued on the ctx stream, nothing synchronises
+        gat_signal_desc d = *sig;
+        const size_t off = (size_t)b * (size_t)sig->block_stride * sample_bytes;
+        d.re = static_cast<const char *>(sig->re) + off;
+        if (sig->im) d.im = static_cast<const char *>(sig->im) + off;
+        float *o_re = acc_re + (size_t)b * (size_t)acc_block_stride, *o_im = acc_im + (size_t)b * (size_t)acc_block_stride;
+        int32_t rc = correlate_impl(c, &d, cur, 1, K, L, shifts, fs, o_re, o_im, flags);
+        if (rc != GAT_OK) return rc;
+        rc = gat_tracking_update(c, o_re, o_im, K, sig->num_ants, cfg, state, cur, nxt);
+        if (rc != GAT_OK) return rc;
+        std::swap(cur, nxt);
+    }
+    if (current_is_b) *current_is_b = cur == params_b ? 1 : 0;
+    return GAT_OK;
+}
+
+template <typename T>
+void key_put(std::vector<unsigned char> &k, const T &v)
+{
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(&v);
+    k.insert(k.end(), p, p + sizeof(T));
+}
+
+} // namespace
+
 extern "C" {
 
 GAT_API const char *gat_version(void) { return "libgat 0.1.0 (gfx950)"; }
@@ -401,6 +440,7 @@ GAT_API int32_t gat_destroy(gat_ctx *c)
     if (c->d_codes) (void)hipFree(c->d_codes);
     if (c->d_code_bits) (void)hipFree(c->d_code_bits);
     if (c->d_zeros) (void)hipFree(c->d_zeros);
+    if (c->loop_graph) (void)hipGraphExecDestroy(c->loop_graph);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -630,6 +670,58 @@ GAT_API int32_t gat_tracking_update(gat_ctx *c, const float *acc_re, const float
         return fail(c, GAT_ERR_ARG, "bad loop configuration");
     GAT_HIP(c, hipSetDevice(c->device));
     GAT_HIP(c, launch_tracking_update(acc_re, acc_im, K, M, *cfg, state, cur, next, c->stream));
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_tracking_run(gat_ctx *c, const gat_signal_desc *sig, int32_t num_blocks, int32_t K, int32_t L,
+                                 const int32_t *shifts, double fs, const gat_loop_config *cfg, gat_loop_state *state,
+                                 gat_channel_params *params_a, gat_channel_params *params_b, float *acc_re,
+                                 float *acc_im, int64_t acc_block_stride, uint32_t flags, int32_t *current_is_b)
+{
+    if (!c || !sig || !shifts || !cfg || !state || !params_a || !params_b || !acc_re || !acc_im)
+        return fail(c, GAT_ERR_ARG, "null argument");
+    if (num_blocks < 1 || acc_block_stride < 0) return fail(c, GAT_ERR_ARG, "bad block count / stride");
+    if (cfg->num_taps != L || L < 1 || L > GAT_MAX_TAPS) return fail(c, GAT_ERR_ARG, "loop configuration and tap list disagree");
+    if (flags & ~(GAT_FLAG_ATOMIC | GAT_FLAG_GRAPH)) return fail(c, GAT_ERR_ARG, "unknown flag bits");
+    GAT_HIP(c, hipSetDevice(c->device));
+    const uint32_t kflags = flags & ~GAT_FLAG_GRAPH;
+    if (!(flags & GAT_FLAG_GRAPH))
+        return tracking_run_enqueue(c, sig, num_blocks, K, L, shifts, fs, cfg, state, params_a, params_b, acc_re, acc_im,
+                                    acc_block_stride, kflags, current_is_b);
+
+    // hipGraph path: the 2-3 launches per block are too short to hide their launch gaps.  Every argument that
+    // shapes the launch sequence is part of the key; a call with the same key replays the instantiated graph.
+    std::vector<unsigned char> key;
+    key_put(key, *sig); key_put(key, num_blocks); key_put(key, K); key_put(key, L); key_put(key, fs); key_put(key, *cfg);
+    key_put(key, state); key_put(key, params_a); key_put(key, params_b); key_put(key, acc_re); key_put(key, acc_im);
+    key_put(key, acc_block_stride); key_put(key, kflags); key_put(key, c->mc_mode); key_put(key, c->d_codes);
+    for (int l = 0; l < L; ++l) key_put(key, shifts[l]);
+    if (current_is_b) *current_is_b = (num_blocks & 1) ? 1 : 0; // the buffers swap once per block
+    if (c->loop_graph && key == c->loop_graph_key) {
+        GAT_HIP(c, hipGraphLaunch(c->loop_graph, c->stream));
+        return GAT_OK;
+    }
+    // first call with these arguments: run it eagerly (this also sizes the library's scratch buffers, which must
+    // not be reallocated inside a capture), then record the same sequence for the following calls
+    int32_t rc = tracking_run_enqueue(c, sig, num_blocks, K, L, shifts, fs, cfg, state, params_a, params_b, acc_re, acc_im,
+                                      acc_block_stride, kflags, nullptr);
+    if (rc != GAT_OK) return rc;
+    if (c->loop_graph) {
+        (void)hipGraphExecDestroy(c->loop_graph);
+        c->loop_graph = nullptr;
+        c->loop_graph_key.clear();
+    }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return GAT_OK; // no graph: stay eager
+    rc = tracking_run_enqueue(c, sig, num_blocks, K, L, shifts, fs, cfg, state, params_a, params_b, acc_re, acc_im,
+                              acc_block_stride, kflags, nullptr);
+    const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
+    if (rc == GAT_OK && ce == hipSuccess && graph &&
+        hipGraphInstantiate(&c->loop_graph, graph, nullptr, nullptr, 0) == hipSuccess)
+        c->loop_graph_key = key;
+    else
+        c->loop_graph = nullptr;
+    if (graph) (void)hipGraphDestroy(graph);
     return GAT_OK;
 }
 

@@ -72,6 +72,46 @@ class TrackingLoop:
         self._cur = 1 - self._cur
         self.blocks_done += 1
 
+    def run(self, re: torch.Tensor, im: torch.Tensor | None, num_blocks: int, start: int = 0, keep: bool = True,
+            graph: bool = False, out: tuple | None = None):
+        """``num_blocks`` consecutive blocks (block b starts at sample start + b * N) through {correlate, update}
+        in one native call (``gat_tracking_run``): the same launches as ``num_blocks`` x ``step`` without a
+        host round trip per block.  Returns the accumulators of every block as device tensors (re, im)
+        [num_blocks, K, L, M] when ``keep`` (into ``out`` = (re, im) if given), else only the last block's in
+        ``out_re`` / ``out_im``.  ``graph``: GAT_FLAG_GRAPH -- calls that repeat with the same buffers replay an
+        instantiated hipGraph (the context must be bound to a non-default stream)."""
+        nb = int(num_blocks)
+        desc = _signal_desc(re, im, self.N, start=start)
+        ntot = re.shape[-2] if im is None else re.shape[-1]
+        if start + nb * self.N > ntot:
+            raise ValueError("signal shorter than start + num_blocks * num_samples")
+        if keep:
+            if out is not None:
+                acc_re, acc_im = out
+            else:
+                acc_re = torch.empty((nb, self.K, self.L, self.M), dtype=torch.float32, device=self.ctx.device)
+                acc_im = torch.empty_like(acc_re)
+            stride = self.K * self.L * self.M
+        else:
+            acc_re, acc_im, stride = self.out_re, self.out_im, 0
+        a, b = self._params[self._cur], self._params[1 - self._cur]
+        is_b = C.c_int32(0)
+        rc = self.ctx.lib.gat_tracking_run(self.ctx._h, C.byref(desc), nb, self.K, self.L,
+                                           self.shifts.ctypes.data_as(C.POINTER(C.c_int32)), self.fs,
+                                           C.byref(self.config), C.c_void_p(self._state.data_ptr()),
+                                           C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()),
+                                           C.c_void_p(acc_re.data_ptr()), C.c_void_p(acc_im.data_ptr()), stride,
+                                           _lib.GAT_FLAG_GRAPH if graph else 0,
+                                           C.byref(is_b))
+        self.ctx.check(rc, "gat_tracking_run")
+        if is_b.value:
+            self._cur = 1 - self._cur
+        self.blocks_done += nb
+        if keep:
+            self.out_re.copy_(acc_re[-1:])
+            self.out_im.copy_(acc_im[-1:])
+        return acc_re, acc_im
+
     def params(self) -> np.ndarray:
         """Current per-channel parameters (host copy; synchronises)."""
         return self._params[self._cur].cpu().numpy().view(_lib.PARAMS_DTYPE).copy()

@@ -50,6 +50,9 @@ extern "C" {
 #define GAT_FLAG_ATOMIC 1u /* single-pass float atomics (reference alg. 4/5,                */
                            /* src/algorithms.jl:625-632); default = deterministic two-stage */
 
+#define GAT_FLAG_GRAPH 2u  /* gat_tracking_run only: replay the launch sequence as an instantiated hipGraph when the */
+                           /* call repeats with the same arguments (needs a non-default stream; else stays eager)    */
+
 /* ---- signal layouts ---------------------------------------------------------------------- */
 #define GAT_LAYOUT_PLANAR 0          /* float32 re[] and im[] planes (reference StructArray)   */
 #define GAT_LAYOUT_INTERLEAVED 1     /* ComplexF32 {re,im} pairs; .im must be NULL             */
@@ -237,6 +240,21 @@ GAT_API int32_t gat_tracking_update(gat_ctx *ctx, const float *acc_re_dev, const
                                     int32_t num_channels, int32_t num_ants,
                                     const gat_loop_config *config_host, gat_loop_state *state_dev,
                                     const gat_channel_params *cur_dev, gat_channel_params *next_dev);
+
+/* num_blocks consecutive integration blocks of a device-resident signal (block b starts b * sig->block_stride
+ * samples in) through {correlate, tracking update} with the parameters ping-ponging between params_a (current at
+ * entry) and params_b: 2 * num_blocks launches enqueued from native code, no host round trip and no
+ * synchronisation (a per-block call from a scripting host is launch-bound: ~16 us per 1 ms block).  Block b's
+ * accumulators go to acc_re/acc_im + b * acc_block_stride floats ([M x L x K] each; stride 0 keeps only the last
+ * block's).  *current_is_b tells which buffer holds the parameters for the block after the last one.
+ * flags: GAT_FLAG_ATOMIC as for the correlator; GAT_FLAG_GRAPH: the first call with a given argument set runs
+ * eagerly and records the sequence, later calls with the same arguments replay it with one hipGraphLaunch. */
+GAT_API int32_t gat_tracking_run(gat_ctx *ctx, const gat_signal_desc *sig, int32_t num_blocks, int32_t num_channels,
+                                 int32_t num_taps, const int32_t *shifts_host, double sampling_freq_hz,
+                                 const gat_loop_config *config_host, gat_loop_state *state_dev,
+                                 gat_channel_params *params_a_dev, gat_channel_params *params_b_dev,
+                                 float *acc_re_dev, float *acc_im_dev, int64_t acc_block_stride, uint32_t flags,
+                                 int32_t *current_is_b);
 
 /* ---- memory + timing helpers (for hosts without their own HIP array type) ---------------- */
 GAT_API int32_t gat_malloc(gat_ctx *ctx, size_t bytes, void **out_dev);

@@ -1,0 +1,31 @@
+"""Closed tracking loop per 1 ms block: per-block step() calls from Python vs one native gat_tracking_run call."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import gpuacceleratedtracking_amd as g
+
+system = g.GPSL1()
+side = torch.cuda.Stream()
+torch.cuda.set_stream(side)  # a non-default stream: hipGraph capture is not allowed on the legacy default stream
+for (K, M, fs) in ((12, 4, 20e6), (4, 16, 50e6)):
+    N, nblk = int(fs * 1e-3), 400
+    prns = np.arange(1, K + 1)
+    dop = np.linspace(-3000, 3000, K)
+    prm_sig = g.make_params(prns - 1, 1.023e6, dop, np.linspace(5, 900, K)[None, :], 0.0, shape=(nblk, K))
+    re, im = g.gen_signal_stream(system, prm_sig, fs, N, M)
+    shifts = g.get_correlator_sample_shifts(system, g.EarlyPromptLateCorrelator(M, 3), fs, 0.5)
+    mk = lambda: g.TrackingLoop(system, prns, N, M, fs, shifts, init_carrier_doppler=dop, init_code_phase=np.linspace(5, 900, K))
+    a = mk(); ctx = a.ctx
+    for i in range(20): a.step(re, im, start=i * N)
+    ctx.sync(); t0 = time.perf_counter()
+    for i in range(nblk): a.step(re, im, start=i * N)
+    ctx.sync(); t_step = (time.perf_counter() - t0) / nblk
+    b = mk(); b.run(re, im, 20, keep=False); ctx.sync(); t0 = time.perf_counter()
+    b.run(re, im, nblk, keep=False)
+    ctx.sync(); t_run = (time.perf_counter() - t0) / nblk
+    c = mk(); c.run(re, im, nblk, keep=False, graph=True); c.run(re, im, nblk, keep=False, graph=True); ctx.sync(); t0 = time.perf_counter()
+    c.run(re, im, nblk, keep=False, graph=True)
+    ctx.sync(); t_graph = (time.perf_counter() - t0) / nblk
+    print(f"   hipGraph replay {t_graph*1e6:.1f} us (RTF {1e-3/t_graph:.0f})")
+    print(f"K={K} M={M} fs={fs/1e6:g} MHz: per-block step() {t_step*1e6:.1f} us (RTF {1e-3/t_step:.0f}) | native run {t_run*1e6:.1f} us (RTF {1e-3/t_run:.0f})")

@@ -101,3 +101,62 @@ def test_closed_loop_four_satellites_track(g):
     assert dtau.max() < 0.06
     assert np.abs(st["last_pll_error_cycles"]).max() < 0.08 and np.abs(st["last_dll_error_chips"]).max() < 0.15
     assert (np.abs(acc[:, 1, :]) > 0.85 * N).all()
+
+
+def test_native_run_equals_stepwise_loop(g):
+    """gat_tracking_run (all blocks from one native call) enqueues exactly the launches of step() x blocks: parameters,
+    loop state and every block's accumulators are bit-identical."""
+    system = g.GPSL1()
+    N, M, fs, nblk = 4000, 2, 4e6, 64
+    prns = np.array([3, 11, 26])
+    dop = np.array([850.0, -1400.0, 40.0])
+    prm_sig = g.make_params(prns - 1, 1.023e6, dop, [[10.0, 400.5, 900.25]], 0.0, shape=(nblk, 3))
+    re, im = g.gen_signal_stream(system, prm_sig, fs, N, M)
+    shifts = g.get_correlator_sample_shifts(system, g.EarlyPromptLateCorrelator(M, 3), fs, 0.5)
+
+    def make():
+        return g.TrackingLoop(system, prns, N, M, fs, shifts, init_carrier_doppler=dop + 5.0,
+                              init_code_phase=np.array([10.1, 400.4, 900.3]), dll_bandwidth_hz=4.0)
+    a, b = make(), make()
+    hist = []
+    for i in range(nblk):
+        a.step(re, im, start=i * N)
+        hist.append(a.accumulators())
+    acc_re, acc_im = b.run(re, im, nblk)
+    got = (acc_re.cpu().numpy() + 1j * acc_im.cpu().numpy()).astype(np.complex64)
+    assert np.array_equal(np.stack(hist).view(np.float32), got.view(np.float32))
+    assert a.params().tobytes() == b.params().tobytes() and a.state().tobytes() == b.state().tobytes()
+    assert b.blocks_done == nblk
+    c = make()  # keep=False: only the last block's accumulators, same parameters
+    c.run(re, im, nblk, keep=False)
+    assert c.params().tobytes() == a.params().tobytes()
+    assert np.array_equal(c.accumulators().view(np.float32), hist[-1].view(np.float32))
+
+
+def test_native_run_graph_replay(g):
+    """GAT_FLAG_GRAPH: the second and later calls with the same buffers replay the recorded hipGraph -- the results
+    equal the eager run's (the parameter buffers swap an even number of times per call, so every call starts from
+    buffer A; state and parameters evolve on the device across replays exactly as across eager calls)."""
+    import torch
+    system = g.GPSL1()
+    N, M, fs, nblk = 4000, 2, 4e6, 32  # even: the ping-pong returns to buffer A after every call
+    prns = np.array([5, 17])
+    dop = np.array([-600.0, 1900.0])
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        prm_sig = g.make_params(prns - 1, 1.023e6, dop, [[77.0, 640.5]], 0.0, shape=(nblk, 2))
+        re, im = g.gen_signal_stream(system, prm_sig, fs, N, M)
+        shifts = g.get_correlator_sample_shifts(system, g.EarlyPromptLateCorrelator(M, 3), fs, 0.5)
+
+        def make():
+            return g.TrackingLoop(system, prns, N, M, fs, shifts, init_carrier_doppler=dop + 3.0,
+                                  init_code_phase=np.array([77.1, 640.4]), dll_bandwidth_hz=4.0)
+        eager, graph = make(), make()
+        assert graph.ctx.stream.cuda_stream != 0
+        out = (torch.empty((nblk, 2, 3, M), device=graph.ctx.device), torch.empty((nblk, 2, 3, M), device=graph.ctx.device))
+        for rep in range(3):  # same signal three times over: call 1 records, calls 2 and 3 replay
+            e_re, e_im = eager.run(re, im, nblk)
+            graph.run(re, im, nblk, graph=True, out=out)
+            graph.ctx.sync()
+            assert torch.equal(e_re, out[0]) and torch.equal(e_im, out[1]), rep
+            assert eager.params().tobytes() == graph.params().tobytes() and eager.state().tobytes() == graph.state().tobytes()
