@@ -453,9 +453,6 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     // full floored modulo only when `anchor`; otherwise it follows from the exact floor differences
     // (chips advance monotonically): ip - ip_prev chips on from the index of T samples ago
     // (c.inc_ok: fewer than Lc chips per step), and the pair's second entry at most one wrap on.
-    auto chip_mask = [&](const unsigned *tab, int t) {
-        return (unsigned)__builtin_amdgcn_sbfe(tab[t >> 5], t & 31, 1) & 0x80008000u; // bit set: chip -1
-    };
     auto gen_rep2 = [&](const ChanInfoB &c, const unsigned *tab, unsigned *row, int nb, int e0, int e_end, bool anchor,
                         int &ip_state, int &t_state) {
         const int x0 = nb + a.shifts[0] + e0;
@@ -477,8 +474,12 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         t_state = t0;
         int t1 = t0 + (ip1 - ip0);
         t1 -= (t1 >= Lc) ? Lc : 0;
-        row[e0] = chip_mask(tab, t0);
-        if (e0 + 1 < e_end) row[e0 + 1] = chip_mask(tab, t1);
+        // both table words first, then both masks: two LDS round trips in flight together, not one after the other
+        const unsigned w0 = tab[t0 >> 5], w1 = tab[t1 >> 5];
+        const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe(w0, t0 & 31, 1) & 0x80008000u; // bit set: chip -1
+        const unsigned m1 = (unsigned)__builtin_amdgcn_sbfe(w1, t1 & 31, 1) & 0x80008000u;
+        row[e0] = m0;
+        if (e0 + 1 < e_end) row[e0 + 1] = m1;
     };
     // one item = (slot, 2 consecutive samples): carrier fragments + the 2 new replica entries.  A producer
     // thread owns the same item in every step (at most one: the planner keeps nslots * T / 2 <= PT) and
@@ -493,14 +494,15 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         u32x2 *wb = s_w + buf * wrows * WS * WE;
         unsigned *rb = s_rep + buf * nslots * RS;
         const unsigned *rprev = s_rep + (buf ^ 1) * nslots * RS;
+        const ChanInfoB c = s_chan[have_item ? item_slot : 0]; // fetched first: in flight behind the overlap copy below
         if (first) { // entries [0, span): ceil(span / 2) pairs per slot
             const int gps = (span + 1) >> 1;
             for (int id = ptid; id < nslots * gps; id += PT) {
                 const int slot = id / gps, g = id - slot * gps;
-                const ChanInfoB c = s_chan[slot];
-                if (!c.valid) continue;
+                const ChanInfoB cs = s_chan[slot];
+                if (!cs.valid) continue;
                 int ip_unused, t_unused;
-                gen_rep2(c, s_code + slot * a.code_bits_stride, rb + slot * RS, nb, 2 * g, span, true, ip_unused, t_unused);
+                gen_rep2(cs, s_code + slot * a.code_bits_stride, rb + slot * RS, nb, 2 * g, span, true, ip_unused, t_unused);
             }
         } else { // the overlap with the previous step is already known
             const int pw = wave - 4;
@@ -508,7 +510,6 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
                 for (int e = lane; e < span; e += 64) rb[slot * RS + e] = rprev[slot * RS + e + T];
         }
         if (!have_item) return;
-        const ChanInfoB c = s_chan[item_slot];
         if (!c.valid) return;
         const bool anchor = first || ((st - s_begin) % kReanchor) == 0; // wave-uniform
 #if defined(GAT_ABLATE) && (GAT_ABLATE & 1) // diagnostic builds (scripts/ablate_mfma_bf16.sh; results wrong on purpose): no replica
