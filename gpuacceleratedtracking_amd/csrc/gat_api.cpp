@@ -327,6 +327,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     cfg.ant_tile = MT;
     cfg.vec = vec;
     cfg.format = fmt;
+    cfg.keep_l2 = K > 1 && sig->chan_stride == 0;
     cfg.grid = (unsigned)grid_wgs;
     a.max_abs_shift = (int)max_shift;
 

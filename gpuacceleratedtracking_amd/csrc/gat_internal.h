@@ -57,6 +57,7 @@ struct DcLaunch {
     int taps;     // L of this launch
     int vec;      // 4 or 1
     int format;   // GAT_LAYOUT_*
+    int keep_l2;  // 1: plain loads (several channels share the signal bytes through L2), 0: non-temporal
     unsigned grid;
     unsigned lds_bytes;
 };

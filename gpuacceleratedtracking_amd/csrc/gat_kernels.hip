@@ -143,11 +143,9 @@ __device__ __forceinline__ float wave_sum(float v)
 // interleaved int16 pairs, interleaved int8 pairs.  VEC = 4: one 16-byte non-temporal load per
 // lane, plane and group (4 / 2 / 4 / 8 complex samples); VEC = 1: scalar loads (unaligned input).
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-#ifdef GAT_NO_NT // experiment: plain loads instead of non-temporal ones
-#define GAT_NT_LOAD(p) (*(p))
-#else
-#define GAT_NT_LOAD(p) __builtin_nontemporal_load(p)
-#endif
+// sample loads: non-temporal when every byte is used once (one channel per signal: + 7 % at configs[1]), plain when
+// the K channel workgroups of a tile are to find it in L2 (+ 4-9 % with 8-12 channels)
+#define GAT_NT_LOAD(p) (KEEP ? *(p) : __builtin_nontemporal_load(p))
 
 template <int FMT>
 struct SampleIO {
@@ -157,6 +155,7 @@ struct SampleIO {
     static constexpr int BYTES = (FMT == GAT_LAYOUT_INTERLEAVED_I16) ? 4 : (FMT == GAT_LAYOUT_INTERLEAVED_I8) ? 2 : 8;
 
     // 16-byte loads of the group starting at complex-sample index e
+    template <bool KEEP>
     static __device__ __forceinline__ void load16(i32x4 (&raw)[NV], const void *re, const void *im, size_t e)
     {
         if constexpr (FMT == GAT_LAYOUT_PLANAR) {
@@ -211,7 +210,7 @@ struct SampleIO {
 
 // No minimum-waves bound on purpose: <4,3,4,planar> needs 136 VGPRs (3 waves/SIMD) and any tighter
 // bound spills to scratch (measured: 4 waves/SIMD no gain at configs[1], 5 and 6 are 1.3-1.8x slower).
-template <int MT, int L, int VEC, int FMT>
+template <int MT, int L, int VEC, int FMT, bool KEEP>
 __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -306,7 +305,7 @@ __global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
     };
     auto load_group = [&](i32x4 (&raw)[MT][IO::NV], int n) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) IO::load16(raw[m], a.re, a.im, base + (size_t)m * a.ant_stride + n);
+        for (int m = 0; m < MT; ++m) IO::template load16<KEEP>(raw[m], a.re, a.im, base + (size_t)m * a.ant_stride + n);
     };
     // S consecutive samples starting at n: one FP64 carrier anchor, then S-1 rotations
     auto process_group = [&](const i32x4 (&raw)[MT][IO::NV], int n, int rel, const float *rep) {
@@ -644,15 +643,18 @@ template <int MT, int L>
 static hipError_t launch_dc_ml(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
 {
     const dim3 grid(cfg.grid), block(kThreads);
-#define GAT_LAUNCH(V, F) hipLaunchKernelGGL((dc_kernel<MT, L, V, F>), grid, block, cfg.lds_bytes, s, a)
-#define GAT_LAUNCH_V(F) do { if (cfg.vec == 4) GAT_LAUNCH(4, F); else GAT_LAUNCH(1, F); } while (0)
+#define GAT_LAUNCH(V, F, K_) hipLaunchKernelGGL((dc_kernel<MT, L, V, F, K_>), grid, block, cfg.lds_bytes, s, a)
+#define GAT_LAUNCH_V(F) do { if (cfg.vec == 4) GAT_LAUNCH(4, F, false); else GAT_LAUNCH(1, F, false); } while (0)
+    // the L2-keeping variant exists for the 16-byte-load float formats only (instance count)
+#define GAT_LAUNCH_VK(F) do { if (cfg.vec == 4 && cfg.keep_l2) GAT_LAUNCH(4, F, true); else GAT_LAUNCH_V(F); } while (0)
     switch (cfg.format) {
-    case GAT_LAYOUT_PLANAR: GAT_LAUNCH_V(GAT_LAYOUT_PLANAR); break;
-    case GAT_LAYOUT_INTERLEAVED: GAT_LAUNCH_V(GAT_LAYOUT_INTERLEAVED); break;
+    case GAT_LAYOUT_PLANAR: GAT_LAUNCH_VK(GAT_LAYOUT_PLANAR); break;
+    case GAT_LAYOUT_INTERLEAVED: GAT_LAUNCH_VK(GAT_LAYOUT_INTERLEAVED); break;
     case GAT_LAYOUT_INTERLEAVED_I16: GAT_LAUNCH_V(GAT_LAYOUT_INTERLEAVED_I16); break;
     case GAT_LAYOUT_INTERLEAVED_I8: GAT_LAUNCH_V(GAT_LAYOUT_INTERLEAVED_I8); break;
     default: return hipErrorInvalidValue;
     }
+#undef GAT_LAUNCH_VK
 #undef GAT_LAUNCH_V
 #undef GAT_LAUNCH
     return hipGetLastError();
