@@ -1,0 +1,20 @@
+"""One-off stress: the random antenna-rich sweep of tests/test_random_sweep_gpu.py over many more seeds."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gpuacceleratedtracking_amd as g
+from tests import test_random_sweep_gpu as t
+
+g.load_library()
+lo, hi = int(sys.argv[1]), int(sys.argv[2])
+bad = []
+t0 = time.time()
+for seed in range(lo, hi):
+    try:
+        t.test_random_matrix_case(g, seed)
+    except Exception as e:  # noqa: BLE001
+        bad.append((seed, str(e)[:300]))
+        print("FAIL", seed, str(e)[:300], flush=True)
+    if (seed - lo) % 50 == 49:
+        print(f"{seed - lo + 1} cases, {len(bad)} failures, {time.time() - t0:.0f} s", flush=True)
+print("done:", hi - lo, "cases,", len(bad), "failures")
+sys.exit(1 if bad else 0)
