@@ -53,8 +53,15 @@ def oracle_result(case):
                                 case["shifts"], N=case["N"])
 
 
-def check_close(got, ref, rtol=RTOL, what=""):
-    """got/ref complex [B, K, L, M]."""
+def check_close(got, ref, rtol=RTOL, what="", floor_frac=None, abs_floor=0.0):
+    """got/ref complex [B, K, L, M].  ``floor_frac`` (default: env GAT_CHECK_FLOOR_FRAC, else 0 = strict): a channel
+    whose own largest accumulator is below this fraction of the block's largest one (a short integration whose
+    interferers happen to cancel its single tap) is scaled by that floor instead -- a relative error against a
+    cancellation residue says nothing about the kernel (scripts/stress_matrix_sweep.py uses 0.01).  ``abs_floor``: the
+    same as an absolute magnitude (callers that know the coherent scale N * rms|x| of the integration)."""
+    import os
+    if floor_frac is None:
+        floor_frac = float(os.environ.get("GAT_CHECK_FLOOR_FRAC", "0"))
     got = np.asarray(got, dtype=np.complex128)
     ref = np.asarray(ref, dtype=np.complex128)
     assert got.shape == ref.shape, (got.shape, ref.shape)
@@ -62,9 +69,11 @@ def check_close(got, ref, rtol=RTOL, what=""):
     for b in range(B):
         for k in range(K):
             r, g = ref[b, k], got[b, k]
-            scale = np.abs(r).max()
+            scale = max(np.abs(r).max(), floor_frac * np.abs(ref[b]).max(), abs_floor)
             e_inf = np.abs(g - r).max() / scale
             assert e_inf <= rtol, f"{what} block {b} chan {k}: norm-wise error {e_inf:.3e} > {rtol}"
+            if np.abs(r).max() < scale:  # only with a floor: the whole channel is a cancellation residue,
+                continue               # there is no signal-bearing element to judge element-wise
             strong = np.abs(r) >= 0.1 * scale
             rel = (np.abs(g - r)[strong] / np.abs(r)[strong]).max()
             assert rel <= rtol, f"{what} block {b} chan {k}: element-wise error {rel:.3e} > {rtol}"

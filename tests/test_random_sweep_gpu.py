@@ -115,6 +115,10 @@ def test_random_matrix_case(g, seed):
     sysobj = g.GNSSDICT[cfg["system"]](use_gpu=True)
     p = case["prm"]
     prm = g.make_params(p["prn0"], p["code_freq_hz"], p["carrier_freq_hz"], p["code_phase_chips"], p["carrier_phase_cycles"])
+    # stress runs only (GAT_CHECK_FLOOR_FRAC > 0): residues of cancellation are judged against the coherent scale
+    import os
+    frac = float(os.environ.get("GAT_CHECK_FLOOR_FRAC", "0"))
+    abs_floor = frac * cfg["N"] * float(np.sqrt(np.mean(case["re"].astype(np.float64) ** 2 + case["im"].astype(np.float64) ** 2)))
     kinds = []
     try:
         for mode in (g.GAT_MC_AUTO, g.GAT_MC_F32, g.GAT_MC_VECTOR):
@@ -123,7 +127,7 @@ def test_random_matrix_case(g, seed):
             op.set_params(prm)
             op(*sig)
             kinds.append(ctx.last_launch_info()["matrix_core"])
-            check_close(op.result(), ref,
+            check_close(op.result(), ref, abs_floor=abs_floor,
                         what=f"seed {seed} mode {mode} kernel {kinds[-1]}: {cfg} layout {layout} shifts {case['shifts'].tolist()} flags {flags}")
     finally:
         ctx.set_matrix_core(1)
