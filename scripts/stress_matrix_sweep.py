@@ -8,11 +8,12 @@ from tests import test_random_sweep_gpu as t
 
 g.load_library()
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
+fn = t.test_random_case if len(sys.argv) > 3 and sys.argv[3] == "vector" else t.test_random_matrix_case
 bad = []
 t0 = time.time()
 for seed in range(lo, hi):
     try:
-        t.test_random_matrix_case(g, seed)
+        fn(g, seed)
     except Exception as e:  # noqa: BLE001
         bad.append((seed, str(e)[:300]))
         print("FAIL", seed, str(e)[:300], flush=True)

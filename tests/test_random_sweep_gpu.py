@@ -67,7 +67,11 @@ def test_random_case(g, seed):
     else:  # host-parameter entry point (gat_downconvert_and_correlate)
         op.ctx.downconvert_and_correlate(op.describe(*sig), prm, cfg["B"], cfg["K"], case["shifts"], cfg["fs"],
                                          op.out_re, op.out_im, flags)
-    check_close(op.result(), ref, what=f"seed {seed}: {cfg} layout {layout} shifts {case['shifts'].tolist()} flags {flags}")
+    import os
+    frac = float(os.environ.get("GAT_CHECK_FLOOR_FRAC", "0"))  # stress runs only, see test_random_matrix_case
+    abs_floor = frac * cfg["N"] * float(np.sqrt(np.mean(case["re"].astype(np.float64) ** 2 + case["im"].astype(np.float64) ** 2)))
+    check_close(op.result(), ref, abs_floor=abs_floor,
+                what=f"seed {seed}: {cfg} layout {layout} shifts {case['shifts'].tolist()} flags {flags}")
 
 
 def _random_matrix_config(rng):
