@@ -53,7 +53,23 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--block-ms", type=float, default=1.0, help="duration of one integration block (fs = N / block)")
-    return ap.parse_args()
+    ap.add_argument("--baseline-config", type=int, choices=[1, 2, 3, 4], default=None,
+                    help="shape of BASELINE.json configs[i] (1 = the default headline workload; 2 = GPS L5, 4 ants, 12 PRNs, "
+                         "5 taps @ 50 MHz; 3 = the per-GPU shard of 16 ants x 32 PRNs @ 50 MHz; 4 = 64 ants x 64 channels, "
+                         "20 ms @ 100 MHz); explicit shape flags still override nothing -- the preset wins")
+    args = ap.parse_args()
+    presets = {
+        1: {},
+        2: dict(gnss="GPSL5", num_samples=50000, num_ants=4, num_taps=5, channels=12, blocks=1024),
+        3: dict(gnss="GPSL1", num_samples=50000, num_ants=16, num_taps=3, channels=4, blocks=512),
+        4: dict(gnss="GPSL1", num_samples=2000000, num_ants=64, num_taps=3, channels=64, blocks=1, block_ms=20.0),
+    }
+    if args.baseline_config is not None:
+        for k, v in presets[args.baseline_config].items():
+            setattr(args, k, v)
+        if args.baseline_config != 1:  # long launches: fewer timed steps keep the run short
+            args.steps, args.warmup, args.settle = min(args.steps, 20), min(args.warmup, 3), min(args.settle, 4)
+    return args
 
 
 def cpu_baseline(args, host_re, host_im, prm, shifts, fs, system):
