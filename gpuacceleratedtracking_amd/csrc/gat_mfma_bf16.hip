@@ -24,6 +24,11 @@
 // Code replica: exactly the reference's FP64 expression, unfused (src/algorithms.jl:179), as in the
 // other kernels; per step only the T new entries are evaluated, the tap-span overlap is copied
 // from the previous step's buffer.
+// Sample formats: planar / interleaved ComplexF32, int16 and int8 pairs (template FMT).  int8 samples are exact in
+// ONE bf16 term: 3 products {x*hi, x*mid, x*lo} = 4 slots per sample, a slice covers 4 samples (half the MFMAs) and
+// both fragments come ready-made from LDS (X = {x|x, x|0}, W = {hi|mid, lo|0} per sample; see X1 below).
+// What bounds the kernel (profiles/r01c_mfma_bf16_ablation.txt): the vector issue port -- the
+// producers' splits / permutes / FP64 code phases do not fit into the issue cycles the MFMAs leave free.
 // One accumulation chain covers at most kMaxChain samples (the planner splits longer blocks over
 // workgroups, finalize_kernel adds the partials in a fixed order), so the f32 rounding of a running
 // sum of millions of samples stays far inside 1e-5.
