@@ -141,10 +141,16 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         const int nct_total = shape_ok ? (K + CT - 1) / CT : 1;
         int nct = nct_total >= 4 ? 4 : (nct_total >= 2 ? 2 : 1);
         while (nct > 1 && nct * CT > 20) nct >>= 1; // both kernels keep at most 20 channel slots per workgroup
-        // kernel choice: 3 / 1 (auto) -> split-bf16 when its tile fits in LDS, 2 -> f32 MFMA
+        // kernel choice: 3 / 1 (auto) -> split-bf16 when its tile fits in LDS, 2 -> f32 MFMA.  GAT_MC_AUTO picks a matrix
+        // kernel only where it measured faster than the vector kernel (scripts/planner_threshold_scan.sh, profiles/
+        // r01d_ab_matrix_kernels.txt): split-bf16 from 24 of the first 32 columns on (K = 4 at three taps: break-even,
+        // K = 2, 3: the vector kernel is 1.1-1.4x faster), the f32-MFMA kernel only for large antenna x channel products.
+        const bool auto_bf16 = 2ll * L * K >= 24, auto_f32 = auto_bf16 && (long long)M * K >= 2048;
+        const bool want_bf16 = c->mc_mode == 3 || (c->mc_mode == 1 && auto_bf16);
+        const bool want_f32 = c->mc_mode == 2 || (c->mc_mode == 1 && auto_f32);
         int kind = 0, rt = 1, rep_stride_m = 0;
         int nslots_b = 0, tiles_b = 0, nct_b = 1;
-        if (shape_any && c->mc_mode != 2 && c->d_code_bits && c->d_zeros && N % spv == 0 && spv <= 8) {
+        if (shape_any && want_bf16 && c->d_code_bits && c->d_zeros && N % spv == 0 && spv <= 8) {
             // split-bf16 kernel: columns packed flat (2 L per channel), 32 per tile
             tiles_b = (2 * L * K + 31) / 32;
             const int rt_max = (M / 16) % 4 == 0 ? 4 : ((M / 16) % 2 == 0 ? 2 : 1);
@@ -163,7 +169,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
                 }
             }
         }
-        if (shape_ok && !kind && c->mc_mode != 3) {
+        if (shape_ok && !kind && want_f32) {
             rep_stride_m = ((256 + (int)span + 31) / 32) * 32 + 1;
             if (mfma_lds_bytes(nct, CT, rep_stride_m, c->code_row_stride, 0) <= 160 * 1024) kind = 1;
         }

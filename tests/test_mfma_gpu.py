@@ -44,12 +44,12 @@ GRID = [
     ("GPSL1", 5000, 16, 3, 6, 1),     # CT + 1 channels: second tile nearly empty
     ("GPSL1", 3004, 32, 3, 21, 1),    # 5 channel tiles -> two channel groups, ragged tile
     ("GPSL5", 8192, 16, 5, 7, 2),     # L = 5 -> CT = 3
-    ("GPSL1", 776, 16, 1, 16, 2, 1),  # L = 1 -> CT = 16: 16 carrier rows per tile do not fit the split-bf16 LDS tile -> f32 MFMA
-    ("GPSL1", 260, 16, 16, 2, 1),     # L = 16 -> CT = 1 (one channel per tile)
+    ("GPSL1", 776, 16, 1, 16, 2, 0),  # L = 1: the split-bf16 tile does not fit, M x K is small for the f32 kernel -> auto: vector
+    ("GPSL1", 260, 16, 16, 2, 1),     # L = 16: one channel per tile
     ("GPSL1", 100, 16, 3, 4, 4),      # shorter than one tile
     ("GPSL1", 200000, 16, 3, 4, 1),   # many steps, split over workgroups + finalize
     ("GPSL1", 9000, 32, 3, 7, 2),     # 2 row tiles per workgroup, 2 channel tiles
-    ("GPSL1", 9000, 64, 3, 3, 1),     # 4 row tiles, one partial channel tile
+    ("GPSL1", 9000, 64, 3, 3, 1, 0),  # 4 row tiles, 18 of 32 columns: below the auto threshold (vector kernel faster)
     ("GPSL1", 70004, 48, 3, 10, 1),   # 3 antenna tiles of one row tile each, ragged last step
     ("GPSL5", 30000, 64, 5, 12, 1),   # L5: 12 channels x 5 taps = 4 channel tiles of CT = 3
 ]
@@ -59,12 +59,17 @@ GRID = [
 def test_mfma_parity(g, cfg):
     system, N, M, L, K, B = cfg[:6]
     auto_kind = cfg[6] if len(cfg) > 6 else 2
+    forced = 2 if not (L == 1 and K == 16) else 1  # GAT_MC_BF16_SPLIT takes every shape whose tile fits
     fs = {"GPSL1": 8e6, "GPSL5": 25e6}[system] if L <= 5 else 2.5e6
     case = make_case(zlib.crc32(repr(cfg).encode()), system=system, N=N, M=M, L=L, K=K, B=B, fs=fs, if_hz=1.1e6)
     ref = oracle_result(case)
-    got, info = run(g, case)  # auto: the split-bf16 kernel
+    got, info = run(g, case)  # auto: the split-bf16 kernel where it is the fastest
     assert info["matrix_core"] == auto_kind, info
     check_close(got, ref, what=f"auto (kind {auto_kind}) mfma {cfg}")
+    if forced == 2:
+        got, info = run(g, case, matrix_core=g.GAT_MC_BF16_SPLIT)
+        assert info["matrix_core"] == 2, info
+        check_close(got, ref, what=f"split-bf16 mfma {cfg}")
     f32, info_f = run(g, case, matrix_core=g.GAT_MC_F32)
     assert info_f["matrix_core"] == 1, info_f
     check_close(f32, ref, what=f"f32 mfma {cfg}")
@@ -155,8 +160,9 @@ def test_planner_fallbacks_of_the_split_bf16_kernel(g):
 
 
 def test_non_pm1_code_table_takes_the_f32_kernel(g):
-    """A caller-supplied table with blanked (0) chips has no sign-bit form: auto selection must use the
-    f32-MFMA kernel (which multiplies by the chip value) and still match the oracle."""
+    """A caller-supplied table with blanked (0) chips has no sign-bit form: the split-bf16 kernel must not take it (auto
+    selection falls to the vector kernel at this size), the f32-MFMA kernel (which multiplies by the chip value) can --
+    every mode matches the oracle."""
     import torch
     case = make_case(21, N=8000, M=16, L=3, K=5, B=1, fs=5e6)
     codes = case["codes"].copy()
@@ -166,7 +172,7 @@ def test_non_pm1_code_table_takes_the_f32_kernel(g):
     ctx = g.get_context()
     sysobj = g.GPSL1(codes=codes, code_frequency=case["fc"])
     try:
-        for mode, kind in ((g.GAT_MC_AUTO, 1), (g.GAT_MC_BF16_SPLIT, 0), (g.GAT_MC_VECTOR, 0)):
+        for mode, kind in ((g.GAT_MC_AUTO, 0), (g.GAT_MC_F32, 1), (g.GAT_MC_BF16_SPLIT, 0), (g.GAT_MC_VECTOR, 0)):
             ctx.set_matrix_core(mode)
             op = g.StreamCorrelator(sysobj, case["N"], case["M"], case["B"], case["K"], case["shifts"], case["fs"])
             p = case["prm"]
