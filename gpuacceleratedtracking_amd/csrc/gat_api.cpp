@@ -160,7 +160,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
                 const int rs = ((T + (int)span + 31) / 32) * 32 + 1; // odd: channel rows land on different banks
                 const int ns = mfma_bf16_slots(n, L, K);
                 // at most one (slot, sample pair) item per producer thread
-                if (ns * T / 2 > mfma_bf16_threads(rt, n) - kThreads || ns > mfma_bf16_max_slots()) continue;
+                if (ns * T / 2 > mfma_bf16_producer_threads(rt, n) || ns > mfma_bf16_max_slots()) continue;
                 if (mfma_bf16_lds_bytes(rt, n, fmt, ns, rs, c->code_bits_stride) <= 160 * 1024) {
                     kind = 2;
                     nct_b = n;

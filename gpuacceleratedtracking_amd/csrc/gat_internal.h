@@ -101,6 +101,7 @@ int mfma_bf16_max_slots();
 int mfma_bf16_tile_samples(int rt, int nct);
 int mfma_bf16_max_chain(); // samples one accumulation chain may cover
 int mfma_bf16_threads(int rt, int nct); // workgroup size of the instance
+int mfma_bf16_producer_threads(int rt, int nct);
 
 // Launchers implemented in gat_kernels.hip.  All return hipError_t of the launch.
 hipError_t launch_dc(const DcArgs &a, const DcLaunch &cfg, hipStream_t s);

@@ -49,6 +49,12 @@ namespace {
 // workgroup size: 4 consumer waves + 12 producer waves (4 per SIMD, 128 VGPRs) where the instance fits that
 // register budget, otherwise + 8 producer waves (3 per SIMD, 168 VGPRs)
 constexpr int mb_threads(int RT, int NCT) { return ((RT == 2 && NCT == 1) || (RT == 4 && NCT == 2)) ? 768 : 1024; }
+// consumer waves: one per SIMD, or (experiment GAT_MB_CW8) two per SIMD for the 4 x 4 instance
+#ifdef GAT_MB_CW8
+constexpr int consumer_waves(int RT, int NCT) { return (RT == 4 && NCT == 4) ? 8 : 4; }
+#else
+constexpr int consumer_waves(int, int) { return 4; }
+#endif
 constexpr int kMaxChain = 8192;  // samples per accumulation chain (f32 rounding of the running sum)
 constexpr int kReanchor = 16;   // steps between FP64 re-anchors of the producers' carried phasor / code index
 constexpr int kMbMaxSlots = 24;  // channel slots per workgroup (header size)
@@ -267,7 +273,8 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
 {
     constexpr int kMbThreads = mb_threads(RT, NCT);
     constexpr int T = tile_samples(RT, NCT);
-    constexpr int WPT = 4 / NCT;   // consumer waves per channel tile (they split the step's samples)
+    constexpr int NCW = consumer_waves(RT, NCT);
+    constexpr int WPT = NCW / NCT; // consumer waves per channel tile (they split the step's samples)
     constexpr int SW = T / WPT;    // samples per consumer wave and step
     constexpr bool X1 = FMT == GAT_LAYOUT_INTERLEAVED_I8; // samples exact in one bf16 term: 4 samples per MFMA
     constexpr int SPS = X1 ? 4 : 2; // samples per k-slice
@@ -283,7 +290,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     constexpr int GS = PLANAR ? 4 : FMT == GAT_LAYOUT_INTERLEAVED ? 2 : FMT == GAT_LAYOUT_INTERLEAVED_I16 ? 4 : 8;
     constexpr int BYTES = FMT == GAT_LAYOUT_INTERLEAVED_I16 ? 4 : FMT == GAT_LAYOUT_INTERLEAVED_I8 ? 2 : 8; // per complex sample
     constexpr int QPR = T / GS;    // groups per row
-    constexpr int PT = kMbThreads - kThreads; // producer threads (768 or 512)
+    constexpr int PT = kMbThreads - 64 * NCW; // producer threads (768 or 512)
     constexpr int NG = (PLANAR ? RT * 32 : RT * 16) * QPR; // groups per step
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // Columns are packed flat: column c = 2*L*k + 2*l + comp, a workgroup owns columns [32*NCT*cg, 32*NCT*(cg+1))
@@ -301,8 +308,8 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     unsigned *s_code = s_rep + ((2 * nslots * RS + 3) & ~3); // [nslots][code_bits_stride] sign-bit tables
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool producer = wave >= 4;
-    const int ptid = tid - kThreads;
+    const bool producer = wave >= NCW;
+    const int ptid = tid - 64 * NCW;
 
     // workgroup -> (tile, channel group); blocks id and id+8 share an XCD, so the channel groups of
     // one sample tile run back to back on one L2 (speed only)
@@ -379,7 +386,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     const int xi_other = tn > 0 ? min(4, (NG + tn - 1) / tn) : 0;
     const int rem = NG - xi_other * tn;                          // groups left for the item waves
     const int xi_item = rem > 0 ? (rem + niw - 1) / niw : 0;     // <= 4 (planner)
-    const bool item_wave = (wave - 4) < item_waves;
+    const bool item_wave = (wave - NCW) < item_waves;
     const int my_xi = __builtin_amdgcn_readfirstlane(item_wave ? xi_item : xi_other); // wave-uniform, in an SGPR
     const int g_first = item_wave ? xi_other * tn + ptid : ptid - niw;
     const int g_stride = item_wave ? niw : tn;
@@ -510,7 +517,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
                 gen_rep2(cs, s_code + slot * a.code_bits_stride, rb + slot * RS, nb, 2 * g, span, true, ip_unused, t_unused);
             }
         } else { // the overlap with the previous step is already known
-            const int pw = wave - 4;
+            const int pw = wave - NCW;
             for (int slot = pw; slot < nslots; slot += PT / 64)
                 for (int e = lane; e < span; e += 64) rb[slot * RS + e] = rprev[slot * RS + e + T];
         }
@@ -560,7 +567,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     };
 
     // ---- consumer state: this lane's column of W ------------------------------------------------
-    const int cw = wave & 3;
+    const int cw = producer ? 0 : wave;
     const int ctl = cw / WPT; // channel tile of this consumer wave within the workgroup
     const int sub = cw % WPT; // sample sub-range of the step
     const int r = lane & 31, h = lane >> 5;
@@ -665,7 +672,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     };
     // Role-specific loops (same barrier count): a shared loop would keep the producers' prefetch
     // registers alive in the consumers and the accumulators alive in the producers.
-    if (__builtin_amdgcn_readfirstlane(wave) >= 4) {
+    if (__builtin_amdgcn_readfirstlane(wave) >= NCW) {
         switch (my_xi) {
         case 0: producer_loop(std::integral_constant<int, 0>{}); break;
         case 1: producer_loop(std::integral_constant<int, 1>{}); break;
@@ -709,7 +716,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
 #pragma unroll
             for (int t = 0; t < RT; ++t)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s_red[((cw * RT + t) * 16 + i) * 64 + lane] = acc[t][i];
+                for (int i = 0; i < 16; ++i) s_red[(((ctl * (WPT - 1) + sub - 1) * RT + t) * 16 + i) * 64 + lane] = acc[t][i];
         }
         __syncthreads();
         if (!producer && sub == 0) { // fixed order: own samples first, then sub-ranges 1 .. WPT-1 (deterministic)
@@ -718,7 +725,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
 #pragma unroll
                 for (int qq = 1; qq < WPT; ++qq)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[t][i] += s_red[(((cw + qq) * RT + t) * 16 + i) * 64 + lane];
+                    for (int i = 0; i < 16; ++i) acc[t][i] += s_red[(((ctl * (WPT - 1) + qq - 1) * RT + t) * 16 + i) * 64 + lane];
                 __builtin_amdgcn_sched_barrier(0); // one row tile at a time: 16 loads in flight, not 64 * WPT
             }
         }
@@ -759,6 +766,7 @@ int mfma_bf16_tile_samples(int rt, int nct) { return tile_samples(rt, nct); }
 int mfma_bf16_max_chain() { return kMaxChain; }
 int mfma_bf16_max_slots() { return kMbMaxSlots; }
 int mfma_bf16_threads(int rt, int nct) { return mb_threads(rt, nct); }
+int mfma_bf16_producer_threads(int rt, int nct) { return mb_threads(rt, nct) - 64 * consumer_waves(rt, nct); }
 
 int mfma_bf16_slots(int nct, int L, int K)
 { // upper bound of the channels a workgroup's 32 * nct flat columns touch
