@@ -35,6 +35,20 @@ def test_library_exports_every_declared_symbol(g):
     assert lib.gat_version().startswith(b"libgat")
 
 
+def test_constants_match_header(g):
+    """Every numeric #define of include/gat.h that the Python host layer mirrors has the same value there."""
+    import re
+    from gpuacceleratedtracking_amd import _lib
+    text = open(os.path.join(ROOT, "include", "gat.h")).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"^#define\s+(GAT_[A-Z0-9_]+)\s+(-?\d+)u?\b", text, re.M)}
+    mirrored = [n for n in defs if hasattr(_lib, n)]
+    for name in ("GAT_FLAG_ATOMIC", "GAT_FLAG_GRAPH", "GAT_LAYOUT_PLANAR", "GAT_LAYOUT_INTERLEAVED", "GAT_LAYOUT_INTERLEAVED_I16",
+                 "GAT_LAYOUT_INTERLEAVED_I8", "GAT_MC_VECTOR", "GAT_MC_AUTO", "GAT_MC_F32", "GAT_MC_BF16_SPLIT", "GAT_MAX_TAPS"):
+        assert name in mirrored, name
+    for name in mirrored:
+        assert getattr(_lib, name) == defs[name], (name, getattr(_lib, name), defs[name])
+
+
 def test_struct_layouts_match_header(g):
     from gpuacceleratedtracking_amd import _lib
     assert C.sizeof(_lib.ChannelParams) == 40 and _lib.PARAMS_DTYPE.itemsize == 40
