@@ -2,7 +2,11 @@
 """bench.py -- headline measurement of the downconvert + correlate hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 works two ways: under an external launcher (python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N ..., the driver's form: RANK / LOCAL_RANK / WORLD_SIZE come from the environment) or
+called plainly as above -- then this process starts N child processes (one rank per GPU) BEFORE anything
+touches the GPU, waits for them and exits with their status; it never re-executes itself.
 
 Workload (BASELINE.json configs[1], the one the metric is quoted on): GPS L1 C/A, 4 antennas,
 1 PRN per GPU, 3 E/P/L correlators, 1 ms integration blocks at fs = 20 MHz (N = 20 000), as a
@@ -10,20 +14,25 @@ batched stream of B consecutive blocks resident in HBM (B = 4096 -> 2.6 GB, far 
 Infinity Cache).  One "step" = one pass of the fused kernel over all B blocks.
 
 Prints ONE JSON line on rank 0:
-  value      = total samples correlated per second over all ranks [Msamples/s]
+  value      = total samples x channels correlated per second over all ranks [Msamples/s]
                (inputs resident in HBM when the timed region starts; sync-inclusive)
-  roofline   = algorithmic bytes per launch / mean launch duration (HIP events on the launch
-               stream) against the 8 TB/s HBM3E peak
+  roofline   = max(algorithmic bytes / 8 TB/s, algorithmic flops / 157.3 TFLOP/s) against the mean launch
+               duration (HIP events on the launch stream); `bound` names the winning term
   cpu_baseline = the oracle's FP32 4-pass CPU restatement ("port") timed on this host on a bounded
                sample of the same stream (the reference's Julia CPU path cannot run here)
+  shard_config3 (N > 1 only) = the same measurement on BASELINE configs[3]'s per-GPU shard
+               (16 antennas, 4 of the 32 PRNs per GPU, 1 ms @ 50 MHz)
 Multi-GPU: satellite channels shard with no collective; every rank holds the full antenna signal
-and correlates its own PRN ("weak" scaling: per-GPU work fixed).
+and correlates its own PRNs ("weak" scaling: per-GPU work fixed).  RCCL carries only the timing
+barrier and the max-over-ranks reduction.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,15 +41,25 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+F32_PEAK_TFLOPS = 157.3   # vector FP32 == f32-input MFMA peak (spec)
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (spec)
+
+PRESETS = {
+    1: {},
+    2: dict(gnss="GPSL5", num_samples=50000, num_ants=4, num_taps=5, channels=12, blocks=1024),
+    3: dict(gnss="GPSL1", num_samples=50000, num_ants=16, num_taps=3, channels=4, blocks=512),
+    4: dict(gnss="GPSL1", num_samples=2000000, num_ants=64, num_taps=3, channels=64, blocks=1, block_ms=20.0),
+}
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--settle", type=int, default=64, help="untimed launches before the warm-up steps (clock settle)")
+    ap.add_argument("--settle", type=int, default=64,
+                    help="untimed launches before the warm-up steps (clock settle); reported in the JSON line")
     ap.add_argument("--blocks", type=int, default=4096, help="B: 1 ms integration blocks per launch")
     ap.add_argument("--num-samples", type=int, default=20000)
     ap.add_argument("--num-ants", type=int, default=4)
@@ -51,25 +70,63 @@ def parse_args():
                     help="sample format: planar/interleaved ComplexF32 (headline), int16 / int8 ingest")
     ap.add_argument("--atomic", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shard-config3", action="store_true", help="N > 1: skip the configs[3] shard measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--block-ms", type=float, default=1.0, help="duration of one integration block (fs = N / block)")
     ap.add_argument("--baseline-config", type=int, choices=[1, 2, 3, 4], default=None,
                     help="shape of BASELINE.json configs[i] (1 = the default headline workload; 2 = GPS L5, 4 ants, 12 PRNs, "
                          "5 taps @ 50 MHz; 3 = the per-GPU shard of 16 ants x 32 PRNs @ 50 MHz; 4 = 64 ants x 64 channels, "
                          "20 ms @ 100 MHz); explicit shape flags still override nothing -- the preset wins")
-    args = ap.parse_args()
-    presets = {
-        1: {},
-        2: dict(gnss="GPSL5", num_samples=50000, num_ants=4, num_taps=5, channels=12, blocks=1024),
-        3: dict(gnss="GPSL1", num_samples=50000, num_ants=16, num_taps=3, channels=4, blocks=512),
-        4: dict(gnss="GPSL1", num_samples=2000000, num_ants=64, num_taps=3, channels=64, blocks=1, block_ms=20.0),
-    }
+    args = ap.parse_args(argv)
     if args.baseline_config is not None:
-        for k, v in presets[args.baseline_config].items():
+        for k, v in PRESETS[args.baseline_config].items():
             setattr(args, k, v)
         if args.baseline_config != 1:  # long launches: fewer timed steps keep the run short
             args.steps, args.warmup, args.settle = min(args.steps, 20), min(args.warmup, 3), min(args.settle, 4)
     return args
+
+
+# ----------------------------------------------------------------------------------------------
+# self-launch: python bench.py --gpus N without an external launcher
+# ----------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n: int) -> int:
+    """Start n ranks of this script as CHILD processes (no GPU call has happened in this process, and it
+    is never replaced by exec), forward rank 0's stdout, return the worst exit status."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GAT_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("GAT_BENCH_LAUNCH_TIMEOUT", "1500"))
+    for p in procs:
+        try:
+            code = p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()  # the exact child this process started
+            code = 124
+        rc = rc or code
+    return rc
+
+
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(args, host_re, host_im, prm, shifts, fs, system):
@@ -118,43 +175,73 @@ def cpu_baseline(args, host_re, host_im, prm, shifts, fs, system):
         "sample": f"first {max_blk} of {args.blocks} blocks of the same stream, repeated for {args.cpu_seconds / len(cands):.1f} s per thread count "
                   f"(N={N}, M={M}, L={args.num_taps}, K={args.channels}); oracle FP32 4-pass, gcc -O3 -march=native, OpenMP",
         "value_1_thread": round(rate_1t, 3), "by_threads": {str(k): round(v, 3) for k, v in rates.items()},
-        "host_threads": cores,
+        "host_threads": cores, "cpu_model": cpu_model(),
     }
 
 
-def main():
-    args = parse_args()
-    import torch
+def algorithmic_flops(B, N, M, L, K) -> float:
+    """SURVEY section 8-d: per (n, k) carrier phase + sincos ~ 30; per (n, m, k) complex x complex = 8;
+    per (n, m, k, l) +-1 complex MAC = 4."""
+    return float(B) * N * K * (30.0 + M * (8.0 + 4.0 * L))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            sys.exit(2)
-    if not torch.cuda.is_available():
-        print("bench.py: no HIP device", file=sys.stderr)
-        sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or os.environ.get("GAT_BENCH_FORCE_DIST") == "1":  # the latter: exercise the RCCL path on 1 GPU
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
+def roofline(shape, launch_s, matrix_core, traffic):
+    """max(bytes / HBM peak, flops / compute peak) vs the measured launch duration; names the winning term."""
     import gpuacceleratedtracking_amd as g
 
+    B, N, M, L, K, layout = shape
+    alg_bytes = g.algorithmic_bytes(B, N, M, L, K, g.SAMPLE_BYTES[layout])
+    flops = algorithmic_flops(B, N, M, L, K)
+    t_hbm = alg_bytes / (HBM_PEAK_GBS * 1e9)
+    t_f32 = flops / (F32_PEAK_TFLOPS * 1e12)
+    out = {"algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": flops,
+           "kernel_ms_per_launch": round(launch_s * 1e3, 6), "traffic": traffic,
+           "terms_ms": {"hbm": round(t_hbm * 1e3, 6), "f32_flops": round(t_f32 * 1e3, 6)},
+           "kernel": {0: "dc_kernel (vector)", 1: "mfma_kernel (f32 MFMA)", 2: "mfma_bf16_kernel (split-bf16 MFMA)"}.get(matrix_core, "?")}
+    if t_hbm >= t_f32:
+        ach = alg_bytes / launch_s / 1e9
+        out.update(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
+    else:
+        # compute roof: the f32 rate (vector FP32 == f32 MFMA, 157.3 TFLOP/s) bounds every formulation with f32
+        # accuracy at the algorithmic flop count; the split-bf16 kernel issues 8x the flops on the bf16 pipe
+        ach = flops / launch_s / 1e12
+        out.update(bound="mfma" if matrix_core else "vector-f32", achieved=round(ach, 2), peak=F32_PEAK_TFLOPS,
+                   unit="TFLOP/s", frac=round(ach / F32_PEAK_TFLOPS, 4))
+        if matrix_core == 2:
+            out["bf16_issue"] = {"executed_tflops": round(8 * 2.0 * 2 * M * 2 * K * L * N * B / launch_s / 1e12, 1),
+                                 "peak": BF16_PEAK_TFLOPS,
+                                 "note": "split-bf16: 8 bf16 products per f32 product, 2M x 2KL x N real GEMM"}
+    out["hbm_frac"] = round(alg_bytes / launch_s / 1e9 / HBM_PEAK_GBS, 4)
+    return out
+
+
+def stored_traffic(key):
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the microarchitecture guide), keyed by workload."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(tpath) as f:
+            tj = json.load(f)
+        for e in tj.get("entries", [tj]):
+            if e.get("workload_key") == key:
+                return e.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def measure(args, g, torch, dist, world, rank, shape_kw, steps, warmup, settle, want_host_copy):
+    """Build one stream + operator, run settle + warm-up + exactly `steps` timed launches between barriers."""
     layout = {"planar": g.GAT_LAYOUT_PLANAR, "interleaved": g.GAT_LAYOUT_INTERLEAVED,
-              "i16": g.GAT_LAYOUT_INTERLEAVED_I16, "i8": g.GAT_LAYOUT_INTERLEAVED_I8}[args.layout]
+              "i16": g.GAT_LAYOUT_INTERLEAVED_I16, "i8": g.GAT_LAYOUT_INTERLEAVED_I8}[shape_kw["layout"]]
     flags = g.GAT_FLAG_ATOMIC if args.atomic else 0
-    N, M, L, K, B = args.num_samples, args.num_ants, args.num_taps, args.channels, args.blocks
+    N, M, L, K, B = (shape_kw[k] for k in ("num_samples", "num_ants", "num_taps", "channels", "blocks"))
     # channel sharding: rank r correlates PRNs [r*K, (r+1)*K) of the constellation on a replicated signal
     plan = g.shard_channels(K * world, world, rank)
-    op, desc, sig, prm = g.build_stream(args.gnss, N, M, L, K, B, layout=layout, first_prn=plan.lo, flags=flags,
-                                        block_seconds=args.block_ms * 1e-3)
+    op, desc, sig, prm = g.build_stream(shape_kw["gnss"], N, M, L, K, B, layout=layout, first_prn=plan.lo, flags=flags,
+                                        block_seconds=shape_kw["block_ms"] * 1e-3)
     ctx = op.ctx
-    fs = N / (args.block_ms * 1e-3)
+    fs = N / (shape_kw["block_ms"] * 1e-3)
 
     def barrier():
         torch.cuda.synchronize()
@@ -164,62 +251,130 @@ def main():
 
     # clock / TLB settle: the first few dozen launches after the stream has been synthesised run 3-6 % slower
     # (0.41-0.42 ms instead of 0.395 ms at configs[1]); like the data generation this is untimed set-up, ahead of
-    # the contract's W warm-up steps, so that a short K still measures the steady state
-    for _ in range(args.settle):
+    # the contract's W warm-up steps, and its count is part of the printed record ("settle")
+    for _ in range(settle):
         op.launch(desc)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         op.launch(desc)
     barrier()
     t0 = time.perf_counter()
     ctx.timer_start()
-    for _ in range(args.steps):
+    for _ in range(steps):
         op.launch(desc)
     kernel_ms_total = ctx.timer_stop()  # HIP events on the launch stream; synchronises
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = [elapsed * 1e3 / steps]
     if dist is not None:
-        t = torch.tensor([elapsed, kernel_ms_total], dtype=torch.float64, device="cuda")
+        dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+        t = torch.tensor([elapsed, kernel_ms_total], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms_total = float(t[0]), float(t[1])
+        per_rank = [float(x[0]) * 1e3 / steps for x in gathered]
+    res = dict(op=op, desc=desc, sig=sig, prm=prm, ctx=ctx, fs=fs, layout=layout, shape=(B, N, M, L, K, layout),
+               elapsed=elapsed, launch_s=kernel_ms_total * 1e-3 / steps, per_rank_ms=per_rank, steps=steps)
+    return res
 
+
+def parity_check(g, m):
+    """Spot-check of the timed output against the FP64 oracle (first blocks; outside the timed region)."""
+    import oracle
+
+    B, N, M, L, K, layout = m["shape"]
+    sig, op, prm = m["sig"], m["op"], m["prm"]
+    host_blocks = min(B, 512)
+    if layout == g.GAT_LAYOUT_PLANAR:
+        h_re = sig[0][:, :host_blocks * N].cpu().numpy()
+        h_im = sig[1][:, :host_blocks * N].cpu().numpy()
+    else:
+        h = sig[0][:, :host_blocks * N, :].cpu().numpy().astype(np.float32)  # ints convert exactly
+        h_re, h_im = np.ascontiguousarray(h[..., 0]), np.ascontiguousarray(h[..., 1])
+    got = op.result()
+    oprm = oracle.make_params(prm["prn"], prm["code_freq_hz"], prm["carrier_freq_hz"],
+                              prm["code_phase_chips"], prm["carrier_phase_cycles"])
+    nchk = min(2, host_blocks)
+    ref = oracle.correlate_f64(h_re[:, :nchk * N], h_im[:, :nchk * N], op.system.codes, oprm[:nchk], m["fs"],
+                               op.shifts, N=N)
+    err = float(np.max(np.abs(got[:nchk] - ref) / np.abs(ref).max(axis=(2, 3), keepdims=True)))
+    return err, h_re, h_im
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        # no external launcher: become the launcher.  Nothing above has touched the GPU (torch is not even imported).
+        sys.exit(self_launch(args.gpus))
+
+    import torch
+
+    world = int(world_env or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    if os.environ.get("GAT_BENCH_DRYRUN") == "1":
+        # launcher rehearsal without a GPU (tests/test_bench_launcher.py): rendezvous, barrier, gather, one line
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo")
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": world, "ranks_seen": [int(x[0]) for x in got],
+                              "local_rank": local_rank}), flush=True)
+        dist.destroy_process_group()
+        return
+    if not torch.cuda.is_available():
+        print("bench.py: no HIP device", file=sys.stderr)
+        sys.exit(2)
+    # GAT_BENCH_SHARE_GPU=1: rehearsal of the N-rank path on a box with ONE GPU (every rank on device 0, gloo for the
+    # barrier because RCCL refuses two ranks on one device); never set by the driver
+    share = os.environ.get("GAT_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    if dev_index >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} needs device {dev_index}, only {torch.cuda.device_count()} visible", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(dev_index)
+    dist = None
+    backend = None
+    if world > 1 or os.environ.get("GAT_BENCH_FORCE_DIST") == "1":  # the latter: exercise the RCCL path on 1 GPU
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        backend = "gloo" if share else "nccl"
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend="gloo")
+
+    import gpuacceleratedtracking_amd as g
+
+    shape_kw = dict(gnss=args.gnss, num_samples=args.num_samples, num_ants=args.num_ants, num_taps=args.num_taps,
+                    channels=args.channels, blocks=args.blocks, layout=args.layout, block_ms=args.block_ms)
+    m = measure(args, g, torch, dist, world, rank, shape_kw, args.steps, args.warmup, args.settle, True)
+    B, N, M, L, K, layout = m["shape"]
+    fs = m["fs"]
+
+    out = None
     if rank == 0:
         total_samples = float(B) * N * K * world * args.steps
-        value = total_samples / elapsed / 1e6
-        launch_s = kernel_ms_total * 1e-3 / args.steps
-        alg_bytes = g.algorithmic_bytes(B, N, M, L, K, g.SAMPLE_BYTES[layout])
-        achieved = alg_bytes / launch_s / 1e9
-        info = ctx.last_launch_info()
-        # parity spot-check of the timed output against the FP64 oracle (first / last blocks)
-        import oracle
-        host_blocks = min(B, 512)
-        if layout == g.GAT_LAYOUT_PLANAR:
-            h_re = sig[0][:, :host_blocks * N].cpu().numpy()
-            h_im = sig[1][:, :host_blocks * N].cpu().numpy()
-        else:
-            h = sig[0][:, :host_blocks * N, :].cpu().numpy().astype(np.float32)  # ints convert exactly
-            h_re, h_im = np.ascontiguousarray(h[..., 0]), np.ascontiguousarray(h[..., 1])
-        got = op.result()
-        oprm = oracle.make_params(prm["prn"], prm["code_freq_hz"], prm["carrier_freq_hz"],
-                                  prm["code_phase_chips"], prm["carrier_phase_cycles"])
-        nchk = min(2, host_blocks)
-        ref = oracle.correlate_f64(h_re[:, :nchk * N], h_im[:, :nchk * N], op.system.codes, oprm[:nchk], fs,
-                                   op.shifts, N=N)
-        err = float(np.max(np.abs(got[:nchk] - ref) / np.abs(ref).max(axis=(2, 3), keepdims=True)))
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    tj = json.load(f)
-                if tj.get("workload_key") == [args.gnss, N, M, L, K, B, args.layout]:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        value = total_samples / m["elapsed"] / 1e6
+        info = m["ctx"].last_launch_info()
+        err, h_re, h_im = parity_check(g, m)
+        traffic = stored_traffic([args.gnss, N, M, L, K, B, args.layout])
         out = {
             "metric": "Msamples/s downconvert+correlate (E/P/L x ants x sats); real-time factor @ 1ms",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 6),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.layout in ("planar", "interleaved") else f"f32 (samples {args.layout})",
+            "warmup": args.warmup, "settle": args.settle, "ms_per_step": round(m["elapsed"] * 1e3 / args.steps, 6),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.layout in ("planar", "interleaved") else f"f32 (samples {args.layout})",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.gnss}, {M} ants, {K} PRN/GPU, {L} correlators, {args.block_ms:g} ms @ {fs / 1e6:g} MHz "
@@ -231,16 +386,41 @@ def main():
                 "launch": info,
             },
             "real_time_factor": round(value * 1e6 / fs / (K * world), 3),
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_per_launch": round(launch_s * 1e3, 6),
-            },
+            "roofline": roofline(m["shape"], m["launch_s"], info.get("matrix_core", 0), traffic),
             "parity_max_rel_err_vs_f64_oracle": err,
         }
+        if world > 1:
+            out["ranks"] = {"world_size": world, "backend": backend, "ms_per_step_by_rank": [round(x, 6) for x in m["per_rank_ms"]]}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, h_re, h_im, prm, op.shifts, fs, op.system)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(args, h_re, h_im, m["prm"], m["op"].shifts, fs, m["op"].system)
+    del m
+
+    # N > 1: the shape the 8-GPU node of BASELINE configs[3] runs -- 16 antennas, 32 PRNs sharded 4 per GPU, 50 MHz
+    if world > 1 and not args.no_shard_config3 and args.baseline_config is None:
+        torch.cuda.empty_cache()
+        kw3 = dict(PRESETS[3], layout="planar", block_ms=1.0)
+        steps3 = max(5, min(args.steps, 40))
+        m3 = measure(args, g, torch, dist, world, rank, kw3, steps3, min(args.warmup, 5), min(args.settle, 8), False)
+        if rank == 0:
+            B3, N3, M3, L3, K3, _ = m3["shape"]
+            v3 = float(B3) * N3 * K3 * world * steps3 / m3["elapsed"] / 1e6
+            info3 = m3["ctx"].last_launch_info()
+            err3, _, _ = parity_check(g, m3)
+            out["shard_config3"] = {
+                "workload": f"GPSL1, {M3} ants, {K3 * world} PRNs sharded {K3}/GPU over {world} GPUs, {L3} correlators, 1 ms @ "
+                            f"{m3['fs'] / 1e6:g} MHz, {B3} blocks/launch (BASELINE configs[3]: 32 PRNs at 8 GPUs)",
+                "value": round(v3, 3), "unit": "Msamples/s", "n_gpus": world, "steps": steps3,
+                "ms_per_step": round(m3["elapsed"] * 1e3 / steps3, 6),
+                "ms_per_step_by_rank": [round(x, 6) for x in m3["per_rank_ms"]],
+                "real_time_factor": round(v3 * 1e6 / m3["fs"] / (K3 * world), 3),
+                "rccl_world_size": world, "backend": backend, "launch": info3,
+                "roofline": roofline(m3["shape"], m3["launch_s"], info3.get("matrix_core", 0),
+                                     stored_traffic(["GPSL1", N3, M3, L3, K3, B3, "planar"])),
+                "parity_max_rel_err_vs_f64_oracle": err3,
+            }
+        del m3
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

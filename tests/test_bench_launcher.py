@@ -1,0 +1,62 @@
+"""bench.py's multi-rank launch paths, rehearsed on CPU (GAT_BENCH_DRYRUN=1: gloo rendezvous, barrier,
+all_gather, one JSON line from rank 0 -- no GPU call).  The driver starts N > 1 through
+torch.distributed.run; a plain `python bench.py --gpus N` must start its own N child processes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = dict(os.environ, GAT_BENCH_DRYRUN="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def _one_line(stdout: str) -> dict:
+    lines = [ln for ln in stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_self_launch_two_ranks():
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = _one_line(p.stdout)
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == [0, 1]
+
+
+def test_external_launcher_two_ranks():
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29653", BENCH, "--gpus", "2", "--steps", "2",
+                        "--warmup", "1"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = _one_line(p.stdout)
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == [0, 1]
+
+
+def test_world_size_mismatch_is_an_error():
+    env = dict(_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2 and "WORLD_SIZE" in p.stderr
+
+
+def test_roofline_names_the_winning_term():
+    """configs[1] is HBM-bound on paper, configs[2] (L5, 12 PRNs, 5 taps) and configs[4] are flop-bound."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    f1 = bench.algorithmic_flops(4096, 20000, 4, 3, 1)
+    b1 = 4096 * (8 * 20000 * 4 + 8 * 4 * 3)
+    assert b1 / 8e12 > f1 / 157.3e12
+    f3 = bench.algorithmic_flops(1024, 50000, 4, 5, 12)
+    b3 = 1024 * (8 * 50000 * 4 + 8 * 4 * 5 * 12)
+    assert f3 / 157.3e12 > b3 / 8e12
+    assert f3 == pytest.approx(8.72e10, rel=0.01)  # the figure VERDICT r01 quotes for configs[2]
