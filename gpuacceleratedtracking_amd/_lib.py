@@ -30,7 +30,7 @@ EXPORTS = [
     "gat_downconvert_and_correlate", "gat_downconvert_and_correlate_dev", "gat_gen_code_replica",
     "gat_gen_code_replica_f32coord",
     "gat_gen_signal", "gat_reduce_cplx_multi", "gat_tracking_update", "gat_malloc", "gat_free", "gat_memcpy_h2d",
-    "gat_memcpy_d2h", "gat_memset", "gat_timer_start", "gat_timer_stop", "gat_last_launch_info", "gat_set_matrix_core", "gat_tracking_run",
+    "gat_memcpy_d2h", "gat_memset", "gat_timer_start", "gat_timer_stop", "gat_last_launch_info", "gat_set_matrix_core", "gat_tracking_run", "gat_set_vector_tiling",
 ]
 
 
@@ -82,7 +82,8 @@ LOOP_STATE_DTYPE = np.dtype([(n, "<f8") for n in (
 
 class LaunchInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("workgroups", "threads", "splits", "ant_tile", "vec",
-                                          "lds_bytes", "finalize_launched", "matrix_core")]
+                                          "lds_bytes", "finalize_launched", "matrix_core", "channels_per_wg",
+                                          "blocks_per_wg")]
 
 
 _LIB = None
@@ -141,9 +142,12 @@ def load(build_if_missing: bool = True):
         "gat_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
         "gat_last_launch_info": (i32, [vp, C.POINTER(LaunchInfo)]),
         "gat_set_matrix_core": (i32, [vp, i32]),
+        "gat_set_vector_tiling": (i32, [vp, i32, i32, i32]),
     }
     assert sorted(sigs) == sorted(EXPORTS)
     for name, (res, args) in sigs.items():
+        if os.environ.get("GAT_LIBRARY") and not hasattr(lib, name):
+            continue  # A/B against an OLDER development build that predates a symbol (GAT_LIBRARY override only)
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args

@@ -13,8 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgat.so")
-SOURCES = ["gat_kernels.hip", "gat_mfma.hip", "gat_mfma_bf16.hip", "gat_api.cpp", "gat_codes.cpp"]
-HEADERS = [os.path.join(CSRC, "gat_internal.h"), os.path.join(ROOT, "include", "gat.h")]
+SOURCES = ["gat_dc_f0.hip", "gat_dc_f1.hip", "gat_dc_f2.hip", "gat_dc_f3.hip", "gat_kernels.hip", "gat_mfma.hip",
+           "gat_mfma_bf16.hip", "gat_api.cpp", "gat_codes.cpp"]
+HEADERS = [os.path.join(CSRC, "gat_internal.h"), os.path.join(CSRC, "gat_phase.h"), os.path.join(CSRC, "gat_dc.h"),
+           os.path.join(ROOT, "include", "gat.h")]
 
 
 def hipcc_path() -> str:
@@ -34,7 +36,7 @@ def _flags(extra: tuple[str, ...] = ()) -> list[str]:
 def command(out: str = LIB) -> list[str]:
     """The one-line recipe (what INTEGRATION.md quotes); build_libgat() runs the same flags per source
     so that an edit to one kernel file does not recompile the others."""
-    return [hipcc_path(), *_flags(), "-shared", *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
+    return [hipcc_path(), *_flags(), "-fno-slp-vectorize", "-shared", *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
 
 
 def is_stale(lib: str = LIB) -> bool:
@@ -59,19 +61,31 @@ def build_libgat(force: bool = False, verbose: bool = False, extra_flags: tuple[
     os.makedirs(os.path.dirname(out), exist_ok=True)
     hdr_t = max(os.path.getmtime(h) for h in HEADERS + [os.path.abspath(__file__)])
     jobs, objs = [], []
+    dc_only = bool(extra_flags) and all(f.startswith("-DGAT_DC_") for f in extra_flags)
+    base_objdir = os.path.join(ROOT, "build", "obj")
+    os.makedirs(base_objdir, exist_ok=True)
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        # flags that only touch the fused vector kernel (-DGAT_DC_*): every other object is shared with the main build
+        shared = dc_only and not src.startswith("gat_dc_f")
+        obj = os.path.join(base_objdir if shared else objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
+        if shared:
+            extra_here = ()
+        else:
+            extra_here = extra_flags
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(sp), hdr_t):
-            jobs.append([hipcc_path(), *_flags(extra_flags), "-c", sp, "-o", obj])
+            # the fused vector kernel is written with scalar FMAs on purpose (gat_dc.h): keep the SLP vectoriser from
+            # re-packing them into v_pk_fma_f32 + operand-pairing moves
+            per_file = ("-fno-slp-vectorize",) if src.startswith("gat_dc_f") else ()
+            jobs.append([hipcc_path(), *_flags(tuple(extra_here) + per_file), "-c", sp, "-o", obj])
 
     def run(cmd):
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
         list(ex.map(run, jobs))
     run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out])
     return out
@@ -90,6 +104,12 @@ def build_c_example(force: bool = False) -> str:
 
 if __name__ == "__main__":
     import sys
+
+    if "--variant" in sys.argv:  # development: python -m ...build --variant NAME -DGAT_DC_DEV -D... -> build/libgat_NAME.so
+        i = sys.argv.index("--variant")
+        name, flags = sys.argv[i + 1], tuple(a for a in sys.argv[i + 2:] if a.startswith("-"))
+        print(build_libgat(extra_flags=flags, out=os.path.join(ROOT, "build", f"libgat_{name}.so"), verbose=False))
+        sys.exit(0)
 
     if "--stamps" in sys.argv:  # diagnostic build of the matrix kernels with per-wave cycle stamps
         print(build_libgat(extra_flags=("-DGAT_MFMA_STAMPS",), out=os.path.join(ROOT, "build", "libgat_stamps.so"),

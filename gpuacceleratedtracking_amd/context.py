@@ -74,6 +74,11 @@ class Context:
         3 = split-bf16 MFMA kernel only."""
         self.check(self.lib.gat_set_matrix_core(self._h, int(mode)), "gat_set_matrix_core")
 
+    def set_vector_tiling(self, max_antenna_tiles: int = 0, max_channels: int = 0, max_blocks: int = 0):
+        """Caps on the vector kernel's workgroup tiling (include/gat.h gat_set_vector_tiling; 0 = unchanged)."""
+        self.check(self.lib.gat_set_vector_tiling(self._h, int(max_antenna_tiles), int(max_channels), int(max_blocks)),
+                   "gat_set_vector_tiling")
+
     def timer_start(self):
         self.check(self.lib.gat_timer_start(self._h), "gat_timer_start")
 

@@ -41,6 +41,7 @@ struct gat_ctx {
     int num_cus = 256;
     unsigned long long *dbg_ptr = nullptr; // diagnostic builds only
     int max_ant_tile = kMaxAntTile; // env GAT_MAX_ANT_TILE (experiments)
+    int max_aw = 4, max_kt = 4, max_bpw = 16; // env GAT_DC_AW / GAT_DC_KT / GAT_DC_BPW: caps of the vector kernel's geometry
     int mc_mode = 1; // GAT_MC_* kernel selection (gat_set_matrix_core); env GAT_NO_MFMA=1 starts at 0
     std::string err;
     gat_launch_info last{};
@@ -114,8 +115,6 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             MT = mt;
             break;
         }
-    const int AT = M / MT;
-
     // 16-byte vector loads need every group start 16-byte aligned: plane bases and all strides
     // multiples of the samples one 16-byte load holds (4 / 2 / 4 / 8 by format)
     const int spv = dc_group_samples(4, fmt);
@@ -125,6 +124,10 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         vec = 4;
 
     const long long N = sig->num_samples;
+    // The vector kernel addresses a wave's antennas as one 32-bit scalar offset each from the tile's first antenna:
+    // streams whose antenna planes lie 4 GB or more apart, and unaligned input (scalar loads), run one antenna per wave
+    const long long sample_bytes_plane = fmt == GAT_LAYOUT_PLANAR ? 4 : fmt == GAT_LAYOUT_INTERLEAVED ? 8 : fmt == GAT_LAYOUT_INTERLEAVED_I16 ? 4 : 2;
+    if (vec != 4 || (long long)(MT - 1) * sig->ant_stride * sample_bytes_plane + N * sample_bytes_plane >= (1ll << 32)) MT = 1;
 
     // ---- matrix-core paths: antenna-rich shapes whose (channel, tap) columns fill a useful part of
     // a 32-column tile run on the matrix cores -- the split-bf16 kernel (gat_mfma_bf16.hip) by default,
@@ -273,14 +276,50 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             c->last.lds_bytes = (int32_t)lds;
             c->last.finalize_launched = fin_m ? 1 : 0;
             c->last.matrix_core = kind;
+            c->last.channels_per_wg = kind == 2 ? m.nslots : nct * CT;
+            c->last.blocks_per_wg = 1;
             return GAT_OK;
         }
     }
     c->last.matrix_core = 0;
 
-    const long long chunk = dc_chunk(vec, fmt);
+    // ---- vector kernel (gat_dc.h): launch geometry ---------------------------------------------------------
+    // aw: antenna tiles (waves) per workgroup -- 16 antennas on 4 waves walk the same samples, so carrier and replica
+    //     are produced once per workgroup; kt: channels a workgroup loops over with the samples held in registers.
+    const int AT = M / MT;
+    int aw = 1, kt = 1;
+    if (vec == 4 && MT == 4) aw = AT % 4 == 0 ? 4 : (AT % 2 == 0 ? 2 : 1);
+    aw = std::min(aw, c->max_aw);
+    if (vec == 4 && aw == 4 && sig->chan_stride == 0 && K > 1) kt = K >= 3 ? 4 : 2;
+    kt = std::min(kt, c->max_kt);
+    // tap launches: sorted taps cut into groups of <= kMaxTapsPerLaunch whose span fits the LDS replica segment
+    int order[GAT_MAX_TAPS];
+    for (int l = 0; l < L; ++l) order[l] = l;
+    std::stable_sort(order, order + L, [&](int x, int y) { return shifts[x] < shifts[y]; });
+    int max_taps = 1; // taps of the widest launch (register accumulators 2 * MT * taps * kt)
+    for (int t0 = 0; t0 < L;) {
+        int t1 = t0 + 1;
+        while (t1 < L && t1 - t0 < kMaxTapsPerLaunch && (long long)shifts[order[t1]] - shifts[order[t0]] <= kMaxReplicaSpan) ++t1;
+        max_taps = std::max(max_taps, t1 - t0);
+        t0 = t1;
+    }
+    while (kt > 1 && !dc_has_instance(MT, max_taps, vec, aw, kt)) kt >>= 1;
+    while (aw > 1 && !dc_has_instance(MT, max_taps, vec, aw, kt)) aw >>= 1;
+    // LDS: two workgroups per CU at least (80 KB each); a chip table that does not even fit alone is an error
+    auto lds_of = [&](int kt_, int aw_) {
+        const int ch = dc_chunk(vec, fmt, aw_);
+        return dc_lds_bytes(kt_, c->code_row_stride, dc_rep_plane_stride(ch, dc_segment_steps(ch, kt_, 1 << 30), kMaxReplicaSpan));
+    };
+    while (kt > 1 && lds_of(kt, aw) > 80 * 1024) kt >>= 1;
+    if (lds_of(kt, aw) > 160 * 1024)
+        return fail(c, GAT_ERR_RANGE, "code table too long for the LDS-resident chip table of the vector kernel");
+    if (!dc_has_instance(MT, max_taps, vec, aw, kt)) return fail(c, GAT_ERR_UNSUPPORTED, "no kernel instance for this shape");
+    const int AG = AT / aw;
+    const int KG = (K + kt - 1) / kt;
+
+    const long long chunk = dc_chunk(vec, fmt, aw);
     const long long chunks = (N + chunk - 1) / chunk;
-    const long long groups = (long long)B * K * AT;
+    const long long groups = (long long)B * KG * AG;
     const long long target = 8ll * c->num_cus;
     long long splits = std::max<long long>(1, (target + groups - 1) / groups);
     splits = std::min(splits, chunks);
@@ -288,8 +327,17 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     if (chunks <= 4 && !(flags & GAT_FLAG_ATOMIC)) splits = 1;
     const long long cps = (chunks + splits - 1) / splits;
     splits = (chunks + cps - 1) / cps;
-    const long long tiles = (long long)B * AT * splits;
-    const long long grid_wgs = ((tiles + 7) / 8) * 8 * K;
+    // short blocks in a long stream: one workgroup loops over several consecutive blocks (chip table, channel set-up
+    // and the workgroup launch are paid once) while the chip stays filled 16 workgroups deep per CU
+    long long bpw = 1;
+    if (splits == 1 && c->max_bpw > 1) {
+        const long long by_fill = std::max<long long>(1, groups / (16ll * c->num_cus));
+        const long long by_len = std::max<long long>(1, 16 / chunks);
+        bpw = std::min<long long>(std::min(by_fill, by_len), c->max_bpw);
+    }
+    const long long BG = (B + bpw - 1) / bpw;
+    const long long tiles = BG * AG * splits;
+    const long long grid_wgs = ((tiles + 7) / 8) * 8 * KG;
     if (grid_wgs >= (1ll << 31)) return fail(c, GAT_ERR_RANGE, "grid too large");
 
     const bool atomic = (flags & GAT_FLAG_ATOMIC) != 0;
@@ -321,29 +369,29 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     a.Lc = c->Lc;
     a.num_prns = c->P;
     a.code_row_stride = c->code_row_stride;
+    a.KG = KG;
     a.splits = (int)splits;
     a.chunks_per_split = (int)cps;
     a.total_chunks = (int)chunks;
-    a.ant_tiles = AT;
+    a.ant_groups = AG;
+    a.blocks_per_wg = (int)bpw;
     a.num_tiles = (int)tiles;
     a.Ltot = L;
     a.flags = flags;
+    a.keep_l2 = KG > 1 && sig->chan_stride == 0;
+    a.max_abs_shift = (int)max_shift;
 
     DcLaunch cfg{};
     cfg.ant_tile = MT;
+    cfg.aw = aw;
+    cfg.kt = kt;
     cfg.vec = vec;
     cfg.format = fmt;
-    cfg.keep_l2 = K > 1 && sig->chan_stride == 0;
     cfg.grid = (unsigned)grid_wgs;
-    a.max_abs_shift = (int)max_shift;
+    a.seg_steps = dc_segment_steps((int)chunk, kt, (int)cps);
 
-    // Taps in any order: sort them, then cut the sorted list into launches of at most
-    // kMaxTapsPerLaunch taps whose span fits the LDS replica segment; tap_index maps each tap back
-    // to its position in the caller's list (a single-tap launch always fits: span 0).
-    int order[GAT_MAX_TAPS];
-    for (int l = 0; l < L; ++l) order[l] = l;
-    std::stable_sort(order, order + L, [&](int x, int y) { return shifts[x] < shifts[y]; });
-    int nlaunch = 0;
+    // Taps in any order: tap_index maps each tap of a launch back to its position in the caller's list
+    // (a single-tap launch always fits: span 0).
     for (int t0 = 0; t0 < L;) {
         int t1 = t0 + 1;
         while (t1 < L && t1 - t0 < kMaxTapsPerLaunch &&
@@ -355,15 +403,16 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             a.tap_index[l] = order[t0 + std::min(l, cfg.taps - 1)];
         }
         a.rep_span = a.shifts[cfg.taps - 1] - a.shifts[0];
-        const int slots = (int)((chunk + a.rep_span + 3) / 4);
-        a.rep_plane_stride = ((slots + 23) / 32) * 32 + 8; // >= slots, == 8 (mod 32)
-        cfg.lds_bytes = (unsigned)(((c->Lc + 15) & ~15) + 4 * 64 * sizeof(float) +
-                                   (size_t)2 * 4 * a.rep_plane_stride * sizeof(float));
+        // replica producers: kThreads / kt threads per channel, a quarter of them per plane; slots per thread and segment
+        const int per_plane = kThreads / kt / 4;
+        const long long seg_slots = (a.seg_steps * chunk + a.rep_span + 3) / 4;
+        a.rep_run = (int)((seg_slots + per_plane - 1) / per_plane);
+        a.rep_plane_stride = kt == 1 ? dc_rep_plane_stride((int)chunk, a.seg_steps, a.rep_span)
+                                     : dc_rep_plane_stride((int)chunk, dc_segment_steps((int)chunk, kt, 1 << 30), kMaxReplicaSpan);
+        cfg.lds_bytes = (unsigned)dc_lds_bytes(kt, c->code_row_stride, a.rep_plane_stride);
         GAT_HIP(c, launch_dc(a, cfg, c->stream));
         t0 = t1;
-        ++nlaunch;
     }
-    (void)nlaunch;
     const bool fin = !atomic && splits > 1;
     if (fin)
         GAT_HIP(c, launch_finalize(c->d_partial, out_re, out_im, (int)splits, L * M * 2, (long long)B * K,
@@ -372,10 +421,12 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     c->last.workgroups = (int32_t)cfg.grid;
     c->last.threads = kThreads;
     c->last.splits = (int32_t)splits;
-    c->last.ant_tile = MT;
+    c->last.ant_tile = MT * aw;
     c->last.vec = vec;
     c->last.lds_bytes = (int32_t)cfg.lds_bytes;
     c->last.finalize_launched = fin ? 1 : 0;
+    c->last.channels_per_wg = kt;
+    c->last.blocks_per_wg = (int32_t)bpw;
     return GAT_OK;
 }
 
@@ -449,6 +500,9 @@ GAT_API int32_t gat_create(int32_t device, void *hip_stream, gat_ctx **out_ctx)
     if (hipMalloc(&c->d_zeros, 64) == hipSuccess) (void)hipMemset(c->d_zeros, 0, 64);
     if (const char *e = std::getenv("GAT_NO_MFMA")) c->mc_mode = e[0] == '1' ? 0 : 1;
     if (const char *e = std::getenv("GAT_MAX_ANT_TILE")) c->max_ant_tile = std::min(kMaxAntTile, std::max(1, std::atoi(e)));
+    if (const char *e = std::getenv("GAT_DC_AW")) c->max_aw = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("GAT_DC_KT")) c->max_kt = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("GAT_DC_BPW")) c->max_bpw = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("GAT_MC_MODE")) c->mc_mode = (e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
         delete c;
@@ -829,6 +883,16 @@ GAT_API int32_t gat_set_matrix_core(gat_ctx *c, int32_t enable)
     if (!c) return GAT_ERR_ARG;
     if (enable < GAT_MC_VECTOR || enable > GAT_MC_BF16_SPLIT) return fail(c, GAT_ERR_ARG, "unknown matrix-core mode");
     c->mc_mode = enable;
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_set_vector_tiling(gat_ctx *c, int32_t max_antenna_tiles, int32_t max_channels, int32_t max_blocks)
+{
+    if (!c) return GAT_ERR_ARG;
+    if (max_antenna_tiles < 0 || max_channels < 0 || max_blocks < 0) return fail(c, GAT_ERR_ARG, "negative cap");
+    if (max_antenna_tiles) c->max_aw = max_antenna_tiles >= 4 ? 4 : (max_antenna_tiles >= 2 ? 2 : 1);
+    if (max_channels) c->max_kt = max_channels >= 4 ? 4 : (max_channels >= 2 ? 2 : 1);
+    if (max_blocks) c->max_bpw = max_blocks;
     return GAT_OK;
 }
 

@@ -1,0 +1,704 @@
+// gat_dc.h -- the fused downconvert + correlate kernel of libgat (vector path), gfx950 / wave64.
+//
+// What is computed (reference: downconvert_and_correlate_kernel_1330!, src/algorithms.jl:170-187;
+// replica convention of kernel 5431, src/algorithms.jl:752-758; equation paper/paper.tex:48-52):
+//
+//   R[m,l,k,b] = sum_n x[n,m,b] * conj(exp(j2pi(n*f/fs + phi))) * c_k[floor(fc/fs*(n+shift_l)+tau) mod Lc]
+//
+// How (CDNA4-first, not the reference's shared-memory tree per sample):
+//   * workgroup = 4 wave64 on one (integration block, antenna group, sample split) and KT channels.  Wave w owns
+//     antenna tile (w % AW) -- MT <= 4 antennas -- and sample sub-chunk (w / AW): with AW = 4 the four waves walk the
+//     SAME samples on 16 antennas and share one code replica;
+//   * every lane owns S consecutive samples per group and loads them as ONE 16-byte buffer load per antenna plane
+//     (1 KiB per wave-instruction in every sample format; one descriptor per plane, a 32-bit lane offset shared by all
+//     loads of a step, a scalar offset per antenna; cache policy = template parameter: non-temporal when the tile is
+//     read once, plain when several channel groups share it through L2);
+//   * the samples of step c+1 are fetched while step c is consumed, antenna by antenna, into the registers that
+//     antenna's samples have just left: loads are in flight all the time without a second register set; with KT > 1
+//     the samples stay in registers while the workgroup loops over its channels (AW = 4 only: measured, a channel
+//     loop over a single antenna tile never beat separate channel workgroups sharing the tile through L2);
+//   * code replica: produced for a SEGMENT of up to 8 steps at once into LDS ([steps*CHUNK + tap span] chips per
+//     channel), by an EXACT walk (gat_phase.h): one double-precision anchor per producer run, then 32.32 fixed-point
+//     steps, branch-free; a batch holding a step that is not proven equal to the reference's floor is re-evaluated with
+//     the reference's expression -- bit-identical chip edges to the CPU oracle at ~1/2 of the vector instructions and
+//     none of the double-precision ones of evaluating floor(ratio*(n+shift)+tau) per sample.  Two barriers per segment,
+//     none in the step loop.  Stored as 4 interleaved planes (entry i at plane i&3, slot i>>2) so that lanes owning
+//     samples 4*lane + j read consecutive dwords (no bank conflict); a producer thread fills consecutive slots of
+//     ONE plane;
+//   * carrier: one phasor per group, anchored in double precision at every segment start, carried from step to step
+//     by one complex rotation, S-1 rotations inside the group; no per-(antenna, tap) double-precision sincos as in
+//     the reference (src/algorithms.jl:172);
+//   * KT x MT x L complex accumulators stay in registers for the whole block (plain scalar FMAs: the packed form
+//     issues at the same rate and costs operand-pairing moves); ONE reduction per block: a butterfly that halves the
+//     value count at each of the 6 wave64 shuffle steps, then the waves that share an antenna tile through LDS;
+//   * the result is written once (deterministic).  When a block is split over several workgroups (small batch),
+//     per-split partials are summed by finalize_kernel in fixed order; GAT_FLAG_ATOMIC uses float atomics instead
+//     (reference alg. 4/5); short blocks: one workgroup walks several consecutive blocks (chip table staged once,
+//     sample prefetch continues across the block boundary).
+#pragma once
+
+#include <type_traits>
+
+#include "gat_internal.h"
+#include "gat_phase.h"
+
+namespace gat {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// Butterfly reduce-scatter over one wave64: NV per-lane values -> after 6 steps each lane
+// holds the full wave sum of ONE value; 25 shuffles for NV = 24 instead of 144.  At a step with
+// offset OFF, values 2i / 2i+1 are paired: the lane whose OFF bit is clear keeps 2i and sends
+// 2i+1, its partner does the opposite; an odd leftover is all-reduced.  Which value a lane ends
+// up with is a function of its lane id only (butterfly_index) -- no index array travels with the
+// values (it would double the register footprint of the epilogue, the kernel's pressure peak).
+template <int NV, int OFF>
+struct Butterfly {
+    static __device__ __forceinline__ void run(float *v, int lane)
+    {
+        constexpr int H = NV / 2;
+        const bool up = (lane & OFF) != 0;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            // load both operands unconditionally: a ternary on the array elements themselves is
+            // turned into a dynamically indexed (scratch) access by the compiler
+            const float lo = v[2 * i], hi = v[2 * i + 1];
+            const float keep = up ? hi : lo;
+            const float send = up ? lo : hi;
+            v[i] = keep + __shfl_xor(send, OFF, 64);
+        }
+        if constexpr (NV & 1) v[H] = v[NV - 1] + __shfl_xor(v[NV - 1], OFF, 64);
+        Butterfly<(NV + 1) / 2, OFF / 2>::run(v, lane);
+    }
+    // original index of the value that ends in slot `slot` after this and all later steps
+    static __device__ __forceinline__ int index(int lane)
+    {
+        const int j = Butterfly<(NV + 1) / 2, OFF / 2>::index(lane); // slot before the later steps
+        constexpr int H = NV / 2;
+        if ((NV & 1) && j == H) return NV - 1;
+        return 2 * j + ((lane & OFF) ? 1 : 0);
+    }
+};
+template <int NV>
+struct Butterfly<NV, 0> {
+    static __device__ __forceinline__ void run(float *, int) {}
+    static __device__ __forceinline__ int index(int) { return 0; } // the survivor sits in slot 0
+};
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// wave-uniform values computed on the vector ALU go back to scalar registers
+__device__ __forceinline__ float uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ unsigned uni(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ double uni(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const unsigned lo = uni((unsigned)b), hi = uni((unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ unsigned long long uni(unsigned long long b)
+{
+    const unsigned lo = uni((unsigned)b), hi = uni((unsigned)(b >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// FMT: sample format of the signal (GAT_LAYOUT_*): planar f32, interleaved ComplexF32,
+// interleaved int16 pairs, interleaved int8 pairs.  VEC = 4: one 16-byte load per
+// lane, plane and group (4 / 2 / 4 / 8 complex samples); VEC = 1: scalar loads (unaligned input).
+// Sample loads are non-temporal when every byte is used once (one workgroup per signal tile: + 7 % at configs[1]),
+// plain when several channel groups are to find the tile in L2 (+ 4-9 % with 8-12 channels).
+template <int FMT>
+struct SampleIO {
+    // number of 16-byte vectors per antenna and group
+    static constexpr int NV = (FMT == GAT_LAYOUT_PLANAR) ? 2 : 1;
+    // bytes of one complex sample
+    static constexpr int BYTES = (FMT == GAT_LAYOUT_INTERLEAVED_I16) ? 4 : (FMT == GAT_LAYOUT_INTERLEAVED_I8) ? 2 : 8;
+
+    template <bool KEEP>
+    static __device__ __forceinline__ i32x4 ld(const i32x4 *p)
+    {
+        if constexpr (KEEP) return *p;
+        else return __builtin_nontemporal_load(p);
+    }
+    // 16-byte loads of the group starting at complex-sample index e
+    template <bool KEEP>
+    static __device__ __forceinline__ void load16(i32x4 (&raw)[NV], const void *re, const void *im, size_t e)
+    {
+        if constexpr (FMT == GAT_LAYOUT_PLANAR) {
+            raw[0] = ld<KEEP>(reinterpret_cast<const i32x4 *>(static_cast<const float *>(re) + e));
+            raw[1] = ld<KEEP>(reinterpret_cast<const i32x4 *>(static_cast<const float *>(im) + e));
+        } else {
+            raw[0] = ld<KEEP>(reinterpret_cast<const i32x4 *>(static_cast<const unsigned char *>(re) + e * BYTES));
+        }
+    }
+    // sample j of a loaded group
+    static __device__ __forceinline__ void get(const i32x4 (&raw)[NV], int j, float &xr, float &xi)
+    {
+        // NOTE: copy the vector element into a scalar BEFORE the bit cast: __builtin_bit_cast applied
+        // directly to an ext-vector element lvalue reads element 0 whatever the index (hipcc 7.2).
+        if constexpr (FMT == GAT_LAYOUT_PLANAR) {
+            const int wr_ = raw[0][j], wi_ = raw[1][j];
+            xr = __int_as_float(wr_);
+            xi = __int_as_float(wi_);
+        } else if constexpr (FMT == GAT_LAYOUT_INTERLEAVED) {
+            const int wr_ = raw[0][2 * j], wi_ = raw[0][2 * j + 1];
+            xr = __int_as_float(wr_);
+            xi = __int_as_float(wi_);
+        } else if constexpr (FMT == GAT_LAYOUT_INTERLEAVED_I16) {
+            const int w = raw[0][j]; // {re: low half, im: high half}, little endian
+            xr = (float)(short)(w & 0xffff);
+            xi = (float)(w >> 16);
+        } else {
+            const int w = raw[0][j >> 1] >> ((j & 1) * 16); // two complex int8 samples per dword
+            xr = (float)(signed char)(w & 0xff);
+            xi = (float)(signed char)((w >> 8) & 0xff);
+        }
+    }
+    // one sample with scalar loads
+    static __device__ __forceinline__ void load1(const void *re, const void *im, size_t e, float &xr, float &xi)
+    {
+        if constexpr (FMT == GAT_LAYOUT_PLANAR) {
+            xr = static_cast<const float *>(re)[e];
+            xi = static_cast<const float *>(im)[e];
+        } else if constexpr (FMT == GAT_LAYOUT_INTERLEAVED) {
+            xr = static_cast<const float *>(re)[2 * e];
+            xi = static_cast<const float *>(re)[2 * e + 1];
+        } else if constexpr (FMT == GAT_LAYOUT_INTERLEAVED_I16) {
+            xr = (float)static_cast<const short *>(re)[2 * e];
+            xi = (float)static_cast<const short *>(re)[2 * e + 1];
+        } else {
+            xr = (float)static_cast<const signed char *>(re)[2 * e];
+            xi = (float)static_cast<const signed char *>(re)[2 * e + 1];
+        }
+    }
+};
+
+
+// Occupancy hint: instances with up to 40 accumulator registers come out at 150-170 registers; asking for three waves
+// per SIMD (<= 168) costs them nothing, while the four-antenna five-tap instance otherwise lands ONE register over
+// that step.  No bound for the larger instances, and never a tighter one: the allocator then spills into the step loop
+// (measured in both rounds: 1.2-3x slower).
+constexpr int dc_min_waves(int mt, int l, int kt) { return 2 * mt * l * kt <= 40 ? 3 : 1; }
+
+template <int MT, int L, int VEC, int FMT, int AW, int KT, bool KEEP>
+__global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(const DcArgs a)
+{
+    using IO = SampleIO<FMT>;
+    // A lane owns G groups of S consecutive samples per step; one group = one 16-byte load per plane.
+    constexpr int S = dc_group_samples(VEC, FMT);
+    constexpr int G = dc_groups(VEC, FMT);
+    constexpr int SUBS = 4 / AW;        // sample sub-chunks per workgroup (waves that share an antenna tile)
+    constexpr int VT = 64 * SUBS;       // lanes that share an antenna tile
+    constexpr int GSTRIDE = VT * S;
+    constexpr int CHUNK = GSTRIDE * G;
+    static_assert(CHUNK == dc_chunk(VEC, FMT, AW), "host and device disagree on the chunk size");
+    constexpr int RPC = kThreads / KT;  // replica producer threads per channel (>= 64: a wave serves one channel)
+    constexpr int NV = 2 * MT * L;      // values of one channel's reduction, id = (l*MT + m)*2 + {0: re, 1: im}
+    constexpr int EB = (FMT == GAT_LAYOUT_PLANAR) ? 4 : IO::BYTES; // bytes per sample in one plane
+    static_assert(NV <= 64, "one value per lane after the butterfly");
+    static_assert(AW == 1 || AW == 2 || AW == 4, "antenna-tile waves");
+    static_assert(KT == 1 || KT == 2 || KT == 4, "channels per workgroup");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    struct ChanConst { double ratio, tau, step, phi; }; // per channel slot: read at segment starts and on ragged ends
+    ChanConst *s_const = reinterpret_cast<ChanConst *>(smem);                          // [KT]
+    float *s_part = reinterpret_cast<float *>(smem + KT * sizeof(ChanConst));          // [KT][4][64]
+    float *s_rep = s_part + KT * 4 * 64;                                               // [KT][4][RPS]
+    const int SEG = a.seg_steps;        // steps whose replica is produced at once (host: LDS budget, block length)
+    // floats per replica plane: sized by the host for the segment of THIS launch when one channel is walked (short
+    // blocks then leave LDS for more workgroups per CU); compile-time with several channels, so that a channel's
+    // replica is an immediate offset from the first one's (scalar registers are scarce there)
+    const int RPS = KT == 1 ? a.rep_plane_stride : dc_rep_plane_stride(CHUNK, dc_segment_steps(CHUNK, KT, 1 << 30), kMaxReplicaSpan);
+    int8_t *s_code = reinterpret_cast<int8_t *>(s_rep + KT * 4 * RPS);                 // [KT][code_row_stride]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = uni(tid >> 6);
+    const int at_w = wave % AW;  // antenna tile of this wave inside the workgroup's antenna group
+    const int sub = wave / AW;   // sample sub-chunk of this wave
+    const int vt = sub * 64 + lane;
+    const int rel0 = vt * S;
+
+    // Workgroup -> (tile, channel group).  A tile = (block group, antenna group, split): the bytes the KG channel
+    // groups share.  Blocks id and id+8 land on the same XCD (round-robin dispatch), so the KG workgroups of one
+    // tile get ids tile%8 + 8*(kg + KG*(tile/8)): same XCD, dispatched back to back -> the tile comes from HBM
+    // once and from that XCD's L2 for the other KG-1 channel groups.  (Speed only: nothing depends on placement.)
+    const unsigned xcd = blockIdx.x & 7u, jq = blockIdx.x >> 3;
+    const int kg = (int)(jq % (unsigned)a.KG);
+    unsigned tile = (jq / (unsigned)a.KG) * 8u + xcd;
+    if (tile >= (unsigned)a.num_tiles) return; // padding of the last group of 8 (whole workgroup exits)
+    const int split = tile % a.splits;
+    tile /= a.splits;
+    const int ag = tile % a.ant_groups;
+    const int bg = tile / a.ant_groups;
+
+    const int Lc = a.Lc;
+    const int N = (int)a.N;
+    const float inv_lc = 1.0f / (float)Lc;
+    const int shift0 = a.shifts[0];
+
+    // replica producer role of this thread: channel slot gk (wave-uniform), plane gp, slots [gs0, gs0 + run)
+    // of every segment; entry i = 4 * slot + plane <-> sample (segment start) + shift0 + i
+    const int gk = uni(tid / RPC);
+    const int gp = tid & 3;
+    const int run = a.rep_run; // slots per producer thread and segment
+    const int gs0 = ((tid % RPC) >> 2) * run;
+
+    const int c_begin = split * a.chunks_per_split;
+    const int c_end = min(c_begin + a.chunks_per_split, a.total_chunks);
+    // steps whose chunk lies completely inside the block take the vector path; the ragged last chunk (and everything
+    // when the input is not 16-byte aligned: VEC == 1) takes the per-group path
+    const int c_full = VEC == 4 ? max(c_begin, min(c_end, N / CHUNK)) : c_begin;
+    int staged_prn[KT];
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) staged_prn[kk] = -1;
+    i32x4 raw[G][MT][IO::NV]; // the samples of the step being consumed / in flight for the next one
+    bool preloaded = false;   // the previous block's last step has already fetched this block's first chunk
+
+    for (int bb = 0; bb < a.blocks_per_wg; ++bb) {
+        const int b = bg * a.blocks_per_wg + bb;
+        if (b >= a.B) break;
+        const bool next_block = bb + 1 < a.blocks_per_wg && b + 1 < a.B && c_begin < c_full; // splits == 1 here
+
+        // ---- per-channel constants of this block --------------------------------------------------------------
+        // The double-precision ones (code rate, code phase, carrier step, carrier phase) are needed at segment starts
+        // and on ragged ends only: they live in LDS.  In registers (wave-uniform -> scalar): the one-sample and
+        // one-step carrier rotations.  (The previous block's last reads of s_const precede its reduction barrier.)
+        float wr_k[KT], wi_k[KT], cwr_k[KT], cwi_k[KT];
+        unsigned valid_mask = 0, bad_mask = 0;
+        bool restage = false;
+        int prn_k[KT];
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            const int k = kg * KT + kk;
+            const bool valid = k < a.K;
+            const gat_channel_params P = a.params[(size_t)b * a.K + (valid ? k : a.K - 1)];
+            double ratio = P.code_freq_hz / a.fs;         // src/algorithms.jl:179 (Float64 division)
+            double tau = P.code_phase_chips;
+            double step = P.carrier_freq_hz / a.fs;       // cycles per sample
+            double phi = P.carrier_phase_cycles;
+            // Parameters this kernel cannot evaluate exactly poison the output with NaN (fail loudly):
+            // prn outside the table, or a code-phase span beyond the int32 / float-reciprocal modulo range
+            // (the host entry point rejects these up front; device-resident parameters are checked here).
+            const double span = __builtin_fabs(tau) + __builtin_fabs(ratio) * (double)(N + a.max_abs_shift) + 1.0;
+            const bool bad = P.prn < 0 || P.prn >= a.num_prns || !(span < 1073741824.0) ||
+                             !(span < 2097152.0 * (double)Lc) || !(ratio >= 0.0) || !(step == step) || !(phi == phi) ||
+                             !(__builtin_fabs(step) < 1.0e15) || !(__builtin_fabs(phi) < 1.0e15);
+            if (bad) ratio = 0.0, tau = 0.0, step = 0.0, phi = 0.0; // tame values; the output is poisoned below
+            if (valid) valid_mask |= 1u << kk;
+            if (valid && bad) bad_mask |= 1u << kk;
+            prn_k[kk] = (P.prn < 0 || P.prn >= a.num_prns) ? 0 : P.prn;
+            restage |= valid && prn_k[kk] != staged_prn[kk];
+            if (tid == 0) s_const[kk] = ChanConst{ratio, tau, step, phi};
+            float c_, s_;
+            sincos_cycles(step - __builtin_rint(step), c_, s_); // one-sample rotation exp(+j*2*pi*step)
+            wr_k[kk] = uni(c_);
+            wi_k[kk] = uni(s_);
+            const double cs = step * (double)CHUNK;             // one-step rotation of a carried phasor
+            sincos_cycles(cs - __builtin_rint(cs), c_, s_);
+            cwr_k[kk] = uni(c_);
+            cwi_k[kk] = uni(s_);
+        }
+        valid_mask = uni(valid_mask);
+        bad_mask = uni(bad_mask);
+
+        if (uni((int)restage)) { // (re)stage the chip tables: rows are padded to 16 bytes on the device -> 16-byte copies
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk) {
+                const i32x4 *g = reinterpret_cast<const i32x4 *>(a.codes + (size_t)prn_k[kk] * a.code_row_stride);
+                i32x4 *d = reinterpret_cast<i32x4 *>(s_code + (size_t)kk * a.code_row_stride);
+                for (int i = tid; i < (Lc + 15) / 16; i += kThreads) d[i] = g[i];
+                staged_prn[kk] = prn_k[kk];
+            }
+        }
+        __syncthreads(); // s_const and the tables are in place
+
+        // ---- replica producer: walk constants of this thread's channel ----------------------------------------
+        // one producer step advances 4 samples (the next slot of the thread's plane)
+        unsigned w_rate_lo, w_rate_hi, w_margin;
+        bool w_exact;
+        const bool g_valid = (valid_mask >> gk) & 1u;
+        {
+            const ChanConst cc = s_const[gk];
+            const double span = __builtin_fabs(cc.tau) + cc.ratio * (double)(N + a.max_abs_shift) + 1.0;
+            const ChipWalkConst wc = chip_walk_setup(cc.ratio, span, 4 * run + 4, 4, Lc);
+            const unsigned long long r4 = uni(wc.rate) * 4ull;
+            w_rate_lo = (unsigned)r4;
+            w_rate_hi = (unsigned)(r4 >> 32);
+            w_margin = uni(wc.margin);
+            w_exact = uni(wc.exact_only) != 0;
+        }
+
+        float car_r[KT][G], car_i[KT][G]; // phasors of this lane's groups, carried from step to step
+
+        f32x2 acc[KT][MT][L]; // (re, im)
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int l = 0; l < L; ++l) acc[kk][m][l] = f32x2{0.f, 0.f};
+
+        // Sample loads are raw buffer loads: ONE descriptor per plane based at sample 0 of this block for antenna 0 of
+        // the wave's tile, a 32-bit lane offset shared by every load of a step and a scalar offset per antenna (the
+        // host guarantees (MT - 1) * antenna stride < 4 GB, else it launches with MT = 1).  The cache policy is a
+        // template parameter: a wave-uniform `if (keep) plain else non-temporal` pair of ordinary loads is merged by the
+        // compiler into plain loads (the hint is only metadata; that cost 7 % at configs[1]), and the same branch
+        // around buffer loads breaks the step into many basic blocks (+ 50 registers).
+        const size_t base = (size_t)b * a.block_stride + (size_t)kg * a.chan_stride /* != 0 only with KT == 1 */ +
+                            (size_t)((ag * AW + at_w) * MT) * a.ant_stride;
+        const __amdgpu_buffer_rsrc_t rs_re = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(static_cast<const char *>(a.re) + base * EB), 0, -1, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_im = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(static_cast<const char *>(FMT == GAT_LAYOUT_PLANAR ? a.im : a.re) + base * EB), 0, -1, 0x00020000);
+        const unsigned ant_bytes = (unsigned)((size_t)a.ant_stride * EB);
+
+        // chips of the sample at segment-relative position rel, for the L taps
+        auto get_chips = [&](float (&chip)[L], int rel, const float *rep) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const int i = rel + (a.shifts[l] - shift0);
+                chip[l] = rep[(i & 3) * RPS + (i >> 2)];
+            }
+        };
+        // one sample of one antenna: conj(carrier) wipe-off (src/algorithms.jl:175-176), L taps.  Plain scalar FMAs:
+        // v_pk_fma_f32 issues at the rate of two v_fma_f32 on gfx950 but needs its operands in aligned register
+        // pairs -- the packed form cost ~20 % extra v_mov in this loop (the dc translation units are built with
+        // -fno-slp-vectorize so that the compiler does not re-pack them).
+        auto accumulate = [&](f32x2 (&ac)[L], float xr, float xi, float cr, float ci, const float (&chip)[L]) {
+            const float dr = __builtin_fmaf(xr, cr, xi * ci), di = __builtin_fmaf(xi, cr, -(xr * ci));
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                ac[l][0] = __builtin_fmaf(chip[l], dr, ac[l][0]);
+                ac[l][1] = __builtin_fmaf(chip[l], di, ac[l][1]);
+            }
+        };
+        // 16-byte loads of antenna m's group at byte offset `off` of the block (KEEP: plain loads that stay in L2 for the
+        // other channel groups, otherwise non-temporal: aux bit 1)
+        auto load_ant = [&](i32x4 (&raw)[IO::NV], int m, unsigned off) {
+            const unsigned so = (unsigned)m * ant_bytes;
+            constexpr int aux = KEEP ? 0 : 2;
+            raw[0] = (i32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_re, off, so, aux);
+            if constexpr (IO::NV == 2) raw[1] = (i32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_im, off, so, aux);
+        };
+        // the S phasors of one group: carried phasor + S-1 rotations
+        auto group_phasors = [&](float (&pr)[S], float (&pi)[S], int kk, int g) {
+            pr[0] = car_r[kk][g];
+            pi[0] = car_i[kk][g];
+#pragma unroll
+            for (int j = 1; j < S; ++j) {
+                pr[j] = __builtin_fmaf(pr[j - 1], wr_k[kk], -(pi[j - 1] * wi_k[kk]));
+                pi[j] = __builtin_fmaf(pr[j - 1], wi_k[kk], pi[j - 1] * wr_k[kk]);
+            }
+        };
+        // samples [n_lo, n_hi) one at a time with scalar loads (ragged block end, unaligned input)
+        auto scalar_run = [&](int kk, int n_lo, int n_hi, int rel, const float *rep) {
+            for (int n = n_lo; n < n_hi; ++n, ++rel) {
+                float cr, ci, chip[L];
+                const double th = __builtin_fma((double)n, s_const[kk].step, s_const[kk].phi);
+                sincos_cycles(th - __builtin_rint(th), cr, ci);
+                get_chips(chip, rel, rep);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    float xr, xi;
+                    IO::load1(a.re, a.im, base + (size_t)m * a.ant_stride + n, xr, xi);
+                    accumulate(acc[kk][m], xr, xi, cr, ci, chip);
+                }
+            }
+        };
+        // The replica of one SEGMENT (SEG steps): entry i of a channel <-> sample c0*CHUNK + shift0 + i
+        // (src/algorithms.jl:753-757), i < seg_cnt = steps*CHUNK + tap span.  A producer thread owns `run` consecutive
+        // slots of one plane: ONE exact double-precision anchor, then the 32.32 walk (gat_phase.h) 4 samples at a
+        // time, branch-free; a batch with an unproven entry is redone with the reference's expression.
+        auto fill_segment = [&](int c0, int seg_cnt) {
+            if (!g_valid) return;
+            float *rep = s_rep + gk * 4 * RPS + gp * RPS + gs0;
+            const int8_t *tab = s_code + (size_t)gk * a.code_row_stride;
+            const int i0 = 4 * gs0 + gp;
+            if (i0 >= seg_cnt + 4) return; // nothing of this run is read (wave-divergent only at the segment's end)
+            const int x0 = c0 * CHUNK + shift0 + i0;
+            const double ratio = s_const[gk].ratio, tau = s_const[gk].tau;
+            // exact anchor (src/algorithms.jl:179-182)
+            const double p0 = code_phase(ratio, tau, x0);
+            const double fl0 = __builtin_floor(p0);
+            unsigned frac = (unsigned)((p0 - fl0) * 4294967296.0); // p - floor(p) is exact; truncation
+            unsigned idx = (unsigned)floormod_fast((int)fl0, Lc, inv_lc);
+            rep[0] = (float)tab[idx];
+            for (int j0 = 1; j0 < run; j0 += 4) {
+                unsigned id[4];
+                bool amb = w_exact;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned f2 = frac + w_rate_lo;
+                    idx += w_rate_hi + (f2 < frac ? 1u : 0u); // carry of the fraction = one more chip
+                    frac = f2;
+                    idx = min(idx, idx - (unsigned)Lc);       // fewer than Lc chips per step: one wrap at most
+                    // proven <=> margin <= frac <= 2^32 - 1 - margin <=> (frac - margin) + 2 margin does not carry
+                    amb |= (frac - w_margin) > (0xffffffffu - 2u * w_margin);
+                    id[u] = idx;
+                }
+                if (__builtin_expect(amb, 0)) { // some entry of the batch is not proven (or nothing is): evaluate exactly
+#pragma unroll 1
+                    for (int u = 0; u < 4; ++u) id[u] = (unsigned)chip_index(ratio, tau, x0 + 4 * (j0 + u), Lc, inv_lc);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j0 + u < run) rep[j0 + u] = (float)tab[id[u]]; // wave-uniform bound; the planes hold every run whole
+            }
+        };
+
+        if (c_begin < c_full && !preloaded) {
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) load_ant(raw[g][m], m, (unsigned)(c_begin * CHUNK + g * GSTRIDE + rel0) * EB);
+        }
+        preloaded = next_block;
+        for (int c0 = c_begin; c0 < c_end; c0 += SEG) {
+            const int c1 = min(c0 + SEG, c_end);
+            if (c0 > c_begin) __syncthreads(); // everybody has finished reading the previous segment's replica
+            fill_segment(c0, (c1 - c0) * CHUNK + a.rep_span);
+            // exact carrier anchors of this lane's groups at the segment start (src/algorithms.jl:172)
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk)
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const double th = __builtin_fma((double)(c0 * CHUNK + g * GSTRIDE + rel0), s_const[kk].step, s_const[kk].phi);
+                    sincos_cycles(th - __builtin_rint(th), car_r[kk][g], car_i[kk][g]);
+                }
+            __syncthreads();
+
+            // ---- whole chunks.  The samples of step c+1 are loaded while step c is consumed: antenna by antenna, into
+            // the registers that antenna's samples of step c have just left (loads in flight all the time, no second
+            // register set).  The prefetch is unconditional -- a conditional one makes the compiler copy the whole
+            // register array around the branch; after the last whole chunk every lane re-loads the block's first bytes.
+            const int cf = min(c1, c_full);
+            for (int c = c0; c < cf; ++c) {
+                const int srel = (c - c0) * CHUNK; // position of the step inside the segment
+                // next: the following chunk; after the last whole chunk the first chunk of the next block this workgroup
+                // walks (same descriptor, one block stride on); else a harmless re-load of the block's first bytes
+                const bool more = c + 1 < c_full;
+                const unsigned next_off = more ? (unsigned)((c + 1) * CHUNK + rel0) * EB
+                                          : (next_block ? (unsigned)a.block_stride * EB + (unsigned)(c_begin * CHUNK + rel0) * EB : 0u);
+                const unsigned next_g = more || next_block ? (unsigned)(GSTRIDE * EB) : 0u;
+#pragma unroll
+                for (int kk = 0; kk < KT; ++kk) {
+                    // The samples of the next step are fetched during the pass of the LAST channel slot (every other pass
+                    // re-reads the registers).  Always: a slot without a channel (K not a multiple of KT, last channel
+                    // group only) still issues the loads -- a conditional refill would make the compiler copy the array.
+                    const bool refill = kk == KT - 1; // compile-time after unrolling
+                    if (KT == 1 || ((valid_mask >> kk) & 1u)) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            const int rel = srel + rel0 + g * GSTRIDE;
+                            float pr[S], pi[S], chip[S][L];
+                            group_phasors(pr, pi, kk, g);
+#pragma unroll
+                            for (int j = 0; j < S; ++j) get_chips(chip[j], rel + j, s_rep + kk * 4 * RPS);
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                                for (int j = 0; j < S; ++j) {
+                                    float xr, xi;
+                                    IO::get(raw[g][m], j, xr, xi);
+                                    accumulate(acc[kk][m], xr, xi, pr[j], pi[j], chip[j]);
+                                }
+                                if (refill) load_ant(raw[g][m], m, next_off + g * next_g);
+                                // antenna by antenna: left alone the scheduler wipes off all antennas first (their
+                                // products and the refilled sample registers are then live together: + 30 registers)
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            // carry the group's phasor to the next step
+                            const float t = __builtin_fmaf(car_r[kk][g], cwr_k[kk], -(car_i[kk][g] * cwi_k[kk]));
+                            car_i[kk][g] = __builtin_fmaf(car_r[kk][g], cwi_k[kk], car_i[kk][g] * cwr_k[kk]);
+                            car_r[kk][g] = t;
+                        }
+                    } else if (refill) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g)
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) load_ant(raw[g][m], m, next_off + g * next_g);
+                    }
+                    if (KT > 1) __builtin_amdgcn_sched_barrier(0); // one channel's chips and phasors at a time
+                }
+            }
+            // ---- ragged tail (at most one chunk when the input is 16-byte aligned) / unaligned input ----------------
+#pragma unroll 1
+            for (int c = max(c0, cf); c < c1; ++c) {
+                const int srel = (c - c0) * CHUNK;
+#pragma unroll 1
+                for (int g = 0; g < G; ++g) {
+                    const int n = c * CHUNK + g * GSTRIDE + rel0;
+                    const int rel = srel + rel0 + g * GSTRIDE;
+                    if (VEC == 4 && n + S <= N) {
+                        i32x4 rawt[MT][IO::NV];
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) load_ant(rawt[m], m, (unsigned)n * EB);
+#pragma unroll
+                        for (int kk = 0; kk < KT; ++kk) {
+                            if (KT > 1 && !((valid_mask >> kk) & 1u)) continue;
+                            float pr[S], pi[S];
+                            const double th = __builtin_fma((double)n, s_const[kk].step, s_const[kk].phi);
+                            sincos_cycles(th - __builtin_rint(th), pr[0], pi[0]);
+#pragma unroll
+                            for (int j = 1; j < S; ++j) {
+                                pr[j] = __builtin_fmaf(pr[j - 1], wr_k[kk], -(pi[j - 1] * wi_k[kk]));
+                                pi[j] = __builtin_fmaf(pr[j - 1], wi_k[kk], pi[j - 1] * wr_k[kk]);
+                            }
+#pragma unroll
+                            for (int j = 0; j < S; ++j) {
+                                float chip[L];
+                                get_chips(chip, rel + j, s_rep + kk * 4 * RPS);
+#pragma unroll
+                                for (int m = 0; m < MT; ++m) {
+                                    float xr, xi;
+                                    IO::get(rawt[m], j, xr, xi);
+                                    accumulate(acc[kk][m], xr, xi, pr[j], pi[j], chip);
+                                }
+                            }
+                        }
+                    } else if (n < N) {
+#pragma unroll
+                        for (int kk = 0; kk < KT; ++kk) {
+                            if (KT > 1 && !((valid_mask >> kk) & 1u)) continue;
+                            scalar_run(kk, n, min(n + S, N), rel, s_rep + kk * 4 * RPS);
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- block reduction: per channel 2*MT*L values per wave -> butterfly -> waves sharing an antenna tile ----
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+            float v[NV];
+#pragma unroll
+            for (int l = 0; l < L; ++l)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    v[(l * MT + m) * 2 + 0] = acc[kk][m][l][0];
+                    v[(l * MT + m) * 2 + 1] = acc[kk][m][l][1];
+                }
+            Butterfly<NV, 32>::run(v, lane);
+            // lanes sharing an index hold bit-identical sums
+            s_part[(kk * 4 + wave) * 64 + Butterfly<NV, 32>::index(lane)] = v[0];
+        }
+        __syncthreads();
+
+        for (int o = tid; o < KT * AW * NV; o += kThreads) {
+            const int kk = o / (AW * NV);
+            const int r = o - kk * (AW * NV);
+            const int at = r / NV, vi = r - (r / NV) * NV;
+            const int k = kg * KT + kk;
+            if (k >= a.K) continue;
+            const float *p = s_part + (kk * 4 + at) * 64 + vi; // wave = sub * AW + at
+            float tot;
+            if constexpr (SUBS == 4) tot = (p[0] + p[64]) + (p[128] + p[192]);
+            else if constexpr (SUBS == 2) tot = p[0] + p[AW * 64];
+            else tot = p[0];
+            if ((bad_mask >> kk) & 1u) tot = __builtin_nanf("");
+            const int comp = vi & 1;
+            const int ml = vi >> 1;
+            const int m = (ag * AW + at) * MT + (ml % MT);
+            const int l = a.tap_index[ml / MT]; // position of this tap in the caller's shift list
+            const size_t bk = (size_t)b * a.K + k;
+            const size_t oidx = (bk * a.Ltot + l) * a.M + m;
+            if (a.flags & GAT_FLAG_ATOMIC) {
+                atomicAdd((comp ? a.out_im : a.out_re) + oidx, tot);
+            } else if (a.splits == 1) {
+                (comp ? a.out_im : a.out_re)[oidx] = tot;
+            } else {
+                const size_t elems = (size_t)a.Ltot * a.M * 2;
+                a.partial[(bk * a.splits + split) * elems + ((size_t)l * a.M + m) * 2 + comp] = tot;
+            }
+        }
+        // the next block's s_const / table writes come after this barrier-separated reduction: the threads that still
+        // read s_part above do not touch s_const, s_rep or s_code
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// instance table: which (MT, L, VEC, AW, KT) combinations exist, per sample format (one translation unit each)
+// ------------------------------------------------------------------------------------------------------------
+// Which instances exist.  Register accumulators 2 * MT * L * KT <= 64; antenna-parallel waves (AW > 1) need full
+// 4-antenna tiles; unaligned input (VEC == 1, scalar loads) is served one antenna per workgroup.
+constexpr bool dc_instance(int mt, int l, int vec, int aw, int kt)
+{
+#ifdef GAT_DC_DEV // development builds: only the instances the BASELINE shapes use (compiles in seconds)
+    if (!((mt == 1 || mt == 4) && (l == 3 || l == 5) && vec == 4)) return false;
+#endif
+    if (mt < 1 || mt > kMaxAntTile || l < 1 || l > kMaxTapsPerLaunch) return false;
+    if (vec != 4) return vec == 1 && mt == 1 && aw == 1 && kt == 1;
+    if (aw != 1 && (mt != 4 || aw != 4)) return false;
+    // several channels per workgroup only with antenna-parallel waves: measured on MI355X, a channel loop over one
+    // antenna tile never beat separate channel workgroups sharing the tile through L2 (M = 1, 4; K = 8, 12)
+    if (kt != 1 && aw != 4) return false;
+    return (kt == 1 || kt == 2 || kt == 4) && mt * l * kt <= 48;
+}
+
+template <int FMT, int MT, int L, int VEC, int AW, int KT>
+static hipError_t launch_dc_one(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
+{
+    if constexpr (dc_instance(MT, L, VEC, AW, KT)) {
+        if (VEC == 4 && a.keep_l2)
+            hipLaunchKernelGGL((dc_kernel<MT, L, VEC, FMT, AW, KT, VEC == 4>), dim3(cfg.grid), dim3(kThreads), cfg.lds_bytes, s, a);
+        else
+            hipLaunchKernelGGL((dc_kernel<MT, L, VEC, FMT, AW, KT, false>), dim3(cfg.grid), dim3(kThreads), cfg.lds_bytes, s, a);
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
+}
+
+template <int FMT, int MT, int L>
+static hipError_t launch_dc_ml(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
+{
+    if (cfg.vec != 4) return launch_dc_one<FMT, MT, L, 1, 1, 1>(a, cfg, s);
+    switch (cfg.aw * 8 + cfg.kt) {
+    case 1 * 8 + 1: return launch_dc_one<FMT, MT, L, 4, 1, 1>(a, cfg, s);
+    case 1 * 8 + 2: return launch_dc_one<FMT, MT, L, 4, 1, 2>(a, cfg, s);
+    case 1 * 8 + 4: return launch_dc_one<FMT, MT, L, 4, 1, 4>(a, cfg, s);
+    case 4 * 8 + 1: return launch_dc_one<FMT, MT, L, 4, 4, 1>(a, cfg, s);
+    case 4 * 8 + 2: return launch_dc_one<FMT, MT, L, 4, 4, 2>(a, cfg, s);
+    case 4 * 8 + 4: return launch_dc_one<FMT, MT, L, 4, 4, 4>(a, cfg, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int FMT, int MT>
+static hipError_t launch_dc_m(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
+{
+    switch (cfg.taps) {
+    case 1: return launch_dc_ml<FMT, MT, 1>(a, cfg, s);
+    case 2: return launch_dc_ml<FMT, MT, 2>(a, cfg, s);
+    case 3: return launch_dc_ml<FMT, MT, 3>(a, cfg, s);
+    case 4: return launch_dc_ml<FMT, MT, 4>(a, cfg, s);
+    case 5: return launch_dc_ml<FMT, MT, 5>(a, cfg, s);
+    case 6: return launch_dc_ml<FMT, MT, 6>(a, cfg, s);
+    case 7: return launch_dc_ml<FMT, MT, 7>(a, cfg, s);
+    case 8: return launch_dc_ml<FMT, MT, 8>(a, cfg, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int FMT>
+hipError_t launch_dc_fmt(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
+{
+    switch (cfg.ant_tile) {
+    case 1: return launch_dc_m<FMT, 1>(a, cfg, s);
+    case 2: return launch_dc_m<FMT, 2>(a, cfg, s);
+    case 3: return launch_dc_m<FMT, 3>(a, cfg, s);
+    case 4: return launch_dc_m<FMT, 4>(a, cfg, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace gat

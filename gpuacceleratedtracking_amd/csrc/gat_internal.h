@@ -11,7 +11,8 @@ namespace gat {
 constexpr int kThreads = 256;       // 4 wave64 per workgroup
 constexpr int kMaxTapsPerLaunch = 8; // taps handled by one launch (register accumulators)
 constexpr int kMaxAntTile = 4;       // antennas handled by one workgroup
-constexpr int kMaxReplicaSpan = 2048; // largest tap span served from the LDS replica segment
+constexpr int kMaxReplicaSpan = 512;  // largest tap span served from the LDS replica segment of one launch (wider tap
+                                      // lists are cut into several launches)
 
 // Sample ownership of one lane per step in dc_kernel: G groups of S consecutive samples, one
 // 16-byte load per plane and group (vec == 4) or scalar loads (vec == 1).  S by format:
@@ -27,7 +28,8 @@ constexpr int dc_groups(int vec, int fmt)
 {
     return vec != 4 ? 1 : fmt == GAT_LAYOUT_PLANAR ? GAT_PLANAR_GROUPS : fmt == GAT_LAYOUT_INTERLEAVED ? 2 : 1;
 }
-constexpr int dc_chunk(int vec, int fmt) { return kThreads * dc_group_samples(vec, fmt) * dc_groups(vec, fmt); }
+// samples one workgroup covers per step: the 4 / aw waves that share an antenna tile, 64 lanes each
+constexpr int dc_chunk(int vec, int fmt, int aw = 1) { return (kThreads / aw) * dc_group_samples(vec, fmt) * dc_groups(vec, fmt); }
 
 // Arguments of the fused correlator kernel (passed by value in the kernarg segment).
 struct DcArgs {
@@ -41,26 +43,55 @@ struct DcArgs {
     long long N, ant_stride, block_stride, chan_stride;
     double fs;
     int M, K, B, Lc, num_prns, code_row_stride;
-    int splits, chunks_per_split, total_chunks, ant_tiles;
-    int num_tiles;         // B * ant_tiles * splits
+    int KG;                // channel groups: ceil(K / KT)
+    int splits, chunks_per_split, total_chunks;
+    int ant_groups;        // M / (MT * AW): antenna groups, one workgroup each
+    int blocks_per_wg;     // consecutive integration blocks one workgroup loops over (splits == 1 only)
+    int num_tiles;         // ceil(B / blocks_per_wg) * ant_groups * splits
     int Ltot;              // taps of the whole call (output indexing)
     int max_abs_shift;     // max |shift| over ALL taps of the call (range check)
     int rep_span;          // shifts[last] - shifts[0] of THIS launch's taps (replica halo)
-    int rep_plane_stride;  // floats per replica plane (== 8 mod 32: conflict-free planes)
+    int rep_run;           // replica slots one producer thread fills per segment
+    int seg_steps;         // steps per segment (replica produced at once)
+    int rep_plane_stride;  // floats per replica plane
+    int keep_l2;           // 1: plain loads (several channel groups share the tile through L2), 0: non-temporal
     unsigned flags;
     int shifts[kMaxTapsPerLaunch];    // ascending
     int tap_index[kMaxTapsPerLaunch]; // position of each tap in the caller's list
 };
 
 struct DcLaunch {
-    int ant_tile; // MT
+    int ant_tile; // MT: antennas per wave
+    int aw;       // antenna tiles (waves) per workgroup: 1, 2, 4
+    int kt;       // channels per workgroup: 1, 2, 4
     int taps;     // L of this launch
     int vec;      // 4 or 1
     int format;   // GAT_LAYOUT_*
-    int keep_l2;  // 1: plain loads (several channels share the signal bytes through L2), 0: non-temporal
     unsigned grid;
     unsigned lds_bytes;
 };
+// Steps whose code replica one workgroup produces at once (a "segment"): ~8192 entries per workgroup over its kt
+// channels, no more than the steps a workgroup has per block
+constexpr int dc_segment_steps(int chunk, int kt, int steps_per_wg)
+{
+    int s = 8192 / (kt * chunk);
+    s = s < 2 ? 2 : (s > 8 ? 8 : s);
+    return s > steps_per_wg ? (steps_per_wg < 1 ? 1 : steps_per_wg) : s;
+}
+// Floats per plane of the 4-plane replica of one segment: segment samples + tap span + room for every producer run to
+// be stored whole (up to 64 producer threads per plane, < 4 spare slots each ... 256), == 8 (mod 32)
+constexpr int dc_rep_plane_stride(int chunk, int seg_steps, int span)
+{
+    return (((seg_steps * chunk + span + 3) / 4 + 256 + 23) / 32) * 32 + 8;
+}
+// dynamic LDS of one dc_kernel workgroup: per-channel constants, reduction scratch, one segment's replica, chip tables
+constexpr size_t dc_lds_bytes(int kt, int code_row_stride, int rep_plane_stride)
+{
+    return (size_t)kt * 32 + (size_t)kt * 4 * 64 * sizeof(float) + (size_t)kt * 4 * rep_plane_stride * sizeof(float) +
+           (size_t)kt * code_row_stride;
+}
+// does an instance of dc_kernel exist for this combination (gat_dc.h: dc_instance)
+bool dc_has_instance(int ant_tile, int taps, int vec, int aw, int kt);
 
 // Arguments of the matrix-core kernel (gat_mfma.hip): 16-antenna tiles, planar f32 input.
 constexpr int kMfmaMaxTaps = 16;     // 2 * CT * L <= 32 columns with CT >= 1
@@ -105,6 +136,8 @@ int mfma_bf16_producer_threads(int rt, int nct);
 
 // Launchers implemented in gat_kernels.hip.  All return hipError_t of the launch.
 hipError_t launch_dc(const DcArgs &a, const DcLaunch &cfg, hipStream_t s);
+// one translation unit per sample format (gat_dc_f*.hip), so that the instances compile in parallel
+template <int FMT> hipError_t launch_dc_fmt(const DcArgs &a, const DcLaunch &cfg, hipStream_t s);
 hipError_t launch_finalize(const float *partial, float *out_re, float *out_im, int splits, int elems,
                            long long groups, hipStream_t s);
 hipError_t launch_gen_code_replica(float *rep, long long count, const int8_t *code_row, int Lc,
@@ -119,6 +152,6 @@ hipError_t launch_reduce_stage1(const float *in_re, const float *in_im, long lon
 hipError_t launch_tracking_update(const float *acc_re, const float *acc_im, int K, int M, const gat_loop_config &cfg,
                                   gat_loop_state *state, const gat_channel_params *cur, gat_channel_params *next,
                                   hipStream_t s);
-bool dc_supported(int ant_tile, int taps);
+
 
 } // namespace gat

@@ -1,422 +1,10 @@
-// gat_kernels.hip -- gfx950 (MI355X, wave64) kernels of the downconvert + correlate path.
-//
-// What is computed (reference: downconvert_and_correlate_kernel_1330!, src/algorithms.jl:170-187;
-// replica convention of kernel 5431, src/algorithms.jl:752-758; equation paper/paper.tex:48-52):
-//
-//   R[m,l,k,b] = sum_n x[n,m,b] * conj(exp(j2pi(n*f/fs + phi))) * c_k[floor(fc/fs*(n+shift_l)+tau) mod Lc]
-//
-// How (CDNA4-first, not the reference's shared-memory tree per sample):
-//   * one workgroup (4 waves) streams a contiguous run of one integration block; every lane
-//     owns VEC consecutive samples per step and loads them as 16-byte vectors per antenna
-//     plane (planar) or 2 x 16 B (interleaved ComplexF32) -- 1 KiB per wave-instruction;
-//   * the +-1 chip table of the workgroup's PRN lives in LDS as int8 (1 KB for C/A, 10 KB L5);
-//   * carrier: one double-precision phase anchor per lane and step, reduced to an octant in
-//     double, float polynomial sincos, then VEC-1 complex rotations -- no per-(antenna,tap)
-//     redundant FP64 sincos as in the reference (src/algorithms.jl:172);
-//   * code phase: the reference's exact double-precision expression, unfused (this file is
-//     built with -ffp-contract=off) so chip edges fall on the same sample as on the CPU;
-//   * MT x L complex accumulators stay in registers for the whole run; ONE reduction per
-//     workgroup: a butterfly that halves the value count at each of the 6 wave64 shuffle
-//     steps (2*MT*L -> 1 value per lane), then 4 waves through LDS;
-//   * the result is written once (deterministic).  When a block is split over several
-//     workgroups (small batch), per-split partials are summed by finalize_kernel in fixed
-//     order; GAT_FLAG_ATOMIC uses float atomics instead (reference alg. 4/5).
-#include "gat_internal.h"
+// gat_kernels.hip -- gfx950 (MI355X, wave64) kernels around the fused correlator: second-stage sum, stand-alone
+// code replica / signal generators, column-sum reduction, tracking-loop update, and the launch dispatch.
+// The fused downconvert + correlate kernel itself is the template in gat_dc.h, instantiated per sample format in
+// gat_dc_f0.hip ... gat_dc_f3.hip (four translation units that compile in parallel).
+#include "gat_dc.h"
 
 namespace gat {
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// ------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// 16-byte streaming load.  The signal is read exactly once, so the loads are non-temporal
-// (global_load_dwordx4 ... nt): measured +7 % on a pure read of this access pattern
-// (scripts/bw_probe.hip: 6.13 -> 6.58 TB/s on MI355X).
-__device__ __forceinline__ f32x4 load_stream16(const float *p)
-{
-    return __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
-}
-
-// exp(j*2*pi*theta) for theta in cycles (double).  Octant reduction in double (exact), float
-// Taylor polynomials on |a| <= pi/4 (|err| < 3e-8), quadrant fix-up.
-__device__ __forceinline__ void sincos_cycles(double theta, float &c, float &s)
-{
-    const double q = __builtin_rint(theta * 4.0);
-    const double r = __builtin_fma(q, -0.25, theta); // exact: |r| <= 0.125 cycles
-    const float a = (float)r * 6.283185307179586f;
-    const float a2 = a * a;
-    float sp = __builtin_fmaf(a2, 2.7557319e-6f, -1.9841270e-4f);
-    sp = __builtin_fmaf(a2, sp, 8.3333333e-3f);
-    sp = __builtin_fmaf(a2, sp, -1.6666667e-1f);
-    sp = __builtin_fmaf(a2 * a, sp, a);
-    float cp = __builtin_fmaf(a2, 2.4801587e-5f, -1.3888889e-3f);
-    cp = __builtin_fmaf(a2, cp, 4.1666667e-2f);
-    cp = __builtin_fmaf(a2, cp, -0.5f);
-    cp = __builtin_fmaf(a2, cp, 1.0f);
-    const int qi = (int)(long long)q & 3;
-    const float cs = (qi & 1) ? sp : cp;
-    const float sn = (qi & 1) ? cp : sp;
-    c = (qi == 1 || qi == 2) ? -cs : cs;
-    s = (qi >= 2) ? -sn : sn;
-}
-
-// floor(p) mod Lc with floored (Julia) semantics; valid for |ip| < 2^30 and |ip| / Lc < 2^21
-// (checked on the host and again per workgroup in dc_kernel; other callers clamp).
-__device__ __forceinline__ int floormod_fast(int ip, int Lc, float inv_lc)
-{
-    const float q = __builtin_floorf((float)ip * inv_lc);
-    int r = ip - (int)q * Lc;
-    r += (r < 0) ? Lc : 0;
-    r -= (r >= Lc) ? Lc : 0;
-    return r;
-}
-
-// chip index of sample x = n + shift: the reference's expression, src/algorithms.jl:179-182.
-// One double multiply and one double add, NOT fused (bit-identical to the CPU oracle).
-__device__ __forceinline__ int chip_index(double ratio, double tau, int x, int Lc, float inv_lc)
-{
-    const double p = __dadd_rn(__dmul_rn(ratio, (double)x), tau);
-    const int ip = (int)__builtin_floor(p);
-    return floormod_fast(ip, Lc, inv_lc);
-}
-
-// Butterfly reduce-scatter over one wave64: NV per-lane values -> after 6 steps each lane
-// holds the full wave sum of ONE value; 25 shuffles for NV = 24 instead of 144.  At a step with
-// offset OFF, values 2i / 2i+1 are paired: the lane whose OFF bit is clear keeps 2i and sends
-// 2i+1, its partner does the opposite; an odd leftover is all-reduced.  Which value a lane ends
-// up with is a function of its lane id only (butterfly_index) -- no index array travels with the
-// values (it would double the register footprint of the epilogue, the kernel's pressure peak).
-template <int NV, int OFF>
-struct Butterfly {
-    static __device__ __forceinline__ void run(float *v, int lane)
-    {
-        constexpr int H = NV / 2;
-        const bool up = (lane & OFF) != 0;
-#pragma unroll
-        for (int i = 0; i < H; ++i) {
-            // load both operands unconditionally: a ternary on the array elements themselves is
-            // turned into a dynamically indexed (scratch) access by the compiler
-            const float lo = v[2 * i], hi = v[2 * i + 1];
-            const float keep = up ? hi : lo;
-            const float send = up ? lo : hi;
-            v[i] = keep + __shfl_xor(send, OFF, 64);
-        }
-        if constexpr (NV & 1) v[H] = v[NV - 1] + __shfl_xor(v[NV - 1], OFF, 64);
-        Butterfly<(NV + 1) / 2, OFF / 2>::run(v, lane);
-    }
-    // original index of the value that ends in slot `slot` after this and all later steps
-    static __device__ __forceinline__ int index(int lane)
-    {
-        const int j = Butterfly<(NV + 1) / 2, OFF / 2>::index(lane); // slot before the later steps
-        constexpr int H = NV / 2;
-        if ((NV & 1) && j == H) return NV - 1;
-        return 2 * j + ((lane & OFF) ? 1 : 0);
-    }
-};
-template <int NV>
-struct Butterfly<NV, 0> {
-    static __device__ __forceinline__ void run(float *, int) {}
-    static __device__ __forceinline__ int index(int) { return 0; } // the survivor sits in slot 0
-};
-
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// ------------------------------------------------------------------------------------------
-// fused downconvert + correlate
-// ------------------------------------------------------------------------------------------
-// The chips of one step are generated ONCE per workgroup into an LDS replica segment
-// [CHUNK + span of the taps] (what gen_code_replica! materialises in global memory in the
-// reference, src/algorithms.jl:752-758) and every tap reads it at its own offset, so a step costs
-// (CHUNK + span)/256 = ~4.1 FP64 code-phase evaluations per lane instead of samples*taps = 12.
-// The segment is stored as 4 interleaved planes (element i at plane i&3, slot i>>2) so that
-// the lanes of a wave, which own samples 4*lane + j, read consecutive dwords (no bank conflict).
-//
-// FMT: sample format of the signal (GAT_LAYOUT_*): planar f32, interleaved ComplexF32,
-// interleaved int16 pairs, interleaved int8 pairs.  VEC = 4: one 16-byte non-temporal load per
-// lane, plane and group (4 / 2 / 4 / 8 complex samples); VEC = 1: scalar loads (unaligned input).
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-// sample loads: non-temporal when every byte is used once (one channel per signal: + 7 % at configs[1]), plain when
-// the K channel workgroups of a tile are to find it in L2 (+ 4-9 % with 8-12 channels)
-#define GAT_NT_LOAD(p) (KEEP ? *(p) : __builtin_nontemporal_load(p))
-
-template <int FMT>
-struct SampleIO {
-    // number of 16-byte vectors per antenna and group
-    static constexpr int NV = (FMT == GAT_LAYOUT_PLANAR) ? 2 : 1;
-    // bytes of one complex sample
-    static constexpr int BYTES = (FMT == GAT_LAYOUT_INTERLEAVED_I16) ? 4 : (FMT == GAT_LAYOUT_INTERLEAVED_I8) ? 2 : 8;
-
-    // 16-byte loads of the group starting at complex-sample index e
-    template <bool KEEP>
-    static __device__ __forceinline__ void load16(i32x4 (&raw)[NV], const void *re, const void *im, size_t e)
-    {
-        if constexpr (FMT == GAT_LAYOUT_PLANAR) {
-            raw[0] = GAT_NT_LOAD(reinterpret_cast<const i32x4 *>(static_cast<const float *>(re) + e));
-            raw[1] = GAT_NT_LOAD(reinterpret_cast<const i32x4 *>(static_cast<const float *>(im) + e));
-        } else {
-            raw[0] = GAT_NT_LOAD(
-                reinterpret_cast<const i32x4 *>(static_cast<const unsigned char *>(re) + e * BYTES));
-        }
-    }
-    // sample j of a loaded group
-    static __device__ __forceinline__ void get(const i32x4 (&raw)[NV], int j, float &xr, float &xi)
-    {
-        // NOTE: copy the vector element into a scalar BEFORE the bit cast: __builtin_bit_cast applied
-        // directly to an ext-vector element lvalue reads element 0 whatever the index (hipcc 7.2).
-        if constexpr (FMT == GAT_LAYOUT_PLANAR) {
-            const int wr_ = raw[0][j], wi_ = raw[1][j];
-            xr = __int_as_float(wr_);
-            xi = __int_as_float(wi_);
-        } else if constexpr (FMT == GAT_LAYOUT_INTERLEAVED) {
-            const int wr_ = raw[0][2 * j], wi_ = raw[0][2 * j + 1];
-            xr = __int_as_float(wr_);
-            xi = __int_as_float(wi_);
-        } else if constexpr (FMT == GAT_LAYOUT_INTERLEAVED_I16) {
-            const int w = raw[0][j]; // {re: low half, im: high half}, little endian
-            xr = (float)(short)(w & 0xffff);
-            xi = (float)(w >> 16);
-        } else {
-            const int w = raw[0][j >> 1] >> ((j & 1) * 16); // two complex int8 samples per dword
-            xr = (float)(signed char)(w & 0xff);
-            xi = (float)(signed char)((w >> 8) & 0xff);
-        }
-    }
-    // one sample with scalar loads
-    static __device__ __forceinline__ void load1(const void *re, const void *im, size_t e, float &xr, float &xi)
-    {
-        if constexpr (FMT == GAT_LAYOUT_PLANAR) {
-            xr = static_cast<const float *>(re)[e];
-            xi = static_cast<const float *>(im)[e];
-        } else if constexpr (FMT == GAT_LAYOUT_INTERLEAVED) {
-            xr = static_cast<const float *>(re)[2 * e];
-            xi = static_cast<const float *>(re)[2 * e + 1];
-        } else if constexpr (FMT == GAT_LAYOUT_INTERLEAVED_I16) {
-            xr = (float)static_cast<const short *>(re)[2 * e];
-            xi = (float)static_cast<const short *>(re)[2 * e + 1];
-        } else {
-            xr = (float)static_cast<const signed char *>(re)[2 * e];
-            xi = (float)static_cast<const signed char *>(re)[2 * e + 1];
-        }
-    }
-};
-
-// No minimum-waves bound on purpose: <4,3,4,planar> needs 136 VGPRs (3 waves/SIMD) and any tighter
-// bound spills to scratch (measured: 4 waves/SIMD no gain at configs[1], 5 and 6 are 1.3-1.8x slower).
-template <int MT, int L, int VEC, int FMT, bool KEEP>
-__global__ void __launch_bounds__(kThreads) dc_kernel(const DcArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int8_t *s_code = reinterpret_cast<int8_t *>(smem);
-    float *s_part = reinterpret_cast<float *>(smem + ((a.Lc + 15) & ~15)); // [4][64]
-    float *s_rep = s_part + 4 * 64;                                        // [2][4][rep_ps]
-    using IO = SampleIO<FMT>;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-
-    // Workgroup -> (tile, channel).  A tile = (block b, antenna tile, split): the bytes K channel
-    // workgroups share.  Blocks id and id+8 land on the same XCD (round-robin dispatch), so the K
-    // workgroups of one tile get ids tile%8 + 8*(k + K*(tile/8)): same XCD, dispatched back to
-    // back -> the tile comes from HBM once and from that XCD's L2 for the other K-1 channels.
-    // (Speed only: nothing depends on the placement.)
-    const unsigned xcd = blockIdx.x & 7u, jq = blockIdx.x >> 3;
-    const int k = (int)(jq % (unsigned)a.K);
-    unsigned tile = (jq / (unsigned)a.K) * 8u + xcd;
-    if (tile >= (unsigned)a.num_tiles) return; // padding of the last group of 8 (whole workgroup exits)
-    const int split = tile % a.splits;
-    tile /= a.splits;
-    const int at = tile % a.ant_tiles;
-    const int b = tile / a.ant_tiles;
-
-    const gat_channel_params P = a.params[(size_t)b * a.K + k];
-    const int Lc = a.Lc;
-    const int N = (int)a.N;
-    const double ratio = P.code_freq_hz / a.fs;    // src/algorithms.jl:179 (Float64 division)
-    const double step = P.carrier_freq_hz / a.fs;  // cycles per sample
-    const double tau = P.code_phase_chips;
-    const double phi = P.carrier_phase_cycles;
-    const float inv_lc = 1.0f / (float)Lc;
-
-    // Parameters this kernel cannot evaluate exactly poison the output with NaN (fail loudly):
-    // prn outside the table, or a code-phase span beyond the int32 / float-reciprocal modulo range
-    // (the host entry point rejects these up front; device-resident parameters are checked here).
-    const double span = __builtin_fabs(tau) + __builtin_fabs(ratio) * (double)(N + a.max_abs_shift) + 1.0;
-    const bool bad = P.prn < 0 || P.prn >= a.num_prns || !(span < 1073741824.0) ||
-                     !(span < 2097152.0 * (double)Lc) || !(ratio >= 0.0) || !(step == step) || !(phi == phi);
-    const int prn = (P.prn < 0 || P.prn >= a.num_prns) ? 0 : P.prn;
-
-    { // stage this PRN's chip table: rows are padded to 16 bytes on the device -> 16-byte copies
-        const i32x4 *g = reinterpret_cast<const i32x4 *>(a.codes + (size_t)prn * a.code_row_stride);
-        i32x4 *d = reinterpret_cast<i32x4 *>(s_code);
-        for (int i = tid; i < (Lc + 15) / 16; i += kThreads) d[i] = g[i];
-    }
-    __syncthreads();
-
-    float wr, wi; // one-sample rotation exp(+j*2*pi*step)
-    sincos_cycles(step - __builtin_rint(step), wr, wi);
-
-    f32x2 acc[MT][L]; // (re, im) pairs: one v_pk_fma_f32 per antenna, tap and sample
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int l = 0; l < L; ++l) acc[m][l] = f32x2{0.f, 0.f};
-
-    const size_t base = (size_t)b * a.block_stride + (size_t)k * a.chan_stride +
-                        (size_t)(at * MT) * a.ant_stride;
-    // A lane owns G groups of S consecutive samples per step; one group = one 16-byte load per
-    // plane, so every wave-instruction covers 1 KiB of contiguous memory in every format.
-    constexpr int S = dc_group_samples(VEC, FMT);
-    constexpr int G = dc_groups(VEC, FMT);
-    constexpr int GSTRIDE = kThreads * S;
-    constexpr int CHUNK = GSTRIDE * G;
-    static_assert(CHUNK == dc_chunk(VEC, FMT), "host and device disagree on the chunk size");
-    const int c_begin = split * a.chunks_per_split;
-    const int c_end = bad ? c_begin : min(c_begin + a.chunks_per_split, a.total_chunks);
-    const int shift0 = a.shifts[0];
-    const int rep_ps = a.rep_plane_stride;
-    const int rep_cnt = CHUNK + a.rep_span; // entries of one replica segment
-
-    // chips of the sample at chunk-relative position rel, for the L taps
-    auto get_chips = [&](float (&chip)[L], int rel, const float *rep) {
-#pragma unroll
-        for (int l = 0; l < L; ++l) {
-            const int i = rel + (a.shifts[l] - shift0);
-            chip[l] = rep[(i & 3) * rep_ps + (i >> 2)];
-        }
-    };
-    // one sample of one antenna: conj(carrier) wipe-off (src/algorithms.jl:175-176), L taps.
-    // (re, im) += chip * (dr, di) written on 2-vectors: ONE v_pk_fma_f32 with the chip broadcast by
-    // op_sel_hi.  (With separate re / im accumulator arrays the vectoriser also gets to v_pk_fma_f32 but
-    // pairs its operands with v_mov first -- more moves than FMAs; with several channels per signal
-    // byte this kernel is bound by vector issue.)
-    auto accumulate = [&](int m, float xr, float xi, float cr, float ci, const float (&chip)[L]) {
-        const f32x2 dw = {__builtin_fmaf(xr, cr, xi * ci), __builtin_fmaf(xi, cr, -(xr * ci))};
-#pragma unroll
-        for (int l = 0; l < L; ++l) acc[m][l] = __builtin_elementwise_fma(f32x2{chip[l], chip[l]}, dw, acc[m][l]);
-    };
-    auto load_group = [&](i32x4 (&raw)[MT][IO::NV], int n) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m) IO::template load16<KEEP>(raw[m], a.re, a.im, base + (size_t)m * a.ant_stride + n);
-    };
-    // S consecutive samples starting at n: one FP64 carrier anchor, then S-1 rotations
-    auto process_group = [&](const i32x4 (&raw)[MT][IO::NV], int n, int rel, const float *rep) {
-        float cr, ci;
-        const double th0 = __builtin_fma((double)n, step, phi);
-        sincos_cycles(th0 - __builtin_rint(th0), cr, ci);
-#pragma unroll
-        for (int j = 0; j < S; ++j) {
-            float chip[L];
-            get_chips(chip, rel + j, rep);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                float xr, xi;
-                IO::get(raw[m], j, xr, xi);
-                accumulate(m, xr, xi, cr, ci, chip);
-            }
-            if (j + 1 < S) {
-                const float t = __builtin_fmaf(cr, wr, -(ci * wi));
-                ci = __builtin_fmaf(cr, wi, ci * wr);
-                cr = t;
-            }
-        }
-    };
-    // samples [n_lo, n_hi) one at a time with scalar loads (ragged block end, unaligned input)
-    auto scalar_run = [&](int n_lo, int n_hi, int rel, const float *rep) {
-        for (int n = n_lo; n < n_hi; ++n, ++rel) {
-            const double th = __builtin_fma((double)n, step, phi);
-            float cr, ci, chip[L];
-            sincos_cycles(th - __builtin_rint(th), cr, ci);
-            get_chips(chip, rel, rep);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                float xr, xi;
-                IO::load1(a.re, a.im, base + (size_t)m * a.ant_stride + n, xr, xi);
-                accumulate(m, xr, xi, cr, ci, chip);
-            }
-        }
-    };
-    // this step's replica segment: entry i <-> sample c*CHUNK + shift0 + i (src/algorithms.jl:753-757)
-    auto fill_replica = [&](float *rep, int c) {
-        const int x0 = c * CHUNK + shift0;
-        // not unrolled on purpose: the FP64 temporaries of 4-5 unrolled iterations cost ~30 VGPRs,
-        // i.e. one wave per SIMD of occupancy, and this loop runs in the shadow of the sample loads
-#pragma unroll 1
-        for (int i = tid; i < rep_cnt; i += kThreads)
-            rep[(i & 3) * rep_ps + (i >> 2)] = (float)s_code[chip_index(ratio, tau, x0 + i, Lc, inv_lc)];
-    };
-
-    for (int c = c_begin; c < c_end; ++c) {
-        const int rel0 = tid * S;
-        const int cb = c * CHUNK + rel0;
-        float *rep = s_rep + ((c - c_begin) & 1) * 4 * rep_ps; // double-buffered: one barrier per step
-        if (VEC == 4 && c * CHUNK + CHUNK <= N) { // whole chunk inside the block: issue every load first
-            i32x4 raw[G][MT][IO::NV];
-#pragma unroll
-            for (int g = 0; g < G; ++g) load_group(raw[g], cb + g * GSTRIDE);
-            fill_replica(rep, c); // generated while the loads are in flight
-            __syncthreads();
-#pragma unroll
-            for (int g = 0; g < G; ++g) process_group(raw[g], cb + g * GSTRIDE, rel0 + g * GSTRIDE, rep);
-        } else {
-            fill_replica(rep, c);
-            __syncthreads();
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const int n = cb + g * GSTRIDE;
-                if (VEC == 4 && n + S <= N) {
-                    i32x4 raw[MT][IO::NV];
-                    load_group(raw, n);
-                    process_group(raw, n, rel0 + g * GSTRIDE, rep);
-                } else if (n < N) {
-                    scalar_run(n, min(n + S, N), rel0 + g * GSTRIDE, rep);
-                }
-            }
-        }
-    }
-
-    // ---- workgroup reduction: 2*MT*L values, id = (l*MT + m)*2 + {0: re, 1: im} ----------
-    constexpr int NV = 2 * MT * L;
-    static_assert(NV <= 64, "one value per lane after the butterfly");
-    float v[NV];
-#pragma unroll
-    for (int l = 0; l < L; ++l)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            v[(l * MT + m) * 2 + 0] = acc[m][l][0];
-            v[(l * MT + m) * 2 + 1] = acc[m][l][1];
-        }
-    Butterfly<NV, 32>::run(v, lane);
-    s_part[wave * 64 + Butterfly<NV, 32>::index(lane)] = v[0]; // lanes sharing an index hold bit-identical sums
-    __syncthreads();
-
-    if (tid < NV) {
-        float tot = (s_part[tid] + s_part[64 + tid]) + (s_part[128 + tid] + s_part[192 + tid]);
-        if (bad) tot = __builtin_nanf("");
-        const int comp = tid & 1;
-        const int ml = tid >> 1;
-        const int m = at * MT + (ml % MT);
-        const int l = a.tap_index[ml / MT]; // position of this tap in the caller's shift list
-        const size_t bk = (size_t)b * a.K + k;
-        const size_t o = (bk * a.Ltot + l) * a.M + m;
-        if (a.flags & GAT_FLAG_ATOMIC) {
-            atomicAdd((comp ? a.out_im : a.out_re) + o, tot);
-        } else if (a.splits == 1) {
-            (comp ? a.out_im : a.out_re)[o] = tot;
-        } else {
-            const size_t elems = (size_t)a.Ltot * a.M * 2;
-            a.partial[(bk * a.splits + split) * elems + ((size_t)l * a.M + m) * 2 + comp] = tot;
-        }
-    }
-}
 
 // second stage: sum of the per-split partials in a FIXED order (deterministic): one wave64 per
 // output element, lane i adds splits i, i+64, ... sequentially, then a fixed butterfly.
@@ -639,55 +227,22 @@ hipError_t launch_tracking_update(const float *acc_re, const float *acc_im, int 
 // ------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------
-template <int MT, int L>
-static hipError_t launch_dc_ml(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
-{
-    const dim3 grid(cfg.grid), block(kThreads);
-#define GAT_LAUNCH(V, F, K_) hipLaunchKernelGGL((dc_kernel<MT, L, V, F, K_>), grid, block, cfg.lds_bytes, s, a)
-#define GAT_LAUNCH_V(F) do { if (cfg.vec == 4) GAT_LAUNCH(4, F, false); else GAT_LAUNCH(1, F, false); } while (0)
-    // the L2-keeping variant exists for the 16-byte-load float formats only (instance count)
-#define GAT_LAUNCH_VK(F) do { if (cfg.vec == 4 && cfg.keep_l2) GAT_LAUNCH(4, F, true); else GAT_LAUNCH_V(F); } while (0)
-    switch (cfg.format) {
-    case GAT_LAYOUT_PLANAR: GAT_LAUNCH_VK(GAT_LAYOUT_PLANAR); break;
-    case GAT_LAYOUT_INTERLEAVED: GAT_LAUNCH_VK(GAT_LAYOUT_INTERLEAVED); break;
-    case GAT_LAYOUT_INTERLEAVED_I16: GAT_LAUNCH_V(GAT_LAYOUT_INTERLEAVED_I16); break;
-    case GAT_LAYOUT_INTERLEAVED_I8: GAT_LAUNCH_V(GAT_LAYOUT_INTERLEAVED_I8); break;
-    default: return hipErrorInvalidValue;
-    }
-#undef GAT_LAUNCH_VK
-#undef GAT_LAUNCH_V
-#undef GAT_LAUNCH
-    return hipGetLastError();
-}
+// the instances live in gat_dc_f*.hip: do not instantiate them here as well
+extern template hipError_t launch_dc_fmt<GAT_LAYOUT_PLANAR>(const DcArgs &, const DcLaunch &, hipStream_t);
+extern template hipError_t launch_dc_fmt<GAT_LAYOUT_INTERLEAVED>(const DcArgs &, const DcLaunch &, hipStream_t);
+extern template hipError_t launch_dc_fmt<GAT_LAYOUT_INTERLEAVED_I16>(const DcArgs &, const DcLaunch &, hipStream_t);
+extern template hipError_t launch_dc_fmt<GAT_LAYOUT_INTERLEAVED_I8>(const DcArgs &, const DcLaunch &, hipStream_t);
 
-template <int MT>
-static hipError_t launch_dc_m(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
-{
-    switch (cfg.taps) {
-    case 1: return launch_dc_ml<MT, 1>(a, cfg, s);
-    case 2: return launch_dc_ml<MT, 2>(a, cfg, s);
-    case 3: return launch_dc_ml<MT, 3>(a, cfg, s);
-    case 4: return launch_dc_ml<MT, 4>(a, cfg, s);
-    case 5: return launch_dc_ml<MT, 5>(a, cfg, s);
-    case 6: return launch_dc_ml<MT, 6>(a, cfg, s);
-    case 7: return launch_dc_ml<MT, 7>(a, cfg, s);
-    case 8: return launch_dc_ml<MT, 8>(a, cfg, s);
-    default: return hipErrorInvalidValue;
-    }
-}
-
-bool dc_supported(int ant_tile, int taps)
-{
-    return ant_tile >= 1 && ant_tile <= kMaxAntTile && taps >= 1 && taps <= kMaxTapsPerLaunch;
-}
+bool dc_has_instance(int ant_tile, int taps, int vec, int aw, int kt) { return dc_instance(ant_tile, taps, vec, aw, kt); }
 
 hipError_t launch_dc(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
 {
-    switch (cfg.ant_tile) {
-    case 1: return launch_dc_m<1>(a, cfg, s);
-    case 2: return launch_dc_m<2>(a, cfg, s);
-    case 3: return launch_dc_m<3>(a, cfg, s);
-    case 4: return launch_dc_m<4>(a, cfg, s);
+    if (!dc_instance(cfg.ant_tile, cfg.taps, cfg.vec, cfg.aw, cfg.kt)) return hipErrorInvalidValue;
+    switch (cfg.format) {
+    case GAT_LAYOUT_PLANAR: return launch_dc_fmt<GAT_LAYOUT_PLANAR>(a, cfg, s);
+    case GAT_LAYOUT_INTERLEAVED: return launch_dc_fmt<GAT_LAYOUT_INTERLEAVED>(a, cfg, s);
+    case GAT_LAYOUT_INTERLEAVED_I16: return launch_dc_fmt<GAT_LAYOUT_INTERLEAVED_I16>(a, cfg, s);
+    case GAT_LAYOUT_INTERLEAVED_I8: return launch_dc_fmt<GAT_LAYOUT_INTERLEAVED_I8>(a, cfg, s);
     default: return hipErrorInvalidValue;
     }
 }

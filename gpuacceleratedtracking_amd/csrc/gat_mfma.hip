@@ -28,6 +28,7 @@
 // Code replica segments [CT][T + span] are generated per step into LDS exactly as in dc_kernel
 // (FP64 code phase, unfused).
 #include "gat_internal.h"
+#include "gat_phase.h"
 
 namespace gat {
 
@@ -39,38 +40,6 @@ namespace {
 constexpr int kTile = 256;          // samples per step
 constexpr int kXStride = kTile + 1; // floats per plane row in LDS: odd, so that for one sample the 32 planes
                                     // (what one MFMA A fetch reads) sit in 32 different banks
-
-__device__ __forceinline__ void sincos_cycles_m(double theta, float &c, float &s)
-{
-    const double q = __builtin_rint(theta * 4.0);
-    const double r = __builtin_fma(q, -0.25, theta);
-    const float a = (float)r * 6.283185307179586f;
-    const float a2 = a * a;
-    float sp = __builtin_fmaf(a2, 2.7557319e-6f, -1.9841270e-4f);
-    sp = __builtin_fmaf(a2, sp, 8.3333333e-3f);
-    sp = __builtin_fmaf(a2, sp, -1.6666667e-1f);
-    sp = __builtin_fmaf(a2 * a, sp, a);
-    float cp = __builtin_fmaf(a2, 2.4801587e-5f, -1.3888889e-3f);
-    cp = __builtin_fmaf(a2, cp, 4.1666667e-2f);
-    cp = __builtin_fmaf(a2, cp, -0.5f);
-    cp = __builtin_fmaf(a2, cp, 1.0f);
-    const int qi = (int)(long long)q & 3;
-    const float cs = (qi & 1) ? sp : cp;
-    const float sn = (qi & 1) ? cp : sp;
-    c = (qi == 1 || qi == 2) ? -cs : cs;
-    s = (qi >= 2) ? -sn : sn;
-}
-
-__device__ __forceinline__ int chip_index_m(double ratio, double tau, int x, int Lc, float inv_lc)
-{
-    const double p = __dadd_rn(__dmul_rn(ratio, (double)x), tau); // src/algorithms.jl:179, unfused
-    const int ip = (int)__builtin_floor(p);
-    const float q = __builtin_floorf((float)ip * inv_lc);
-    int r = ip - (int)q * Lc;
-    r += (r < 0) ? Lc : 0;
-    r -= (r >= Lc) ? Lc : 0;
-    return r;
-}
 
 struct ChanInfo { // per channel slot of the workgroup, in LDS
     double ratio, tau, step, phi;
@@ -205,12 +174,9 @@ __global__ void __launch_bounds__(2 * kThreads) mfma_kernel(const MfArgs a)
             tau_s[z] = c.tau;
             tab_s[z] = a.codes_in_lds ? (s_code + (have ? slot : 0) * a.code_row_stride)
                                       : (a.codes + (size_t)c.prn * a.code_row_stride);
-            const double p0 = __dadd_rn(__dmul_rn(c.ratio, (double)(x0 + i0)), c.tau);
+            const double p0 = code_phase(c.ratio, c.tau, x0 + i0);
             const int ip0 = (int)__builtin_floor(p0);
-            const float qf = __builtin_floorf((float)ip0 * inv_lc);
-            int idx0 = ip0 - (int)qf * Lc;
-            idx0 += (idx0 < 0) ? Lc : 0;
-            idx0 -= (idx0 >= Lc) ? Lc : 0;
+            const int idx0 = floormod_fast(ip0, Lc, inv_lc);
             ip0_s[z] = ip0;
             idx0_s[z] = idx0;
         }
@@ -220,7 +186,7 @@ __global__ void __launch_bounds__(2 * kThreads) mfma_kernel(const MfArgs a)
             for (int z = 0; z < MS; ++z) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const double pj = __dadd_rn(__dmul_rn(ratio_s[z], (double)(x0 + i0 + j0 + u)), tau_s[z]);
+                    const double pj = code_phase(ratio_s[z], tau_s[z], x0 + i0 + j0 + u);
                     int t = idx0_s[z] + ((int)__builtin_floor(pj) - ip0_s[z]);
                     t -= (t >= Lc) ? Lc : 0; // at most one wrap: E * ratio < Lc (channel marked bad otherwise)
                     ch[z][u] = valid_s[z] > 0 ? (float)tab_s[z][t] : 0.f; // tab_s: LDS or global (generic pointer)
@@ -259,7 +225,7 @@ __global__ void __launch_bounds__(2 * kThreads) mfma_kernel(const MfArgs a)
     const bool live_col = kc < CT && my.valid;
     const int rep_off = slot_c * a.rep_stride + (a.shifts[l < L ? l : 0] - a.shifts[0]);
     float wr, wi;
-    sincos_cycles_m(my.step - __builtin_rint(my.step), wr, wi);
+    sincos_cycles(my.step - __builtin_rint(my.step), wr, wi);
     const float gain = live_col ? 1.f : 0.f; // dead columns multiply by zero
     const int col0 = sub * SW + h * NM;      // first sample (tile-relative) of this lane's stream
 
@@ -282,7 +248,7 @@ __global__ void __launch_bounds__(2 * kThreads) mfma_kernel(const MfArgs a)
         auto anchor = [&](int cb) { // FP64 carrier anchor
             const double th = __builtin_fma((double)(nb + cb), my.step, my.phi);
             float cr, ci;
-            sincos_cycles_m(th - __builtin_rint(th), cr, ci);
+            sincos_cycles(th - __builtin_rint(th), cr, ci);
             p = (comp ? -ci : cr) * gain;
             q = (comp ? cr : ci) * gain;
         };

@@ -33,6 +33,7 @@
 // workgroups, finalize_kernel adds the partials in a fixed order), so the f32 rounding of a running
 // sum of millions of samples stays far inside 1e-5.
 #include "gat_internal.h"
+#include "gat_phase.h"
 
 #include <utility>
 
@@ -59,27 +60,6 @@ constexpr int kMaxChain = 8192;  // samples per accumulation chain (f32 rounding
 constexpr int kReanchor = 16;   // steps between FP64 re-anchors of the producers' carried phasor / code index
 constexpr int kMbMaxSlots = 24;  // channel slots per workgroup (header size)
 constexpr int kHeader = 1536; // ChanInfoB[<= 20] (64 B each) + slack, 16-byte aligned
-
-__device__ __forceinline__ void sincos_cycles_b(double theta, float &c, float &s)
-{
-    const double q = __builtin_rint(theta * 4.0);
-    const double r = __builtin_fma(q, -0.25, theta);
-    const float a = (float)r * 6.283185307179586f;
-    const float a2 = a * a;
-    float sp = __builtin_fmaf(a2, 2.7557319e-6f, -1.9841270e-4f);
-    sp = __builtin_fmaf(a2, sp, 8.3333333e-3f);
-    sp = __builtin_fmaf(a2, sp, -1.6666667e-1f);
-    sp = __builtin_fmaf(a2 * a, sp, a);
-    float cp = __builtin_fmaf(a2, 2.4801587e-5f, -1.3888889e-3f);
-    cp = __builtin_fmaf(a2, cp, 4.1666667e-2f);
-    cp = __builtin_fmaf(a2, cp, -0.5f);
-    cp = __builtin_fmaf(a2, cp, 1.0f);
-    const int qi = (int)(long long)q & 3;
-    const float cs = (qi & 1) ? sp : cp;
-    const float sn = (qi & 1) ? cp : sp;
-    c = (qi == 1 || qi == 2) ? -cs : cs;
-    s = (qi >= 2) ? -sn : sn;
-}
 
 // hi/mid/lo bf16 terms of a float by TRUNCATION: hi = top 16 bits of v, mid = top 16 bits of
 // r = v - hi, lo = top 16 bits of r2 = r - mid.  Every residual is exact in f32 and each term takes 8
@@ -342,9 +322,9 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
                      !(ci.ratio >= 0.0) || !(ci.ratio * 32.0 < (double)Lc) || !(ci.step == ci.step) || !(ci.phi == ci.phi);
             ci.prn = (P.prn < 0 || P.prn >= a.num_prns) ? 0 : P.prn;
             if (ci.bad) { ci.ratio = 0.0; ci.tau = 0.0; ci.step = 0.0; ci.phi = 0.0; }
-            sincos_cycles_b(ci.step - __builtin_rint(ci.step), ci.wr, ci.wi);
+            sincos_cycles(ci.step - __builtin_rint(ci.step), ci.wr, ci.wi);
             const double st_T = ci.step * (double)T;
-            sincos_cycles_b(st_T - __builtin_rint(st_T), ci.wTr, ci.wTi);
+            sincos_cycles(st_T - __builtin_rint(st_T), ci.wTr, ci.wTi);
             ci.inc_ok = ci.ratio * (double)(T + 2) < (double)Lc;
         }
         s_chan[tid] = ci;
@@ -468,16 +448,13 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     auto gen_rep2 = [&](const ChanInfoB &c, const unsigned *tab, unsigned *row, int nb, int e0, int e_end, bool anchor,
                         int &ip_state, int &t_state) {
         const int x0 = nb + a.shifts[0] + e0;
-        const double p0 = __dadd_rn(__dmul_rn(c.ratio, (double)x0), c.tau);
-        const double p1 = __dadd_rn(__dmul_rn(c.ratio, (double)(x0 + 1)), c.tau);
+        const double p0 = code_phase(c.ratio, c.tau, x0);
+        const double p1 = code_phase(c.ratio, c.tau, x0 + 1);
         const int ip0 = (int)__builtin_floor(p0);
         const int ip1 = (int)__builtin_floor(p1);
         int t0;
         if (anchor) {
-            const float qf = __builtin_floorf((float)ip0 * inv_lc);
-            t0 = ip0 - (int)qf * Lc;
-            t0 += (t0 < 0) ? Lc : 0;
-            t0 -= (t0 >= Lc) ? Lc : 0;
+            t0 = floormod_fast(ip0, Lc, inv_lc);
         } else {
             t0 = t_state + (ip0 - ip_state);
             t0 -= (t0 >= Lc) ? Lc : 0;
@@ -535,7 +512,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         float cr, ci;
         if (anchor) {
             const double th = __builtin_fma((double)(nb + 2 * item_q), c.step, c.phi);
-            sincos_cycles_b(th - __builtin_rint(th), cr, ci);
+            sincos_cycles(th - __builtin_rint(th), cr, ci);
         } else { // T samples on from the previous step's first sample
             cr = __builtin_fmaf(car_r, c.wTr, -(car_i * c.wTi));
             ci = __builtin_fmaf(car_r, c.wTi, car_i * c.wTr);

@@ -77,14 +77,16 @@ struct ChipWalkConst {   // per (block, channel): uniform over the workgroup
     int exact_only;          // 1: the walk cannot be trusted at these magnitudes -> evaluate every sample exactly
 };
 
-// max_run: longest run of consecutive samples one anchor serves.  span: the kernels' range bound
+// max_run: most samples an anchor is walked away from (margin); max_advance: most samples ONE step advances
+// (fewer than Lc chips per step: one wrap of the table index at most).  span: the kernels' range bound
 // |tau| + ratio * (N + max|shift|) + 1 (every |code phase| and |ratio * x| of the block is below it).
-__device__ __forceinline__ ChipWalkConst chip_walk_setup(double ratio, double span, int max_run, int Lc)
+__device__ __forceinline__ ChipWalkConst chip_walk_setup(double ratio, double span, int max_run, int max_advance, int Lc)
 {
     ChipWalkConst w;
-    const double m = span * 0x1p-19 /* 2 * 2 * 2^-52 * 2^32, with a factor 2 of slack */ + (double)(max_run + 2);
-    w.exact_only = !(ratio >= 0.0) || !(ratio * (double)(max_run + 1) + 2.0 < (double)Lc) || !(m < 1.0e9) ||
-                   !(ratio < 1.0e9);
+    // two double roundings on each side, each <= 2^-53 * 2 span: 2 * 2^-52 * span * 2^32 = span * 2^-19; doubled for slack
+    const double m = span * 0x1p-18 + (double)(max_run + 2);
+    w.exact_only = !(ratio >= 0.0) || !(ratio * (double)(max_advance + 1) + 2.0 < (double)Lc) || !(m < 1.0e9) ||
+                   !(ratio < 1.0e6);
     w.rate = w.exact_only ? 0ull : (unsigned long long)(ratio * 4294967296.0); // truncation: rate <= ratio * 2^32
     w.margin = w.exact_only ? 0u : (unsigned)m + 1u;
     return w;
@@ -92,7 +94,7 @@ __device__ __forceinline__ ChipWalkConst chip_walk_setup(double ratio, double sp
 
 struct ChipWalk {
     unsigned long long q; // 32.32 fixed point: floor(code phase) in the high word (two's complement), fraction low
-    int base;             // floor(anchor phase) - chip index of the anchor: index = hi(q) - base, wrapped once
+    int base;             // floor(code phase) - table index at the current position: index = hi(q) - base
 };
 
 // exact anchor at sample x; returns its chip index
@@ -108,15 +110,18 @@ __device__ __forceinline__ int chip_walk_anchor(ChipWalk &w, double ratio, doubl
     return idx;
 }
 
-// advance to the next sample; returns the predicted chip index, sets `ambiguous` when the prediction is not proven
-__device__ __forceinline__ int chip_walk_next(ChipWalk &w, const ChipWalkConst &c, int Lc, bool &ambiguous)
+// advance by `rate` (one sample: c.rate; several: a multiple of it); returns the predicted chip index and sets
+// `ambiguous` when the prediction is not proven to equal the reference's floor
+__device__ __forceinline__ int chip_walk_next(ChipWalk &w, unsigned long long rate, unsigned margin, int Lc, bool &ambiguous)
 {
-    w.q += c.rate;
+    w.q += rate;
     const unsigned frac = (unsigned)w.q;
     // safe  <=>  margin <= frac <= 2^32 - 1 - margin  <=>  (frac - margin) <= (2^32 - 1 - 2 margin)   (unsigned)
-    ambiguous = (frac - c.margin) > (0xffffffffu - 2u * c.margin);
+    ambiguous = (frac - margin) > (0xffffffffu - 2u * margin);
     const unsigned idx = (unsigned)((int)(w.q >> 32) - w.base);
-    return (int)min(idx, idx - (unsigned)Lc); // idx < 2 Lc: one conditional subtraction of Lc
+    const unsigned wrapped = min(idx, idx - (unsigned)Lc); // idx < 2 Lc: one conditional subtraction of Lc
+    w.base += (int)(idx - wrapped);                        // keep the table index relative to the current lap
+    return (int)wrapped;
 }
 
 } // namespace gat

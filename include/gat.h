@@ -280,10 +280,20 @@ GAT_API int32_t gat_timer_stop(gat_ctx *ctx, float *elapsed_ms);
 #define GAT_MC_BF16_SPLIT 3
 GAT_API int32_t gat_set_matrix_core(gat_ctx *ctx, int32_t enable);
 
+/* Caps on the vector kernel's workgroup tiling (0 = leave a cap unchanged).  By default a workgroup covers up to 4
+ * antenna tiles (16 antennas: carrier and replica are produced once per workgroup), loops over up to 4 channels with
+ * the samples held in registers, and over several consecutive short blocks.  (1, 1, 1) gives one antenna tile, one
+ * channel and one block per workgroup -- the round-1 geometry; used by A/B measurements and by the parity tests,
+ * which run every tiling against the oracle. */
+GAT_API int32_t gat_set_vector_tiling(gat_ctx *ctx, int32_t max_antenna_tiles, int32_t max_channels,
+                                      int32_t max_blocks);
+
 /* Launch geometry chosen for the last correlate call (diagnostics / DESIGN.md tables). */
 typedef struct gat_launch_info {
     int32_t workgroups, threads, splits, ant_tile, vec, lds_bytes, finalize_launched;
     int32_t matrix_core; /* 0: the vector kernel ran, 1: the f32-MFMA kernel, 2: the split-bf16 MFMA kernel */
+    int32_t channels_per_wg; /* channels one workgroup loops over (signal held in registers / LDS meanwhile)  */
+    int32_t blocks_per_wg;   /* consecutive integration blocks one workgroup loops over                       */
 } gat_launch_info;
 GAT_API int32_t gat_last_launch_info(const gat_ctx *ctx, gat_launch_info *out);
 

@@ -1,0 +1,164 @@
+"""Every workgroup tiling of the fused vector kernel (csrc/gat_dc.h) against the FP64 oracle.
+
+The kernel family is templated on (antennas per wave, antenna-tile waves per workgroup AW, channels per workgroup
+KT -- several only together with AW = 4); the host picks a tiling per shape and `gat_set_vector_tiling` caps it.  These tests force each cap
+combination on the same seeded inputs -- ragged block ends, several short blocks per workgroup, channel counts that
+do not divide KT (trailing invalid channel slots), every sample format -- and compare with the oracle at the north
+star's 1e-5; all tilings must also agree with each other on chip edges (bit-exact replica => identical all-ones sums).
+Run with -m gpu."""
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle
+from tests.helpers import check_close, make_case, oracle_result
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gat():
+    import gpuacceleratedtracking_amd as g
+    g.load_library()
+    return g
+
+
+@pytest.fixture()
+def vector_ctx(gat):
+    ctx = gat.get_context()
+    ctx.set_matrix_core(gat.GAT_MC_VECTOR)
+    yield ctx
+    ctx.set_matrix_core(gat.GAT_MC_AUTO)
+    ctx.set_vector_tiling(4, 4, 16)
+
+
+def run_case(g, ctx, case, layout=0, scale=None):
+    import torch
+    sysobj = g.GNSSDICT[case["system"]](use_gpu=True)
+    dev = ctx.device
+    N, M, B, K = case["N"], case["M"], case["B"], case["K"]
+    op = g.StreamCorrelator(sysobj, N, M, B, K, case["shifts"], case["fs"], ctx=ctx)
+    op.set_params(g.make_params(case["prm"]["prn0"], case["prm"]["code_freq_hz"], case["prm"]["carrier_freq_hz"],
+                                case["prm"]["code_phase_chips"], case["prm"]["carrier_phase_cycles"]))
+    re, im = torch.from_numpy(case["re"]).to(dev), torch.from_numpy(case["im"]).to(dev)
+    if layout == 0:
+        op(re, im)
+    elif layout == 1:
+        op(torch.stack([re, im], dim=-1).contiguous(), None)
+    else:
+        dt = torch.int16 if layout == 2 else torch.int8
+        op(torch.stack([re, im], dim=-1).to(dt).contiguous(), None)
+    return op.result(), ctx.last_launch_info()
+
+
+SHAPES = [
+    # system, N, M, L, K, B
+    ("GPSL1", 20000, 4, 3, 1, 3),    # configs[1] shape
+    ("GPSL1", 5000, 16, 3, 4, 2),    # configs[3] shard shape (shortened): AW = 4, KT = 4
+    ("GPSL1", 5003, 16, 3, 3, 2),    # ragged end, scalar tail, K = 3 -> one invalid channel slot at KT = 4
+    ("GPSL5", 20000, 4, 5, 6, 1),    # configs[2] shape (6 PRNs)
+    ("GPSL1", 4000, 1, 3, 5, 9),     # single antenna, 5 channels, 9 short blocks -> several blocks per workgroup
+    ("GPSL1", 3000, 8, 3, 2, 3),     # two antenna tiles, one workgroup each
+    ("GPSL1", 2047, 12, 7, 2, 2),    # 3 antenna tiles (AW = 1), 7 taps
+    ("GPSL1", 700, 32, 1, 4, 2),     # 8 antenna tiles -> two antenna groups of AW = 4
+    ("GPSL1", 333, 2, 8, 7, 4),      # two antennas per wave, 8 taps, 7 channels
+]
+TILINGS = [(1, 1, 1), (4, 1, 1), (1, 4, 1), (4, 4, 16), (2, 2, 4), (4, 2, 1)]
+
+
+@pytest.mark.parametrize("tiling", TILINGS, ids=[f"aw{t[0]}-kt{t[1]}-bpw{t[2]}" for t in TILINGS])
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"{s[0]}-N{s[1]}-M{s[2]}-L{s[3]}-K{s[4]}-B{s[5]}" for s in SHAPES])
+def test_every_tiling_matches_the_oracle(gat, vector_ctx, shape, tiling):
+    system, N, M, L, K, B = shape
+    case = make_case(zlib.crc32(repr(shape).encode()), system=system, N=N, M=M, L=L, K=K, B=B)
+    vector_ctx.set_vector_tiling(*tiling)
+    got, info = run_case(gat, vector_ctx, case)
+    assert info["matrix_core"] == 0, info
+    assert info["channels_per_wg"] <= tiling[1] and info["blocks_per_wg"] <= tiling[2], info
+    check_close(got, oracle_result(case), what=f"{shape} {tiling} {info}")
+
+
+@pytest.mark.parametrize("layout", [1, 2, 3])
+@pytest.mark.parametrize("tiling", [(1, 1, 1), (4, 4, 16)])
+def test_tilings_in_every_sample_format(gat, vector_ctx, layout, tiling):
+    """Interleaved ComplexF32 / int16 / int8 input: integer-valued samples so that every format holds them exactly."""
+    shape = ("GPSL1", 6000, 16, 3, 4, 2)
+    system, N, M, L, K, B = shape
+    case = make_case(77, system=system, N=N, M=M, L=L, K=K, B=B)
+    amp = 100.0 if layout == 3 else 1000.0
+    peak = max(np.abs(case["re"]).max(), np.abs(case["im"]).max())
+    case["re"] = np.rint(case["re"] * (amp / peak)).astype(np.float32)
+    case["im"] = np.rint(case["im"] * (amp / peak)).astype(np.float32)
+    vector_ctx.set_vector_tiling(*tiling)
+    got, info = run_case(gat, vector_ctx, case, layout=layout)
+    assert info["matrix_core"] == 0
+    check_close(got, oracle_result(case), what=f"layout {layout} {tiling}")
+
+
+def test_chip_edges_identical_in_every_tiling_and_kernel(gat):
+    """All-ones signal, zero carrier: every accumulator is an integer (sum of +-1 chips), so ANY chip-edge
+    disagreement between the exact walk, the matrix kernels and the oracle shows up as a different integer.
+    GPS L5 at 50 MHz (4.9 samples per chip, 5 taps) and a fractional code phase near an edge."""
+    import torch
+    g = gat
+    ctx = g.get_context()
+    N, M, K, L, B = 50000, 16, 4, 5, 2
+    system = g.GPSL5(use_gpu=True)
+    fs, fc = N / 1e-3, 10.23e6
+    shifts = oracle.sample_shifts(L, fs, fc)
+    rng = np.random.default_rng(5)
+    tau = np.array([[0.0, 10229.999999, 5115.5, 1e-9], [3.0 - 1e-12, 7.25, 9000.125, 10229.5]])
+    prm = oracle.make_params(np.broadcast_to(np.arange(K), (B, K)), fc * (1 + rng.uniform(-3e-6, 3e-6, (B, K))),
+                             np.zeros((B, K)), tau, np.zeros((B, K)))
+    re = np.ones((M, B * N), dtype=np.float32)
+    im = np.zeros_like(re)
+    ref = oracle.correlate_f64(re, im, oracle.codes("GPSL5", 32), prm, fs, shifts, N=N)
+    assert np.all(ref.imag == 0) and np.all(ref.real == np.rint(ref.real))
+    op = g.StreamCorrelator(system, N, M, B, K, shifts, fs, ctx=ctx)
+    op.set_params(g.make_params(prm["prn0"], prm["code_freq_hz"], prm["carrier_freq_hz"], prm["code_phase_chips"],
+                                prm["carrier_phase_cycles"]))
+    d_re, d_im = torch.from_numpy(re).to(ctx.device), torch.from_numpy(im).to(ctx.device)
+    try:
+        for mode, tiling in [(g.GAT_MC_VECTOR, (1, 1, 1)), (g.GAT_MC_VECTOR, (4, 4, 16)), (g.GAT_MC_VECTOR, (4, 2, 1)),
+                             (g.GAT_MC_F32, (4, 4, 16)), (g.GAT_MC_BF16_SPLIT, (4, 4, 16))]:
+            ctx.set_matrix_core(mode)
+            ctx.set_vector_tiling(*tiling)
+            op(d_re, d_im)
+            got = op.result()
+            assert np.array_equal(got.real.astype(np.float64), ref.real), (mode, tiling, ctx.last_launch_info())
+            assert np.all(got.imag == 0)
+    finally:
+        ctx.set_matrix_core(g.GAT_MC_AUTO)
+        ctx.set_vector_tiling(4, 4, 16)
+
+
+def test_exact_walk_survives_adversarial_code_phases(gat, vector_ctx):
+    """Code phases chosen so that ratio*(n+shift)+tau lands within a few ulps of an integer at many samples (ratio =
+    exactly 1/16 chip per sample, tau at and around multiples of 1/16): the walk's margin test must hand these to the
+    exact evaluation.  All-ones signal => integer sums, compared exactly."""
+    import torch
+    g = gat
+    N, M, K, L, B = 8192, 4, 4, 3, 3
+    system = g.GPSL1(use_gpu=True)
+    fc = 1.023e6
+    fs = fc * 16.0          # ratio = 1/16 exactly
+    shifts = np.array([-8, 0, 8], dtype=np.int32)
+    eps = np.spacing(512.0)
+    tau = np.array([[0.0, 0.0625, 511.9375, 1022.9375 + 0.0],
+                    [512.0 - eps, 512.0 + eps, 0.0625 - np.spacing(0.0625), 0.0625 + np.spacing(0.0625)],
+                    [1022.0 + 15 * 0.0625, 3 * 0.0625, 700.5, 1e-300]])
+    prm = oracle.make_params(np.broadcast_to(np.arange(K), (B, K)), np.full((B, K), fc), np.zeros((B, K)), tau,
+                             np.zeros((B, K)))
+    re = np.ones((M, B * N), dtype=np.float32)
+    im = np.zeros_like(re)
+    ref = oracle.correlate_f64(re, im, oracle.codes("GPSL1", 32), prm, fs, shifts, N=N)
+    op = g.StreamCorrelator(system, N, M, B, K, shifts, fs, ctx=vector_ctx)
+    op.set_params(g.make_params(prm["prn0"], prm["code_freq_hz"], prm["carrier_freq_hz"], prm["code_phase_chips"],
+                                prm["carrier_phase_cycles"]))
+    d_re, d_im = torch.from_numpy(re).to(vector_ctx.device), torch.from_numpy(im).to(vector_ctx.device)
+    for tiling in [(1, 1, 1), (4, 4, 16)]:
+        vector_ctx.set_vector_tiling(*tiling)
+        op(d_re, d_im)
+        got = op.result()
+        assert np.array_equal(got.real.astype(np.float64), ref.real), tiling
