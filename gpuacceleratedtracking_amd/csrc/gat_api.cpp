@@ -145,10 +145,15 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         int nct = nct_total >= 4 ? 4 : (nct_total >= 2 ? 2 : 1);
         while (nct > 1 && nct * CT > 20) nct >>= 1; // both kernels keep at most 20 channel slots per workgroup
         // kernel choice: 3 / 1 (auto) -> split-bf16 when its tile fits in LDS, 2 -> f32 MFMA.  GAT_MC_AUTO picks a matrix
-        // kernel only where it measured faster than the vector kernel (scripts/planner_threshold_scan.sh, profiles/
-        // r01d_ab_matrix_kernels.txt): split-bf16 from 24 of the first 32 columns on (K = 4 at three taps: break-even,
-        // K = 2, 3: the vector kernel is 1.1-1.4x faster), the f32-MFMA kernel only for large antenna x channel products.
-        const bool auto_bf16 = 2ll * L * K >= 24, auto_f32 = auto_bf16 && (long long)M * K >= 2048;
+        // kernel only where it measured faster than the vector kernel (scripts/r02_planner_scan.sh, profiles/r02/
+        // r02d_planner_scan.txt; N = 50 000, 3 taps): with float samples the re-tiled vector kernel (16 antennas per
+        // workgroup, channel loop over register-resident samples) wins at 16 antennas for every channel count and at
+        // 32 / 64 antennas up to ~4-8 channels, so the split-bf16 kernel takes M >= 32 with M * K >= 512; from int8
+        // pairs (single-term path, half the MFMAs) it wins from 24 (channel, tap, re/im) columns on at every M.  The
+        // f32-MFMA kernel serves only code tables that are not +-1, at large antenna x channel products.
+        const bool int8_in = fmt == GAT_LAYOUT_INTERLEAVED_I8;
+        const bool auto_bf16 = 2ll * L * K >= 24 && (int8_in || (M >= 32 && (long long)M * K >= 512));
+        const bool auto_f32 = 2ll * L * K >= 24 && (long long)M * K >= 2048;
         const bool want_bf16 = c->mc_mode == 3 || (c->mc_mode == 1 && auto_bf16);
         const bool want_f32 = c->mc_mode == 2 || (c->mc_mode == 1 && auto_f32);
         int kind = 0, rt = 1, rep_stride_m = 0;
@@ -306,10 +311,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     while (kt > 1 && !dc_has_instance(MT, max_taps, vec, aw, kt)) kt >>= 1;
     while (aw > 1 && !dc_has_instance(MT, max_taps, vec, aw, kt)) aw >>= 1;
     // LDS: two workgroups per CU at least (80 KB each); a chip table that does not even fit alone is an error
-    auto lds_of = [&](int kt_, int aw_) {
-        const int ch = dc_chunk(vec, fmt, aw_);
-        return dc_lds_bytes(kt_, c->code_row_stride, dc_rep_plane_stride(ch, dc_segment_steps(ch, kt_, 1 << 30), kMaxReplicaSpan));
-    };
+    auto lds_of = [&](int kt_, int aw_) { return dc_lds_bytes(kt_, MT, c->code_row_stride, dc_chunk(vec, fmt, aw_)); };
     while (kt > 1 && lds_of(kt, aw) > 80 * 1024) kt >>= 1;
     if (lds_of(kt, aw) > 160 * 1024)
         return fail(c, GAT_ERR_RANGE, "code table too long for the LDS-resident chip table of the vector kernel");
@@ -388,7 +390,8 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     cfg.vec = vec;
     cfg.format = fmt;
     cfg.grid = (unsigned)grid_wgs;
-    a.seg_steps = dc_segment_steps((int)chunk, kt, (int)cps);
+    a.seg_steps = (int)std::min<long long>(dc_segment_steps((int)chunk, kt, MT), cps);
+    cfg.lds_bytes = (unsigned)dc_lds_bytes(kt, MT, c->code_row_stride, (int)chunk);
 
     // Taps in any order: tap_index maps each tap of a launch back to its position in the caller's list
     // (a single-tap launch always fits: span 0).
@@ -403,13 +406,13 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             a.tap_index[l] = order[t0 + std::min(l, cfg.taps - 1)];
         }
         a.rep_span = a.shifts[cfg.taps - 1] - a.shifts[0];
+        a.tap_step = cfg.taps > 1 ? a.shifts[1] - a.shifts[0] : 0;
+        for (int l = 1; l < cfg.taps; ++l)
+            if (a.shifts[l] - a.shifts[0] != l * a.tap_step) a.tap_step = -1;
         // replica producers: kThreads / kt threads per channel, a quarter of them per plane; slots per thread and segment
         const int per_plane = kThreads / kt / 4;
         const long long seg_slots = (a.seg_steps * chunk + a.rep_span + 3) / 4;
         a.rep_run = (int)((seg_slots + per_plane - 1) / per_plane);
-        a.rep_plane_stride = kt == 1 ? dc_rep_plane_stride((int)chunk, a.seg_steps, a.rep_span)
-                                     : dc_rep_plane_stride((int)chunk, dc_segment_steps((int)chunk, kt, 1 << 30), kMaxReplicaSpan);
-        cfg.lds_bytes = (unsigned)dc_lds_bytes(kt, c->code_row_stride, a.rep_plane_stride);
         GAT_HIP(c, launch_dc(a, cfg, c->stream));
         t0 = t1;
     }

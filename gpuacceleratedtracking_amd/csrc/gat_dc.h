@@ -212,11 +212,8 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
     ChanConst *s_const = reinterpret_cast<ChanConst *>(smem);                          // [KT]
     float *s_part = reinterpret_cast<float *>(smem + KT * sizeof(ChanConst));          // [KT][4][64]
     float *s_rep = s_part + KT * 4 * 64;                                               // [KT][4][RPS]
-    const int SEG = a.seg_steps;        // steps whose replica is produced at once (host: LDS budget, block length)
-    // floats per replica plane: sized by the host for the segment of THIS launch when one channel is walked (short
-    // blocks then leave LDS for more workgroups per CU); compile-time with several channels, so that a channel's
-    // replica is an immediate offset from the first one's (scalar registers are scarce there)
-    const int RPS = KT == 1 ? a.rep_plane_stride : dc_rep_plane_stride(CHUNK, dc_segment_steps(CHUNK, KT, 1 << 30), kMaxReplicaSpan);
+    const int SEG = a.seg_steps;        // steps whose replica is produced at once (<= dc_segment_steps(CHUNK, KT, MT))
+    constexpr int RPS = dc_rep_plane_stride(CHUNK, KT, MT); // floats per replica plane
     int8_t *s_code = reinterpret_cast<int8_t *>(s_rep + KT * 4 * RPS);                 // [KT][code_row_stride]
 
     const int tid = threadIdx.x;
@@ -369,6 +366,47 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
                 chip[l] = rep[(i & 3) * RPS + (i >> 2)];
             }
         };
+        // chips of the S samples of one group (first sample at segment-relative position rel, a multiple of 4) for the
+        // L taps.  Entry (rel + j + o) sits in plane (j + o) & 3 -- the same for every lane -- at slot rel/4 + (j + o)/4.
+        // For evenly spaced taps (o_l = l * step: every E/P/L... correlator) the planes follow from step & 3 alone: a
+        // wave-uniform 4-way switch makes every read an immediate offset from ONE lane address per tap (the plain form
+        // costs 4-5 vector instructions of address arithmetic per read: a quarter of the step loop at 5 taps).
+        // The reads are inline assembly (left to itself the compiler sinks the cases' reads into one block and turns the
+        // immediates back into per-read additions).  It does not count asm loads: each case waits for its reads
+        // (lgkmcnt) and passes every destination through an empty statement after the wait BEFORE the case ends, so
+        // neither a consumer nor a register copy at the merge can come before the data.
+        auto fetch_chips = [&](auto tag, float (&chip)[S][L], unsigned pl) {
+            constexpr int A = decltype(tag)::value; // tap spacing & 3
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                const unsigned p = pl + (unsigned)((l * a.tap_step) >> 2) * 4u;
+#pragma unroll
+                for (int j = 0; j < S; ++j)
+                    asm volatile("ds_read_b32 %0, %1 offset:%2"
+                                 : "=v"(chip[j][l])
+                                 : "v"(p), "i"((((j + l * A) & 3) * RPS + ((j + ((l * A) & 3)) >> 2)) * 4)
+                                 : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < S; ++j)
+#pragma unroll
+                for (int l = 0; l < L; ++l) asm volatile("" : "+v"(chip[j][l]));
+        };
+        auto get_chips_group = [&](float (&chip)[S][L], int rel, const float *rep) {
+            if (S % 4 == 0 && a.tap_step >= 0) { // wave-uniform
+                const unsigned pl = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)(rep + (rel >> 2));
+                switch (a.tap_step & 3) {
+                case 0: fetch_chips(std::integral_constant<int, 0>{}, chip, pl); break;
+                case 1: fetch_chips(std::integral_constant<int, 1>{}, chip, pl); break;
+                case 2: fetch_chips(std::integral_constant<int, 2>{}, chip, pl); break;
+                default: fetch_chips(std::integral_constant<int, 3>{}, chip, pl); break;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < S; ++j) get_chips(chip[j], rel + j, rep);
+            }
+        };
         // one sample of one antenna: conj(carrier) wipe-off (src/algorithms.jl:175-176), L taps.  Plain scalar FMAs:
         // v_pk_fma_f32 issues at the rate of two v_fma_f32 on gfx950 but needs its operands in aligned register
         // pairs -- the packed form cost ~20 % extra v_mov in this loop (the dc translation units are built with
@@ -501,8 +539,7 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
                             const int rel = srel + rel0 + g * GSTRIDE;
                             float pr[S], pi[S], chip[S][L];
                             group_phasors(pr, pi, kk, g);
-#pragma unroll
-                            for (int j = 0; j < S; ++j) get_chips(chip[j], rel + j, s_rep + kk * 4 * RPS);
+                            get_chips_group(chip, rel, s_rep + kk * 4 * RPS);
 #pragma unroll
                             for (int m = 0; m < MT; ++m) {
 #pragma unroll

@@ -52,8 +52,8 @@ struct DcArgs {
     int max_abs_shift;     // max |shift| over ALL taps of the call (range check)
     int rep_span;          // shifts[last] - shifts[0] of THIS launch's taps (replica halo)
     int rep_run;           // replica slots one producer thread fills per segment
-    int seg_steps;         // steps per segment (replica produced at once)
-    int rep_plane_stride;  // floats per replica plane
+    int seg_steps;         // steps per segment (replica produced at once), <= dc_segment_steps()
+    int tap_step;          // shifts[l] - shifts[0] == l * tap_step for every tap of this launch, or -1 (uneven spacing)
     int keep_l2;           // 1: plain loads (several channel groups share the tile through L2), 0: non-temporal
     unsigned flags;
     int shifts[kMaxTapsPerLaunch];    // ascending
@@ -70,24 +70,27 @@ struct DcLaunch {
     unsigned grid;
     unsigned lds_bytes;
 };
-// Steps whose code replica one workgroup produces at once (a "segment"): ~8192 entries per workgroup over its kt
-// channels, no more than the steps a workgroup has per block
-constexpr int dc_segment_steps(int chunk, int kt, int steps_per_wg)
+// Most steps whose code replica one workgroup produces at once (a "segment").  One channel per workgroup: ~8192 entries
+// (39 KB of LDS) when a wave carries 3-4 antennas -- those instances are limited to 3 workgroups per CU by registers
+// anyway, and longer segments mean fewer barriers (configs[1]: 0.846 vs 0.822 of HBM) --, ~4096 entries (25 KB) for 1-2
+// antennas per wave, where LDS is what limits the workgroups per CU; ~8192 entries over the channels of a channel-
+// looping workgroup.  The host may ask for fewer (short blocks).
+constexpr int dc_segment_steps(int chunk, int kt, int mt)
 {
-    int s = 8192 / (kt * chunk);
-    s = s < 2 ? 2 : (s > 8 ? 8 : s);
-    return s > steps_per_wg ? (steps_per_wg < 1 ? 1 : steps_per_wg) : s;
+    const int s = (kt == 1 ? (mt >= 3 ? 8192 : 4096) : 8192 / kt) / chunk;
+    return s < 2 ? 2 : (s > 8 ? 8 : s);
 }
-// Floats per plane of the 4-plane replica of one segment: segment samples + tap span + room for every producer run to
-// be stored whole (up to 64 producer threads per plane, < 4 spare slots each ... 256), == 8 (mod 32)
-constexpr int dc_rep_plane_stride(int chunk, int seg_steps, int span)
+// Floats per plane of the 4-plane replica of one segment: segment samples + kMaxReplicaSpan taps + room for every
+// producer run to be stored whole (up to 64 producer threads per plane, < 4 spare slots each ... 256).  Compile-time:
+// every chip read of the step loop is an immediate offset from one lane base.
+constexpr int dc_rep_plane_stride(int chunk, int kt, int mt)
 {
-    return (((seg_steps * chunk + span + 3) / 4 + 256 + 23) / 32) * 32 + 8;
+    return (((dc_segment_steps(chunk, kt, mt) * chunk + kMaxReplicaSpan + 3) / 4 + 256 + 23) / 32) * 32 + 8;
 }
 // dynamic LDS of one dc_kernel workgroup: per-channel constants, reduction scratch, one segment's replica, chip tables
-constexpr size_t dc_lds_bytes(int kt, int code_row_stride, int rep_plane_stride)
+constexpr size_t dc_lds_bytes(int kt, int mt, int code_row_stride, int chunk)
 {
-    return (size_t)kt * 32 + (size_t)kt * 4 * 64 * sizeof(float) + (size_t)kt * 4 * rep_plane_stride * sizeof(float) +
+    return (size_t)kt * 32 + (size_t)kt * 4 * 64 * sizeof(float) + (size_t)kt * 4 * dc_rep_plane_stride(chunk, kt, mt) * sizeof(float) +
            (size_t)kt * code_row_stride;
 }
 // does an instance of dc_kernel exist for this combination (gat_dc.h: dc_instance)

@@ -58,14 +58,17 @@ GRID = [
 @pytest.mark.parametrize("cfg", GRID, ids=lambda c: f"{c[0]}-N{c[1]}-M{c[2]}-L{c[3]}-K{c[4]}-B{c[5]}")
 def test_mfma_parity(g, cfg):
     system, N, M, L, K, B = cfg[:6]
-    auto_kind = cfg[6] if len(cfg) > 6 else 2
+    # GAT_MC_AUTO (float samples): the split-bf16 kernel from 24 (channel, tap, re/im) columns on when M >= 32 and
+    # M * K >= 512; below that the re-tiled vector kernel measured faster (profiles/r02/r02d_planner_scan.txt)
+    auto_kind = cfg[6] if len(cfg) > 6 else (2 if (2 * L * K >= 24 and M >= 32 and M * K >= 512) else 0)
     forced = 2 if not (L == 1 and K == 16) else 1  # GAT_MC_BF16_SPLIT takes every shape whose tile fits
     fs = {"GPSL1": 8e6, "GPSL5": 25e6}[system] if L <= 5 else 2.5e6
     case = make_case(zlib.crc32(repr(cfg).encode()), system=system, N=N, M=M, L=L, K=K, B=B, fs=fs, if_hz=1.1e6)
     ref = oracle_result(case)
-    got, info = run(g, case)  # auto: the split-bf16 kernel where it is the fastest
+    auto, info = run(g, case)  # auto: the split-bf16 kernel where it is the fastest
     assert info["matrix_core"] == auto_kind, info
-    check_close(got, ref, what=f"auto (kind {auto_kind}) mfma {cfg}")
+    check_close(auto, ref, what=f"auto (kind {auto_kind}) mfma {cfg}")
+    got = auto
     if forced == 2:
         got, info = run(g, case, matrix_core=g.GAT_MC_BF16_SPLIT)
         assert info["matrix_core"] == 2, info
@@ -86,7 +89,7 @@ def test_mfma_unsorted_taps_atomic_and_determinism(g):
     case["shifts"] = np.array([4, -4, 0, 9, -120], dtype=np.int32)
     case["L"] = 5
     ref = oracle_result(case)
-    for mode, kind in ((g.GAT_MC_AUTO, 2), (g.GAT_MC_F32, 1)):
+    for mode, kind in ((g.GAT_MC_BF16_SPLIT, 2), (g.GAT_MC_F32, 1)):
         got, info = run(g, case, matrix_core=mode)
         assert info["matrix_core"] == kind and info["splits"] > 1, info
         check_close(got, ref, what="unsorted taps")
@@ -97,7 +100,7 @@ def test_mfma_unsorted_taps_atomic_and_determinism(g):
 
 
 def test_planner_keeps_vector_kernel_for_other_shapes(g):
-    for (M, K, L) in ((4, 1, 3), (16, 1, 3), (12, 8, 3), (16, 4, 17)):
+    for (M, K, L) in ((4, 1, 3), (16, 1, 3), (12, 8, 3), (16, 4, 17), (16, 32, 3), (32, 8, 3), (64, 4, 3)):
         case = make_case(7, N=4000, M=M, L=L, K=K, B=1)
         _, info = run(g, case)
         assert info["matrix_core"] == 0, (M, K, L, info)
@@ -130,7 +133,7 @@ def test_split_bf16_ingest_formats(g, cfg, fmt):
     xd = torch.from_numpy(x).to(ctx.device)
     res = {}
     try:
-        for mode, kind in ((g.GAT_MC_AUTO, 2), (g.GAT_MC_VECTOR, 0)):
+        for mode, kind in ((g.GAT_MC_BF16_SPLIT, 2), (g.GAT_MC_VECTOR, 0)):
             ctx.set_matrix_core(mode)
             op = g.StreamCorrelator(sysobj, N, M, B, K, case["shifts"], case["fs"])
             op.set_params(prm)
@@ -153,7 +156,7 @@ def test_planner_fallbacks_of_the_split_bf16_kernel(g):
     # two taps: 8 channels per f32 tile; 20 channels pack flat into 80 columns = 3 split-bf16 tiles
     case = make_case(12, N=6000, M=16, L=2, K=20, B=2, fs=4e6)
     ref = oracle_result(case)
-    for mode, kind in ((g.GAT_MC_AUTO, 2), (g.GAT_MC_F32, 1), (g.GAT_MC_VECTOR, 0)):
+    for mode, kind in ((g.GAT_MC_BF16_SPLIT, 2), (g.GAT_MC_F32, 1), (g.GAT_MC_VECTOR, 0), (g.GAT_MC_AUTO, 0)):
         got, info = run(g, case, matrix_core=mode)
         assert info["matrix_core"] == kind, (mode, info)
         check_close(got, ref, what=f"L=2 K=20 mode {mode}")
@@ -201,7 +204,7 @@ def test_mfma_bad_prn_poisons_output(g):
     op.params_dev = ctx.params_to_device(bad)
     op._prepared = None
     try:
-        for mode, kind in ((g.GAT_MC_AUTO, 2), (g.GAT_MC_F32, 1)):
+        for mode, kind in ((g.GAT_MC_BF16_SPLIT, 2), (g.GAT_MC_F32, 1)):
             ctx.set_matrix_core(mode)
             op(re, im)
             out = op.result()
@@ -219,7 +222,7 @@ def test_split_bf16_extreme_dynamic_range(g):
     case["re"] = (case["re"].reshape(16, -1) * gains[:, None]).reshape(case["re"].shape)
     case["im"] = (case["im"].reshape(16, -1) * gains[:, None]).reshape(case["im"].shape)
     ref = oracle_result(case)
-    got, info = run(g, case)
+    got, info = run(g, case, matrix_core=g.GAT_MC_BF16_SPLIT)
     assert info["matrix_core"] == 2
     vec, _ = run(g, case, matrix_core=g.GAT_MC_VECTOR)
     scale = np.abs(ref).max(axis=(2,), keepdims=True)  # per (block, channel, antenna): max over taps

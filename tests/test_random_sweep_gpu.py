@@ -125,7 +125,7 @@ def test_random_matrix_case(g, seed):
     abs_floor = frac * cfg["N"] * float(np.sqrt(np.mean(case["re"].astype(np.float64) ** 2 + case["im"].astype(np.float64) ** 2)))
     kinds = []
     try:
-        for mode in (g.GAT_MC_AUTO, g.GAT_MC_F32, g.GAT_MC_VECTOR):
+        for mode in (g.GAT_MC_AUTO, g.GAT_MC_F32, g.GAT_MC_VECTOR, g.GAT_MC_BF16_SPLIT):
             ctx.set_matrix_core(mode)
             op = g.StreamCorrelator(sysobj, cfg["N"], cfg["M"], cfg["B"], cfg["K"], case["shifts"], cfg["fs"], flags=flags)
             op.set_params(prm)
@@ -135,4 +135,4 @@ def test_random_matrix_case(g, seed):
                         what=f"seed {seed} mode {mode} kernel {kinds[-1]}: {cfg} layout {layout} shifts {case['shifts'].tolist()} flags {flags}")
     finally:
         ctx.set_matrix_core(1)
-    assert kinds[2] == 0 and kinds[1] in (0, 1) and kinds[0] in (0, 1, 2)
+    assert kinds[2] == 0 and kinds[1] in (0, 1) and kinds[0] in (0, 1, 2) and kinds[3] in (0, 1, 2)
