@@ -30,7 +30,8 @@ EXPORTS = [
     "gat_downconvert_and_correlate", "gat_downconvert_and_correlate_dev", "gat_gen_code_replica",
     "gat_gen_code_replica_f32coord",
     "gat_gen_signal", "gat_reduce_cplx_multi", "gat_tracking_update", "gat_malloc", "gat_free", "gat_memcpy_h2d",
-    "gat_memcpy_d2h", "gat_memset", "gat_timer_start", "gat_timer_stop", "gat_last_launch_info", "gat_set_matrix_core", "gat_tracking_run", "gat_set_vector_tiling",
+    "gat_memcpy_d2h", "gat_memset", "gat_timer_start", "gat_timer_stop", "gat_last_launch_info", "gat_set_matrix_core", "gat_tracking_run", "gat_set_vector_tiling", "gat_gen_code_replica_multi",
+    "gat_downconvert_and_accumulate",
 ]
 
 
@@ -143,6 +144,8 @@ def load(build_if_missing: bool = True):
         "gat_last_launch_info": (i32, [vp, C.POINTER(LaunchInfo)]),
         "gat_set_matrix_core": (i32, [vp, i32]),
         "gat_set_vector_tiling": (i32, [vp, i32, i32, i32]),
+        "gat_gen_code_replica_multi": (i32, [vp, vp, i64, i64, i32, vp, dbl, i64]),
+        "gat_downconvert_and_accumulate": (i32, [vp, sp, pp, i32, i32p, dbl, vp, vp, vp, vp, vp, vp]),
     }
     assert sorted(sigs) == sorted(EXPORTS)
     for name, (res, args) in sigs.items():

@@ -142,6 +142,7 @@ def kernel_algorithm(*args):
         if len(args) != 28:
             raise TypeError(f"KernelAlgorithm({aid}) takes 28 positional arguments, got {len(args)}")
         res_re, res_im = args[14], args[15]  # phi_re, phi_im hold the reduced result
+        accum = (args[12], args[13])         # [N x M x L] per-sample products of the materialising stage
         rest = args[16:]
     elif aid in _FORM_C:
         if len(args) != 26:
@@ -168,6 +169,18 @@ def kernel_algorithm(*args):
     ctx.downconvert_and_correlate(desc, prm, 1, 1, sh, float(sampling_frequency), out_re, out_im,
                                   algorithm_flags(algorithm))
     _store(res_re, res_im, out_re, out_im)
+    if aid in _FORM_B:
+        # algorithm 2 materialises its middle stage (src/algorithms.jl:1093-1110): fill the caller's buffers when they
+        # are real ones ([L, M, N] products, [N] carrier, [M, N] downconverted signal); the RESULT above still comes
+        # from the fused kernel
+        n = int(num_samples)
+        bufs = [b if isinstance(b, torch.Tensor) and b.dtype == torch.float32 and b.is_contiguous() and b.numel() >= need
+                else None
+                for b, need in ((accum[0], n * M * sh.size), (accum[1], n * M * sh.size), (_car_re, n), (_car_im, n),
+                                (_dw_re, n * M), (_dw_im, n * M))]
+        if any(b is not None for b in bufs):
+            ctx.downconvert_and_accumulate(desc, prm.reshape(-1), sh, float(sampling_frequency), bufs[2], bufs[3], bufs[4],
+                                           bufs[5], bufs[0], bufs[1])
     return None
 
 

@@ -162,6 +162,37 @@ class Context:
                 float(code_phase), int(first_shift))
         self.check(rc, "gat_gen_code_replica")
 
+    def gen_code_replica_multi(self, out: torch.Tensor, count: int, params_dev: torch.Tensor, num_channels: int,
+                               sampling_frequency: float, first_shift: int):
+        """out: float32 [num_channels, >= count] (row k = channel k); params_dev: gat_channel_params[num_channels]."""
+        if out.dtype != torch.float32 or out.dim() != 2 or out.shape[0] < num_channels or out.shape[1] < count or out.stride(1) != 1:
+            raise ValueError("replica tensor must be float32 [num_channels, >= count] with unit inner stride")
+        if params_dev.numel() * params_dev.element_size() < num_channels * 40:
+            raise ValueError("device params tensor too small")
+        rc = self.lib.gat_gen_code_replica_multi(self._h, C.c_void_p(_ptr(out)), count, out.stride(0), num_channels,
+                                                 C.c_void_p(_ptr(params_dev)), float(sampling_frequency), int(first_shift))
+        self.check(rc, "gat_gen_code_replica_multi")
+
+    def downconvert_and_accumulate(self, desc: _lib.SignalDesc, params, shifts, sampling_frequency: float,
+                                   carrier_re=None, carrier_im=None, dw_re=None, dw_im=None, accum_re=None, accum_im=None):
+        """The reference's materialising algorithm-2 stage (include/gat.h gat_downconvert_and_accumulate): any of
+        carrier [N], downconverted [M, N], accum [L, M, N] (float32, contiguous) may be None."""
+        sh = np.ascontiguousarray(shifts, dtype=np.int32)
+        prm = np.ascontiguousarray(params, dtype=_lib.PARAMS_DTYPE).reshape(-1)
+        if prm.size != 1:
+            raise ValueError("one channel")
+        n, m = int(desc.num_samples), int(desc.num_ants)
+        for t, need in ((carrier_re, n), (carrier_im, n), (dw_re, n * m), (dw_im, n * m), (accum_re, n * m * sh.size),
+                        (accum_im, n * m * sh.size)):
+            if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.numel() < need):
+                raise ValueError("debug outputs must be contiguous float32 tensors of sufficient size")
+        rc = self.lib.gat_downconvert_and_accumulate(
+            self._h, C.byref(desc), prm.ctypes.data_as(C.POINTER(_lib.ChannelParams)), int(sh.size),
+            sh.ctypes.data_as(C.POINTER(C.c_int32)), float(sampling_frequency), C.c_void_p(_ptr(carrier_re)),
+            C.c_void_p(_ptr(carrier_im)), C.c_void_p(_ptr(dw_re)), C.c_void_p(_ptr(dw_im)), C.c_void_p(_ptr(accum_re)),
+            C.c_void_p(_ptr(accum_im)))
+        self.check(rc, "gat_downconvert_and_accumulate")
+
     def gen_signal(self, re: torch.Tensor, im: torch.Tensor | None, layout: int, num_samples: int,
                    num_ants: int, ant_stride: int, block_stride: int, num_blocks: int, num_channels: int,
                    params_dev: torch.Tensor, sampling_frequency: float, amplitude: float = 1.0):

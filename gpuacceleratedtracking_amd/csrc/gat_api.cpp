@@ -705,6 +705,54 @@ GAT_API int32_t gat_gen_code_replica_f32coord(gat_ctx *c, float *rep, int64_t co
     return gen_code_replica_impl(c, rep, count, prn, fc, fs, tau, first_shift, true);
 }
 
+GAT_API int32_t gat_gen_code_replica_multi(gat_ctx *c, float *rep, int64_t count, int64_t row_stride, int32_t K,
+                                           const gat_channel_params *params_dev, double fs, int64_t first_shift)
+{
+    if (!c || !rep || !params_dev) return fail(c, GAT_ERR_ARG, "null argument");
+    if (!c->d_codes) return fail(c, GAT_ERR_STATE, "gat_set_codes has not been called");
+    if (count < 1 || K < 1 || K > 65535 || row_stride < count) return fail(c, GAT_ERR_ARG, "bad sizes");
+    if (!(fs > 0.0) || count + std::llabs((long long)first_shift) >= (1ll << 30)) return fail(c, GAT_ERR_RANGE, "replica too long");
+    GAT_HIP(c, hipSetDevice(c->device));
+    GAT_HIP(c, launch_gen_code_replica_multi(rep, count, row_stride, K, params_dev, c->d_codes, c->code_row_stride, c->Lc,
+                                             c->P, fs, first_shift, c->stream));
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_downconvert_and_accumulate(gat_ctx *c, const gat_signal_desc *sig, const gat_channel_params *p,
+                                               int32_t L, const int32_t *shifts, double fs, float *car_re, float *car_im,
+                                               float *dw_re, float *dw_im, float *acc_re, float *acc_im)
+{
+    if (!c || !sig || !p || !shifts) return fail(c, GAT_ERR_ARG, "null argument");
+    if (!c->d_codes) return fail(c, GAT_ERR_STATE, "gat_set_codes has not been called");
+    if (sig->layout != GAT_LAYOUT_PLANAR || !sig->re || !sig->im) return fail(c, GAT_ERR_UNSUPPORTED, "planar float signal only");
+    if (L < 1 || L > GAT_MAX_TAPS || sig->num_ants < 1 || sig->num_samples < 1 || sig->num_samples >= (1ll << 30))
+        return fail(c, GAT_ERR_RANGE, "size out of range");
+    if (p->prn < 0 || p->prn >= c->P) return fail(c, GAT_ERR_RANGE, "prn outside the code table");
+    if (!(fs > 0.0) || !std::isfinite(p->code_freq_hz) || !(p->code_freq_hz >= 0.0) || !std::isfinite(p->carrier_freq_hz) ||
+        !std::isfinite(p->code_phase_chips) || !std::isfinite(p->carrier_phase_cycles))
+        return fail(c, GAT_ERR_ARG, "bad frequency / phase");
+    GAT_HIP(c, hipSetDevice(c->device));
+    // the tap list goes through the library's parameter scratch (device memory the kernel can read)
+    const size_t need = ((size_t)L * sizeof(int32_t) + sizeof(gat_channel_params) - 1) / sizeof(gat_channel_params);
+    if (need > c->params_cap) {
+        if (c->d_params) {
+            GAT_HIP(c, hipStreamSynchronize(c->stream));
+            GAT_HIP(c, hipFree(c->d_params));
+            c->d_params = nullptr;
+            c->params_cap = 0;
+        }
+        GAT_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->d_params), need * sizeof(gat_channel_params)));
+        c->params_cap = need;
+    }
+    GAT_HIP(c, hipMemcpyAsync(c->d_params, shifts, (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    GAT_HIP(c, launch_accumulate_debug(static_cast<const float *>(sig->re), static_cast<const float *>(sig->im),
+                                       sig->num_samples, sig->num_ants, sig->ant_stride, *p,
+                                       c->d_codes + (size_t)p->prn * c->code_row_stride, c->Lc, fs, L,
+                                       reinterpret_cast<const int *>(c->d_params), car_re, car_im, dw_re, dw_im, acc_re, acc_im,
+                                       c->stream));
+    return GAT_OK;
+}
+
 GAT_API int32_t gat_gen_signal(gat_ctx *c, void *re, void *im, int32_t layout, int64_t N, int32_t M,
                                int64_t ant_stride, int64_t block_stride, int32_t B, int32_t K,
                                const gat_channel_params *params_dev, double fs, double amplitude)

@@ -146,6 +146,13 @@ hipError_t launch_finalize(const float *partial, float *out_re, float *out_im, i
 hipError_t launch_gen_code_replica(float *rep, long long count, const int8_t *code_row, int Lc,
                                    double fc, double fs, double tau, long long first_shift,
                                    bool f32_coordinates, hipStream_t s);
+hipError_t launch_gen_code_replica_multi(float *rep, long long count, long long row_stride, int K,
+                                         const gat_channel_params *params, const int8_t *codes, int code_row_stride,
+                                         int Lc, int num_prns, double fs, long long first_shift, hipStream_t s);
+hipError_t launch_accumulate_debug(const float *sig_re, const float *sig_im, long long N, int M, long long ant_stride,
+                                   const gat_channel_params &P, const int8_t *code_row, int Lc, double fs, int L,
+                                   const int *shifts_dev, float *car_re, float *car_im, float *dw_re, float *dw_im,
+                                   float *acc_re, float *acc_im, hipStream_t s);
 hipError_t launch_gen_signal(void *re, void *im, int format, long long N, int M,
                              long long ant_stride, long long block_stride, int B, int K,
                              const gat_channel_params *params, const int8_t *codes, int code_row_stride,

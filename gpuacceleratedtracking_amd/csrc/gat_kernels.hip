@@ -62,6 +62,60 @@ code_replica_kernel(float *__restrict__ rep, long long count, const int8_t *__re
     }
 }
 
+// gen_code_replica_texture_mem_strided_nsat_kernel! (src/algorithms.jl:78-98): one replica row per satellite channel
+// (grid.y = channel), each with its own PRN, code rate and code phase; exact index arithmetic.
+__global__ void __launch_bounds__(kThreads)
+code_replica_multi_kernel(float *__restrict__ rep, long long count, long long row_stride, int K,
+                          const gat_channel_params *__restrict__ params, const int8_t *__restrict__ codes,
+                          int code_row_stride, int Lc, int num_prns, double fs, long long first_shift)
+{
+    const int k = blockIdx.y;
+    if (k >= K) return;
+    const gat_channel_params P = params[k];
+    const bool bad = P.prn < 0 || P.prn >= num_prns;
+    const int8_t *code = codes + (size_t)(bad ? 0 : P.prn) * code_row_stride;
+    const double ratio = P.code_freq_hz / fs;
+    const float inv_lc = 1.0f / (float)Lc;
+    float *row = rep + (size_t)k * row_stride;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < count; i += (long long)gridDim.x * kThreads)
+        row[i] = bad ? __builtin_nanf("") : (float)code[chip_index(ratio, P.code_phase_chips, (int)(i + first_shift), Lc, inv_lc)];
+}
+
+// downconvert_and_accumulate_strided_kernel! (src/algorithms.jl:828-866): the MATERIALISING middle stage of the
+// reference's algorithm 2 -- carrier replica [N], downconverted signal [N x M] and the per-sample products
+// [N x M x L] written to global memory (the fused correlator materialises none of them; this kernel exists so that
+// the reference's test of that stage, test/algorithms.jl:1438-1514, has a counterpart: prompt products == 1, column
+// sums == the correlator result).  Same arithmetic as the fused kernel: double-precision carrier phase reduced to
+// a quadrant, float sincos; conj(carrier) wipe-off; exact chip index.  Any output pointer may be null.
+__global__ void __launch_bounds__(kThreads)
+accumulate_debug_kernel(const float *__restrict__ sig_re, const float *__restrict__ sig_im, long long N, int M,
+                        long long ant_stride, gat_channel_params P, const int8_t *__restrict__ code, int Lc, double fs,
+                        int L, const int *__restrict__ shifts, float *__restrict__ car_re, float *__restrict__ car_im,
+                        float *__restrict__ dw_re, float *__restrict__ dw_im, float *__restrict__ acc_re,
+                        float *__restrict__ acc_im)
+{
+    const double ratio = P.code_freq_hz / fs, step = P.carrier_freq_hz / fs;
+    const float inv_lc = 1.0f / (float)Lc;
+    for (long long n = (long long)blockIdx.x * kThreads + threadIdx.x; n < N; n += (long long)gridDim.x * kThreads) {
+        float cr, ci;
+        const double th = __builtin_fma((double)n, step, P.carrier_phase_cycles);
+        sincos_cycles(th - __builtin_rint(th), cr, ci);
+        if (car_re) car_re[n] = cr;
+        if (car_im) car_im[n] = ci;
+        for (int m = 0; m < M; ++m) {
+            const float xr = sig_re[(size_t)m * ant_stride + n], xi = sig_im[(size_t)m * ant_stride + n];
+            const float dr = __builtin_fmaf(xr, cr, xi * ci), di = __builtin_fmaf(xi, cr, -(xr * ci));
+            if (dw_re) dw_re[(size_t)m * N + n] = dr;
+            if (dw_im) dw_im[(size_t)m * N + n] = di;
+            for (int l = 0; l < L; ++l) {
+                const float chip = (float)code[chip_index(ratio, P.code_phase_chips, (int)n + shifts[l], Lc, inv_lc)];
+                if (acc_re) acc_re[((size_t)l * M + m) * N + n] = chip * dr;
+                if (acc_im) acc_im[((size_t)l * M + m) * N + n] = chip * di;
+            }
+        }
+    }
+}
+
 // gen_signal! (src/gen_signal.jl:64-70, :86-90): Float64 code phase, carrier phase evaluated in
 // Float64 then rounded to Float32 BEFORE cos/sin (src/gen_signal.jl:88), identical antennas.
 // `amplitude` scales the sum (1 = the reference); integer formats store rint(value) saturated.
@@ -269,6 +323,29 @@ hipError_t launch_gen_code_replica(float *rep, long long count, const int8_t *co
     else
         hipLaunchKernelGGL(code_replica_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0, s, rep, count,
                            code_row, Lc, fc, fs, tau, first_shift);
+    return hipGetLastError();
+}
+
+hipError_t launch_gen_code_replica_multi(float *rep, long long count, long long row_stride, int K,
+                                         const gat_channel_params *params, const int8_t *codes, int code_row_stride,
+                                         int Lc, int num_prns, double fs, long long first_shift, hipStream_t s)
+{
+    long long bx = (count + kThreads - 1) / kThreads;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(code_replica_multi_kernel, dim3((unsigned)bx, (unsigned)K), dim3(kThreads), 0, s, rep, count,
+                       row_stride, K, params, codes, code_row_stride, Lc, num_prns, fs, first_shift);
+    return hipGetLastError();
+}
+
+hipError_t launch_accumulate_debug(const float *sig_re, const float *sig_im, long long N, int M, long long ant_stride,
+                                   const gat_channel_params &P, const int8_t *code_row, int Lc, double fs, int L,
+                                   const int *shifts_dev, float *car_re, float *car_im, float *dw_re, float *dw_im,
+                                   float *acc_re, float *acc_im, hipStream_t s)
+{
+    long long bx = (N + kThreads - 1) / kThreads;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(accumulate_debug_kernel, dim3((unsigned)bx), dim3(kThreads), 0, s, sig_re, sig_im, N, M, ant_stride, P,
+                       code_row, Lc, fs, L, shifts_dev, car_re, car_im, dw_re, dw_im, acc_re, acc_im);
     return hipGetLastError();
 }
 

@@ -122,6 +122,43 @@ def gen_code_replica(code_replica: torch.Tensor, system: GNSSSystem, code_freque
     return code_replica
 
 
+def gen_code_replica_nsat(code_replica: torch.Tensor, system: GNSSSystem, code_frequency, sampling_frequency: float,
+                          start_code_phase, num_samples: int, latest_shift: int, prns) -> torch.Tensor:
+    """Mirror of ``gen_code_replica_texture_mem_strided_nsat_kernel!`` (src/algorithms.jl:78-98): the replicas of several
+    satellites in one launch.  ``code_replica`` is float32 [num_sats, >= num_samples] (the reference's column-major
+    [num_samples x num_sats]); row k gets ``c_k[floor(fc_k/fs*(i + latest_shift) + phase_k) mod Lc]`` for i = 0 ..
+    num_samples-1 (0-based ``i``; the reference's ``thread_idx`` is 1-based).  ``prns`` are 1-based; ``code_frequency`` and
+    ``start_code_phase`` may be scalars or one value per satellite."""
+    ctx = get_context(code_replica.device)
+    ctx.set_codes(system.codes)
+    prns = np.atleast_1d(np.asarray(prns, dtype=np.int64))
+    if (prns < 1).any() or (prns > system.codes.shape[0]).any():
+        raise ValueError("prn outside the code table")
+    k = prns.size
+    prm = make_params(prns - 1, np.broadcast_to(np.asarray(code_frequency, dtype=np.float64), (k,)), 0.0,
+                      np.broadcast_to(np.asarray(start_code_phase, dtype=np.float64), (k,)), 0.0, shape=(k,))
+    ctx.gen_code_replica_multi(code_replica, int(num_samples), ctx.params_to_device(prm), k, sampling_frequency,
+                               int(latest_shift))
+    return code_replica
+
+
+def downconvert_and_accumulate_strided(accum_re, accum_im, carrier_replica_re, carrier_replica_im,
+                                       downconverted_signal_re, downconverted_signal_im, signal_re: torch.Tensor,
+                                       signal_im: torch.Tensor, system: GNSSSystem, code_frequency: float,
+                                       carrier_frequency: float, sampling_frequency: float, start_code_phase: float,
+                                       carrier_phase: float, num_samples: int, correlator_sample_shifts, prn: int):
+    """Mirror of ``downconvert_and_accumulate_strided_kernel!`` (src/algorithms.jl:828-866): the materialising middle
+    stage of the reference's algorithm 2 (debug export; the fused correlator writes none of this).  Fills
+    ``carrier_replica`` [N], ``downconverted_signal`` [M, N] and ``accum`` [L, M, N] (= the reference's column-major
+    [N x M x L]); any of them may be None.  The code replica is evaluated in place (no replica buffer argument)."""
+    ctx = get_context(signal_re.device)
+    ctx.set_codes(system.codes)
+    desc = _signal_desc(signal_re, signal_im, int(num_samples))
+    prm = make_params(int(prn) - 1, code_frequency, carrier_frequency, start_code_phase, carrier_phase, shape=(1,))
+    ctx.downconvert_and_accumulate(desc, prm, correlator_sample_shifts, sampling_frequency, carrier_replica_re,
+                                   carrier_replica_im, downconverted_signal_re, downconverted_signal_im, accum_re, accum_im)
+
+
 class StreamCorrelator:
     """Batched-stream operator: B consecutive integration blocks x K satellite channels per call.
 

@@ -178,6 +178,27 @@ GAT_API int32_t gat_gen_code_replica_f32coord(gat_ctx *ctx, float *replica_dev, 
                                               double sampling_freq_hz, double code_phase_chips,
                                               int64_t first_shift);
 
+/* gen_code_replica_texture_mem_strided_nsat_kernel! (src/algorithms.jl:78-98): the replicas of num_channels
+ * satellite channels in ONE call -- row k (row_stride floats apart) = channel k with its own prn, code_freq_hz and
+ * code_phase_chips (params_dev[k]; the carrier fields are ignored); rep[k][i] = c_k[floor(fc_k/fs*(i + first_shift)
+ * + tau_k) mod Lc].  Exact index arithmetic (prn is a table column here, not the reference's normalised texture
+ * coordinate, SURVEY defect D5).  A prn outside the table poisons its row with NaN. */
+GAT_API int32_t gat_gen_code_replica_multi(gat_ctx *ctx, float *replica_dev, int64_t count, int64_t row_stride,
+                                           int32_t num_channels, const gat_channel_params *params_dev,
+                                           double sampling_freq_hz, int64_t first_shift);
+
+/* downconvert_and_accumulate_strided_kernel! (src/algorithms.jl:828-866), the materialising middle stage of the
+ * reference's algorithm 2, as a DEBUG export: for one integration block (planar float signal) and one channel it
+ * writes what the fused correlator never materialises -- carrier replica [N], downconverted signal [N x M]
+ * (sample fastest) and the per-sample products [N x M x L] -- so that the reference's test of that stage
+ * (test/algorithms.jl:1438-1514: prompt products == 1, column sums == [1476 2500 1476]) has a counterpart.
+ * Any output pointer may be NULL.  Not a fast path: 8*N*(1 + M + M*L) bytes of stores for 8*N*M bytes of signal. */
+GAT_API int32_t gat_downconvert_and_accumulate(gat_ctx *ctx, const gat_signal_desc *signal,
+                                               const gat_channel_params *params_host, int32_t num_taps,
+                                               const int32_t *shifts_host, double sampling_freq_hz,
+                                               float *carrier_re_dev, float *carrier_im_dev, float *dw_re_dev,
+                                               float *dw_im_dev, float *accum_re_dev, float *accum_im_dev);
+
 /* gen_signal! (src/gen_signal.jl:53-175): noise-free synthetic IF signal, identical on every
  * antenna.  Writes, for every block b, x[n,m,b] = sum_k c_k[floor(fc_k/fs*n + tau_kb) mod Lc]
  *   * (cos, sin)(float32(2pi*n*f_kb/fs + phase_kb)).  NOTE: for THIS call the

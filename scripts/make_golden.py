@@ -24,11 +24,23 @@ CA_OCTAL = ["1440", "1620", "1710", "1744", "1133", "1455", "1131", "1454", "162
             "1772", "1775", "1776", "1156", "1467", "1633", "1715", "1746", "1763", "1063", "1706", "1743", "1761",
             "1770", "1774", "1127", "1453", "1625", "1712"]
 
-# reference literals: test/algorithms.jl:85 (and :191, :300, :1374, :1513); 3-D test shape N = 2048
+# IS-GPS-705 Table 3-Ia, I5 columns, PRN 1..16 (typed from the ICD; stage 1 is the leftmost digit): the per-PRN XB
+# code advance in chips and the "Initial XB Code State".  The two columns are redundant -- clocking the XB register
+# (1 + x + x^3 + x^4 + x^6 + x^7 + x^8 + x^12 + x^13, all ones) `advance` times must give the state -- which
+# tests/test_oracle_golden.py checks with its own 13-stage register before using the states to pin both generators.
+L5I_XB_ADVANCE = [266, 365, 804, 1138, 1509, 1559, 1756, 2084, 2170, 2303, 2527, 2687, 2930, 3471, 3940, 4132]
+L5I_XB_INITIAL_STATE = ["0101011100100", "1100000110101", "0100000001000", "1011000100110", "1110111010111",
+                        "0110011111010", "1010010011111", "1011110100100", "1111100101011", "0111111011110",
+                        "0000100111010", "1110011111001", "0001110011100", "0100000100111", "0110101011010",
+                        "0001111001001"]
+
+# reference literals: test/algorithms.jl:85 (and :191, :300, :1374, :1513).  G3 is NOT a reference literal: the
+# reference's N = 2048 test asserts 1476 there (test/algorithms.jl:1310, a known defect); [1024 2048 1024] is this
+# build's own derivation for that shape (fs = 2.048 MHz: exactly two samples per chip)
 KNOWN = [
     {"id": "G1", "system": "GPSL1", "prn": 1, "N": 2500, "M": 1, "f": 1500.0, "expect": [1476, 2500, 1476], "ref": "test/algorithms.jl:85"},
     {"id": "G2", "system": "GPSL1", "prn": 1, "N": 2500, "M": 4, "f": 1500.0, "expect": [1476, 2500, 1476], "ref": "test/algorithms.jl:191"},
-    {"id": "G3", "system": "GPSL1", "prn": 1, "N": 2048, "M": 4, "f": 1500.0, "expect": [1024, 2048, 1024], "ref": "test/algorithms.jl:1161 (N = 2048 shape)"},
+    {"id": "G3", "system": "GPSL1", "prn": 1, "N": 2048, "M": 4, "f": 1500.0, "expect": [1024, 2048, 1024], "ref": "builder-derived (shape of test/algorithms.jl:1161; the reference asserts 1476 there, a defect)"},
 ]
 
 # G6: seeded randomised cases (tau != 0, phi != 0, Doppler +-5 kHz, IF, ragged N, K > 1)
@@ -66,7 +78,8 @@ def main():
         reps.append({"system": system, "fs": fs, "tau": tau, "prn0": prn0, "first_shift": int(sh[0]), "rep": r.astype(int).tolist()})
     with open(os.path.join(OUT, "golden.json"), "w") as f:
         json.dump({"generator": "scripts/make_golden.py (oracle/gat_oracle.c FP64 restatement)",
-                   "ca_first10_octal": CA_OCTAL, "known_answers": KNOWN, "cases": cases, "code_sha256": digests,
+                   "ca_first10_octal": CA_OCTAL, "l5i_xb_advance": L5I_XB_ADVANCE,
+                   "l5i_xb_initial_state": L5I_XB_INITIAL_STATE, "known_answers": KNOWN, "cases": cases, "code_sha256": digests,
                    "replicas": reps}, f)
     print("wrote", os.path.join(OUT, "golden.json"), os.path.getsize(os.path.join(OUT, "golden.json")), "bytes")
 

@@ -73,6 +73,26 @@ def test_host_code_generators_match_oracle(g, system):
         assert np.array_equal(row, tbl[p]), f"{system} PRN {p + 1}"
 
 
+def test_host_l5_generator_against_icd_initial_states(g):
+    """libgat's own GPS L5 I5 generator against IS-GPS-705's initial XB code states (tests/golden, PRN 1-16): the
+    first 13 code chips are the complement of the state read from stage 13 down (XA = all ones); and its C/A
+    generator against IS-GPS-200's first-10-chip octals -- the product's tables are pinned to the ICDs directly, not
+    only through the oracle."""
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden.json")))
+    tbl, _ = g.generate_codes("GPSL5", 37)
+    for prn, state in enumerate(gold["l5i_xb_initial_state"], 1):
+        want = [1 - 2 * (1 ^ int(c)) for c in reversed(state)]
+        assert tbl[prn - 1, :13].tolist() == want, f"PRN {prn}"
+    ca, _ = g.generate_codes("GPSL1", 32)
+    for p, want in enumerate(gold["ca_first10_octal"]):
+        v = 0
+        for b in (1 - ca[p, :10].astype(int)) // 2:
+            v = (v << 1) | int(b)
+        assert oct(v)[2:] == want, f"PRN {p + 1}"
+
+
 def test_gen_codes_errors(g):
     lib = g.load_library()
     lc, fc = C.c_int32(), C.c_double()

@@ -1,7 +1,8 @@
 """CPU tests: pin the oracle.
 
 1. against the reference's own known-answer literals (test/algorithms.jl:85 ...; test/reduction.jl:51);
-2. against IS-GPS-200's first-10-chip octals (typed by hand in scripts/make_golden.py);
+2. against IS-GPS-200's first-10-chip octals and IS-GPS-705's I5 initial XB code states (typed by hand in
+   scripts/make_golden.py);
 3. the C restatement against an independent numpy restatement;
 4. the FP32 4-pass CPU baseline against the FP64 oracle (north-star tolerance 1e-5);
 5. against the committed fixtures (regression)."""
@@ -46,6 +47,40 @@ def test_ca_first_ten_chips_octal():
         for b in bits:
             v = (v << 1) | int(b)
         assert oct(v)[2:] == want, f"PRN {p + 1}"
+
+
+def _xb_register_states(count):
+    """States of the L5 XB register (IS-GPS-705: 1 + x + x^3 + x^4 + x^6 + x^7 + x^8 + x^12 + x^13, all ones at the
+    start, feedback into stage 1, output = stage 13) -- a third implementation, independent of both generators."""
+    taps = (1, 3, 4, 6, 7, 8, 12, 13)
+    reg = [1] * 13
+    out = []
+    for _ in range(count):
+        out.append("".join(map(str, reg)))
+        fb = 0
+        for t in taps:
+            fb ^= reg[t - 1]
+        reg = [fb] + reg[:-1]
+    return out
+
+
+def test_l5_icd_columns_are_consistent():
+    """IS-GPS-705 Table 3-Ia gives, per PRN, the XB code advance AND the initial XB code state: clocking the register
+    `advance` times from all ones must give the state.  16 x 13 bits agree -> neither column was mistyped."""
+    states = _xb_register_states(max(GOLD["l5i_xb_advance"]) + 1)
+    for prn, (adv, want) in enumerate(zip(GOLD["l5i_xb_advance"], GOLD["l5i_xb_initial_state"]), 1):
+        assert states[adv] == want, f"PRN {prn}"
+
+
+def test_l5_first_chips_from_icd_initial_states():
+    """The external pin of the GPS L5 I5 code CONTENT (the reference holds no L5 vector): the first 13 XB output chips
+    of a PRN are its ICD initial state read from stage 13 down to stage 1; XA starts at all ones, so the first 13 code
+    chips are their complement (logic 0 -> +1, logic 1 -> -1).  Covers PRN 1-16, i.e. every PRN of BASELINE configs[2]."""
+    codes = oracle.codes("GPSL5", 32)
+    for prn, state in enumerate(GOLD["l5i_xb_initial_state"], 1):
+        xb = [int(c) for c in reversed(state)]          # output order: stage 13 first
+        want = [1 - 2 * (1 ^ b) for b in xb]            # XA = 1 for the first 13 chips
+        assert codes[prn - 1, :13].tolist() == want, f"PRN {prn}"
 
 
 def test_code_tables_properties_and_digest():
