@@ -36,6 +36,7 @@ class Context:
         if rc != 0:
             raise GatError(rc, "gat_create")
         self._codes_key = None
+        self._codes_obj = None
 
     # -- plumbing -----------------------------------------------------------------------
     def check(self, rc: int, where: str):
@@ -89,15 +90,21 @@ class Context:
 
     # -- code tables --------------------------------------------------------------------
     def set_codes(self, codes: np.ndarray):
-        """codes: int8 [num_prns, code_length] (C-order == reference's column-major [Lc x P])."""
-        codes = np.ascontiguousarray(codes, dtype=np.int8)
-        key = (codes.shape, hash(codes.tobytes()))
-        if key == self._codes_key:
+        """codes: int8 [num_prns, code_length] (C-order == reference's column-major [Lc x P]).
+
+        The table is per-context state in libgat while the reference passes `system` with every call, and one context
+        serves every operator on a (device, stream): each operator therefore re-binds its own table before every launch
+        (a dual-frequency receiver alternates L1 and L5 on one context).  Cheap: the table bound last is remembered by
+        identity; only a different array object is hashed, and only different contents are uploaded."""
+        if codes is self._codes_obj:
             return
-        p, lc = codes.shape
-        self.check(self.lib.gat_set_codes(self._h, codes.ctypes.data_as(C.POINTER(C.c_int8)), lc, p),
-                   "gat_set_codes")
-        self._codes_key = key
+        arr = np.ascontiguousarray(codes, dtype=np.int8)
+        key = (arr.shape, hash(arr.tobytes()))
+        if key != self._codes_key:
+            p, lc = arr.shape
+            self.check(self.lib.gat_set_codes(self._h, arr.ctypes.data_as(C.POINTER(C.c_int8)), lc, p), "gat_set_codes")
+            self._codes_key = key
+        self._codes_obj = codes  # keeps the array alive, so the identity test above cannot be fooled by a recycled id
 
     # -- operators ----------------------------------------------------------------------
     def downconvert_and_correlate(self, desc: _lib.SignalDesc, params, num_blocks: int, num_channels: int,

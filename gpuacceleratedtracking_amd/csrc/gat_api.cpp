@@ -26,8 +26,13 @@ struct gat_ctx {
     int8_t *d_codes = nullptr;
     // gat_tracking_run with GAT_FLAG_GRAPH: the launch sequence of the last such call, instantiated (replayed when the
     // next call has the same arguments: a receiver cycling through one ring buffer)
-    hipGraphExec_t loop_graph = nullptr;
-    std::vector<unsigned char> loop_graph_key;
+    struct LoopGraph {
+        std::vector<unsigned char> key;
+        hipGraphExec_t exec = nullptr;
+        unsigned long long last_use = 0;
+    };
+    std::vector<LoopGraph> loop_graphs; // small LRU (kMaxLoopGraphs): e.g. the a/b parameter order of odd block counts
+    unsigned long long loop_graph_clock = 0;
     void *d_zeros = nullptr;         // 64 zero bytes (out-of-range sample loads of the split-bf16 kernel read these)
     uint32_t *d_code_bits = nullptr; // bit i of row p = (chip i of PRN p is -1); only when every chip is +-1
     int code_bits_stride = 0;        // dwords per row, a multiple of 4
@@ -48,6 +53,18 @@ struct gat_ctx {
 };
 
 namespace {
+
+constexpr size_t kMaxLoopGraphs = 4;
+
+// Every instantiated graph bakes in device pointers of the library's own buffers (split partials, code tables) and the
+// launch geometry: drop them all whenever one of those can change (scratch reallocation, gat_set_codes, gat_set_stream,
+// kernel-selection knobs).
+void drop_loop_graphs(gat_ctx *c)
+{
+    for (auto &g : c->loop_graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    c->loop_graphs.clear();
+}
 
 int32_t fail(gat_ctx *c, int32_t code, const char *msg)
 {
@@ -74,6 +91,7 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) ==
 int32_t ensure_partial(gat_ctx *c, size_t bytes)
 {
     if (bytes <= c->partial_bytes) return GAT_OK;
+    drop_loop_graphs(c); // recorded launches point at the old buffer
     if (c->d_partial) {
         GAT_HIP(c, hipStreamSynchronize(c->stream)); // previous launches may still read it
         GAT_HIP(c, hipFree(c->d_partial));
@@ -523,7 +541,7 @@ GAT_API int32_t gat_destroy(gat_ctx *c)
     if (c->d_codes) (void)hipFree(c->d_codes);
     if (c->d_code_bits) (void)hipFree(c->d_code_bits);
     if (c->d_zeros) (void)hipFree(c->d_zeros);
-    if (c->loop_graph) (void)hipGraphExecDestroy(c->loop_graph);
+    drop_loop_graphs(c);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -538,6 +556,7 @@ GAT_API int32_t gat_set_stream(gat_ctx *c, void *hip_stream)
     if (!c) return GAT_ERR_ARG;
     GAT_HIP(c, hipSetDevice(c->device));
     GAT_HIP(c, hipStreamSynchronize(c->stream));
+    drop_loop_graphs(c);
     if (c->own_stream) {
         GAT_HIP(c, hipStreamDestroy(c->stream));
         c->own_stream = false;
@@ -583,9 +602,11 @@ GAT_API int32_t gat_set_codes(gat_ctx *c, const int8_t *codes_host, int32_t code
 {
     if (!c || !codes_host) return fail(c, GAT_ERR_ARG, "null argument");
     if (code_length < 1 || num_prns < 1) return fail(c, GAT_ERR_ARG, "sizes must be positive");
-    if (code_length > 150000) return fail(c, GAT_ERR_RANGE, "code table does not fit in LDS (max 150000 chips)");
+    // the vector kernel keeps a workgroup's chip table in LDS next to one replica segment (~40 KB): 160 KB - that
+    if (code_length > 120000) return fail(c, GAT_ERR_RANGE, "code table does not fit in LDS (max 120000 chips)");
     GAT_HIP(c, hipSetDevice(c->device));
     GAT_HIP(c, hipStreamSynchronize(c->stream));
+    drop_loop_graphs(c); // recorded launches point at the old tables
     if (c->d_codes) {
         GAT_HIP(c, hipFree(c->d_codes));
         c->d_codes = nullptr;
@@ -652,12 +673,17 @@ GAT_API int32_t gat_downconvert_and_correlate(gat_ctx *c, const gat_signal_desc 
     for (int l = 0; l < L && l < GAT_MAX_TAPS; ++l)
         max_shift = std::max<long long>(max_shift, std::llabs((long long)shifts[l]));
     const size_t n = (size_t)B * K;
-    for (size_t i = 0; i < n; ++i) {
+    if (!c->d_codes) return fail(c, GAT_ERR_STATE, "gat_set_codes has not been called");
+    if (!(fs > 0.0) || !std::isfinite(fs)) return fail(c, GAT_ERR_ARG, "sampling frequency must be positive");
+    for (size_t i = 0; i < n; ++i) { // mirrors the kernels' `bad` predicate: what passes here is not poisoned there
         const gat_channel_params &p = params_host[i];
         if (p.prn < 0 || p.prn >= c->P) return fail(c, GAT_ERR_RANGE, "prn outside the code table");
         if (!std::isfinite(p.code_freq_hz) || !std::isfinite(p.carrier_freq_hz) ||
             !std::isfinite(p.code_phase_chips) || !std::isfinite(p.carrier_phase_cycles))
             return fail(c, GAT_ERR_ARG, "non-finite channel parameter");
+        if (p.code_freq_hz < 0.0) return fail(c, GAT_ERR_RANGE, "negative code frequency");
+        if (std::fabs(p.carrier_freq_hz / fs) >= 1.0e15 || std::fabs(p.carrier_phase_cycles) >= 1.0e15)
+            return fail(c, GAT_ERR_RANGE, "carrier frequency / phase out of range");
         const double span = std::fabs(p.code_phase_chips) +
                             std::fabs(p.code_freq_hz / fs) * (double)(sig->num_samples + max_shift) + 1.0;
         if (span >= 1073741824.0 || (c->Lc > 0 && span / c->Lc >= 2097152.0))
@@ -821,37 +847,62 @@ GAT_API int32_t gat_tracking_run(gat_ctx *c, const gat_signal_desc *sig, int32_t
                                     acc_block_stride, kflags, current_is_b);
 
     // hipGraph path: the 2-3 launches per block are too short to hide their launch gaps.  Every argument that
-    // shapes the launch sequence is part of the key; a call with the same key replays the instantiated graph.
-    std::vector<unsigned char> key;
-    key_put(key, *sig); key_put(key, num_blocks); key_put(key, K); key_put(key, L); key_put(key, fs); key_put(key, *cfg);
-    key_put(key, state); key_put(key, params_a); key_put(key, params_b); key_put(key, acc_re); key_put(key, acc_im);
-    key_put(key, acc_block_stride); key_put(key, kflags); key_put(key, c->mc_mode); key_put(key, c->d_codes);
-    for (int l = 0; l < L; ++l) key_put(key, shifts[l]);
+    // shapes the launch sequence is part of the key -- field by field (struct padding of a C caller is not
+    // initialised) --, together with the library-owned pointers and sizes the recorded launches bake in; a call with
+    // a known key replays its instantiated graph.  Up to kMaxLoopGraphs graphs are kept (least recently used goes).
+    auto make_key = [&]() {
+        std::vector<unsigned char> key;
+        key_put(key, sig->re); key_put(key, sig->im); key_put(key, sig->layout); key_put(key, sig->num_ants);
+        key_put(key, sig->num_samples); key_put(key, sig->ant_stride); key_put(key, sig->block_stride);
+        key_put(key, sig->chan_stride); key_put(key, num_blocks); key_put(key, K); key_put(key, L); key_put(key, fs);
+        key_put(key, cfg->block_seconds); key_put(key, cfg->pll_bandwidth_hz); key_put(key, cfg->dll_bandwidth_hz);
+        key_put(key, cfg->code_freq_nominal_hz); key_put(key, cfg->carrier_center_hz); key_put(key, cfg->if_hz);
+        key_put(key, cfg->early_late_spacing_chips); key_put(key, cfg->code_length); key_put(key, cfg->num_taps);
+        key_put(key, cfg->early_index); key_put(key, cfg->prompt_index); key_put(key, cfg->late_index);
+        key_put(key, state); key_put(key, params_a); key_put(key, params_b); key_put(key, acc_re); key_put(key, acc_im);
+        key_put(key, acc_block_stride); key_put(key, kflags); key_put(key, c->mc_mode); key_put(key, c->max_aw);
+        key_put(key, c->max_kt); key_put(key, c->max_bpw); key_put(key, c->d_codes); key_put(key, c->d_code_bits);
+        key_put(key, c->Lc); key_put(key, c->P); key_put(key, c->d_partial); key_put(key, c->partial_bytes);
+        for (int l = 0; l < L; ++l) key_put(key, shifts[l]);
+        return key;
+    };
     if (current_is_b) *current_is_b = (num_blocks & 1) ? 1 : 0; // the buffers swap once per block
-    if (c->loop_graph && key == c->loop_graph_key) {
-        GAT_HIP(c, hipGraphLaunch(c->loop_graph, c->stream));
-        return GAT_OK;
+    {
+        const std::vector<unsigned char> key = make_key();
+        for (auto &g : c->loop_graphs)
+            if (g.exec && g.key == key) {
+                g.last_use = ++c->loop_graph_clock;
+                GAT_HIP(c, hipGraphLaunch(g.exec, c->stream));
+                return GAT_OK;
+            }
     }
     // first call with these arguments: run it eagerly (this also sizes the library's scratch buffers, which must
-    // not be reallocated inside a capture), then record the same sequence for the following calls
+    // not be reallocated inside a capture -- a reallocation drops every recorded graph), then record the same
+    // sequence for the following calls under the key of the buffers the capture really uses
     int32_t rc = tracking_run_enqueue(c, sig, num_blocks, K, L, shifts, fs, cfg, state, params_a, params_b, acc_re, acc_im,
                                       acc_block_stride, kflags, nullptr);
     if (rc != GAT_OK) return rc;
-    if (c->loop_graph) {
-        (void)hipGraphExecDestroy(c->loop_graph);
-        c->loop_graph = nullptr;
-        c->loop_graph_key.clear();
-    }
+    const std::vector<unsigned char> key = make_key();
     hipGraph_t graph = nullptr;
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return GAT_OK; // no graph: stay eager
     rc = tracking_run_enqueue(c, sig, num_blocks, K, L, shifts, fs, cfg, state, params_a, params_b, acc_re, acc_im,
                               acc_block_stride, kflags, nullptr);
     const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
-    if (rc == GAT_OK && ce == hipSuccess && graph &&
-        hipGraphInstantiate(&c->loop_graph, graph, nullptr, nullptr, 0) == hipSuccess)
-        c->loop_graph_key = key;
-    else
-        c->loop_graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    if (rc == GAT_OK && ce == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+        if (c->loop_graphs.size() >= kMaxLoopGraphs) { // evict the least recently used
+            size_t lru = 0;
+            for (size_t i = 1; i < c->loop_graphs.size(); ++i)
+                if (c->loop_graphs[i].last_use < c->loop_graphs[lru].last_use) lru = i;
+            if (c->loop_graphs[lru].exec) (void)hipGraphExecDestroy(c->loop_graphs[lru].exec);
+            c->loop_graphs.erase(c->loop_graphs.begin() + (long)lru);
+        }
+        gat_ctx::LoopGraph g;
+        g.key = key;
+        g.exec = exec;
+        g.last_use = ++c->loop_graph_clock;
+        c->loop_graphs.push_back(std::move(g));
+    }
     if (graph) (void)hipGraphDestroy(graph);
     return GAT_OK;
 }
@@ -934,6 +985,7 @@ GAT_API int32_t gat_set_matrix_core(gat_ctx *c, int32_t enable)
     if (!c) return GAT_ERR_ARG;
     if (enable < GAT_MC_VECTOR || enable > GAT_MC_BF16_SPLIT) return fail(c, GAT_ERR_ARG, "unknown matrix-core mode");
     c->mc_mode = enable;
+    drop_loop_graphs(c);
     return GAT_OK;
 }
 
@@ -944,6 +996,7 @@ GAT_API int32_t gat_set_vector_tiling(gat_ctx *c, int32_t max_antenna_tiles, int
     if (max_antenna_tiles) c->max_aw = max_antenna_tiles >= 4 ? 4 : (max_antenna_tiles >= 2 ? 2 : 1);
     if (max_channels) c->max_kt = max_channels >= 4 ? 4 : (max_channels >= 2 ? 2 : 1);
     if (max_blocks) c->max_bpw = max_blocks;
+    drop_loop_graphs(c);
     return GAT_OK;
 }
 

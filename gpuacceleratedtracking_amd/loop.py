@@ -61,6 +61,7 @@ class TrackingLoop:
     def step(self, re: torch.Tensor, im: torch.Tensor | None = None, start: int = 0):
         """Correlate the block starting at sample ``start`` of the given signal with the current
         parameters, then update them on the device.  Nothing is synchronised."""
+        self.ctx.set_codes(self.system.codes)  # the context may have been bound to another system's table meanwhile
         desc = _signal_desc(re, im, self.N, start=start)
         cur, nxt = self._params[self._cur], self._params[1 - self._cur]
         self.ctx.downconvert_and_correlate(desc, cur, 1, self.K, self.shifts, self.fs, self.out_re, self.out_im)
@@ -81,6 +82,7 @@ class TrackingLoop:
         ``out_re`` / ``out_im``.  ``graph``: GAT_FLAG_GRAPH -- calls that repeat with the same buffers replay an
         instantiated hipGraph (the context must be bound to a non-default stream)."""
         nb = int(num_blocks)
+        self.ctx.set_codes(self.system.codes)  # the context may have been bound to another system's table meanwhile
         desc = _signal_desc(re, im, self.N, start=start)
         ntot = re.shape[-2] if im is None else re.shape[-1]
         if start + nb * self.N > ntot:

@@ -207,6 +207,7 @@ class StreamCorrelator:
         """Enqueue with a pre-built descriptor (lowest per-call overhead; used by bench.py)."""
         if self.params_dev is None:
             raise RuntimeError("set_params() has not been called")
+        self.ctx.set_codes(self.system.codes)  # another operator may have bound its own table to this context
         key = (id(desc), self.params_dev.data_ptr())
         if self._prepared is None or self._prepared[0] != key:
             self._prepared = (key, self.ctx.prepared_call(desc, self.params_dev, self.B, self.K, self.shifts,

@@ -293,6 +293,24 @@ def test_errors(gat):
     with pytest.raises(g.GatError):
         op.ctx.downconvert_and_correlate(op.describe(signal.re, signal.im), op.params_dev, 1, 1, shifts, -1.0,
                                          op.out_re, op.out_im)
+    # the host entry point mirrors the kernels' `bad` predicate: a negative code frequency is GAT_ERR_RANGE up
+    # front, not GAT_OK plus NaN outputs
+    host_prm = g.make_params(0, -1.023e6, 0.0, 0.0, 0.0, shape=(1, 1))
+    with pytest.raises(g.GatError) as ei:
+        op.ctx.downconvert_and_correlate(op.describe(signal.re, signal.im), host_prm, 1, 1, shifts, fs, op.out_re, op.out_im)
+    assert ei.value.status == 2
+    # ... while device-resident parameters cannot be checked on the host: the kernel poisons that channel with NaN
+    op.params_dev = op.ctx.params_to_device(host_prm)
+    op._prepared = None
+    op(signal.re, signal.im)
+    assert np.isnan(op.result().view(np.float32)).all()
+    # before gat_set_codes: GAT_ERR_STATE, whatever the prn says
+    fresh = g.Context(0, torch.cuda.Stream())
+    with pytest.raises(g.GatError) as ei:
+        fresh.downconvert_and_correlate(op.describe(signal.re, signal.im), g.make_params(99, 1.023e6, 0.0, 0.0, 0.0, shape=(1, 1)),
+                                        1, 1, shifts, fs, op.out_re, op.out_im)
+    assert ei.value.status == 3
+    fresh.close()
     with pytest.raises(NotImplementedError):
         g.run_kernel_benchmark({"processor": "CPU", "GNSS": "GPSL1", "num_samples": 2048, "num_ants": 1,
                                 "num_correlators": 3, "algorithm": "1_3_cplx_multi"})

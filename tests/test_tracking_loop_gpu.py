@@ -160,3 +160,79 @@ def test_native_run_graph_replay(g):
             graph.ctx.sync()
             assert torch.equal(e_re, out[0]) and torch.equal(e_im, out[1]), rep
             assert eager.params().tobytes() == graph.params().tobytes() and eager.state().tobytes() == graph.state().tobytes()
+
+
+def test_graph_replay_survives_scratch_growth_and_code_rebinding(g):
+    """a recorded hipGraph bakes in the library's split-partials buffer and code tables.  After
+    graph runs, (1) a larger correlate on the same context grows (re-allocates) that buffer, (2) another system's table
+    is bound and the first one re-bound: the next graph-flagged runs must re-record instead of replaying launches that
+    point at freed memory / stale tables -- and stay bit-identical to the eager loop."""
+    import torch
+    system = g.GPSL1()
+    N, M, fs, nblk = 4000, 2, 4e6, 16
+    prns = np.array([5, 17])
+    dop = np.array([-600.0, 1900.0])
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        prm_sig = g.make_params(prns - 1, 1.023e6, dop, [[77.0, 640.5]], 0.0, shape=(nblk, 2))
+        re, im = g.gen_signal_stream(system, prm_sig, fs, N, M)
+        shifts = g.get_correlator_sample_shifts(system, g.EarlyPromptLateCorrelator(M, 3), fs, 0.5)
+
+        def make():
+            return g.TrackingLoop(system, prns, N, M, fs, shifts, init_carrier_doppler=dop + 3.0,
+                                  init_code_phase=np.array([77.1, 640.4]), dll_bandwidth_hz=4.0)
+        eager, graph = make(), make()
+        ctx = graph.ctx
+        assert ctx.stream.cuda_stream != 0
+        out = (torch.empty((nblk, 2, 3, M), device=ctx.device), torch.empty((nblk, 2, 3, M), device=ctx.device))
+
+        def both(tag):
+            e_re, e_im = eager.run(re, im, nblk)
+            graph.run(re, im, nblk, graph=True, out=out)
+            ctx.sync()
+            assert torch.equal(e_re, out[0]) and torch.equal(e_im, out[1]), tag
+            assert eager.params().tobytes() == graph.params().tobytes(), tag
+        both("record")
+        both("replay")
+        # (1) grow the library's scratch buffer on the same context: one long block split over many workgroups
+        big_n = 2_000_000
+        big = g.StreamCorrelator(system, big_n, 4, 1, 2, shifts, fs, ctx=ctx)
+        big.set_params(g.make_params(np.arange(2), 1.023e6, 1500.0, 0.0, 0.0, shape=(1, 2)))
+        big(torch.zeros((4, big_n), device=ctx.device), torch.zeros((4, big_n), device=ctx.device))
+        assert ctx.last_launch_info()["splits"] > 1
+        ctx.sync()
+        both("after scratch growth")
+        both("replay after scratch growth")
+        # (2) another system's tables on the same context, then back (TrackingLoop re-binds its table per run)
+        l5 = g.StreamCorrelator(g.GPSL5(), 4096, 1, 1, 1, np.array([0], dtype=np.int32), 50e6, ctx=ctx)
+        l5.set_params(g.make_params(0, 10.23e6, 0.0, 0.0, 0.0, shape=(1, 1)))
+        l5(torch.ones((1, 4096), device=ctx.device), torch.zeros((1, 4096), device=ctx.device))
+        ctx.sync()
+        both("after another system's table")
+        both("replay after another system's table")
+
+
+def test_two_systems_share_one_context(g):
+    """the code table is per-context state; operators of two systems created on the same context
+    must each correlate against THEIR table, whatever the creation order (the reference passes `system` per call)."""
+    import torch
+    ctx = g.get_context()
+    dev = ctx.device
+    l1, l5 = g.GPSL1(use_gpu=True), g.GPSL5(use_gpu=True)
+    N = 10230
+    ops = {}
+    for name, system, fc, fs in (("L1", l1, 1.023e6, 10.23e6), ("L5", l5, 10.23e6, 10.23e6)):
+        op = g.StreamCorrelator(system, N, 1, 1, 1, np.array([0], dtype=np.int32), fs, ctx=ctx)
+        op.set_params(g.make_params(4, fc, 0.0, 0.0, 0.0, shape=(1, 1)))
+        ops[name] = (op, system, fc, fs)
+    # signals: each system's own PRN 5 code at one sample per chip (L5) / ten samples per chip (L1) -> sum = N
+    sig = {}
+    for name, (op, system, fc, fs) in ops.items():
+        idx = np.floor(np.arange(N) * fc / fs).astype(int) % system.codes.shape[1]
+        sig[name] = torch.from_numpy(system.codes[4, idx].astype(np.float32))[None, :].to(dev)
+    zero = torch.zeros((1, N), device=dev)
+    for order in (("L1", "L5", "L1", "L5"), ("L5", "L5", "L1", "L1")):
+        for name in order:
+            op = ops[name][0]
+            op(sig[name], zero)
+            assert op.result()[0, 0, 0, 0].real == N, (order, name)
