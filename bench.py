@@ -73,6 +73,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-shard-config3", action="store_true", help="N > 1: skip the configs[3] shard measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--block-ms", type=float, default=1.0, help="duration of one integration block (fs = N / block)")
+    ap.add_argument("--cpu-sweep", metavar="OUT.json", default=None,
+                    help="CPU-baseline leg only (no GPU): time the oracle's FP32 4-pass port, 1 thread, on the reference's "
+                         "single-block sweep grid (scripts/run_benchmarks_gpsl1.jl / _gpsl5.jl with processor = CPU) and "
+                         "write the rows to OUT.json -- the CPU series scripts/plot_benchmarks.py draws beside the GPU's")
     ap.add_argument("--baseline-config", type=int, choices=[1, 2, 3, 4], default=None,
                     help="shape of BASELINE.json configs[i] (1 = the default headline workload; 2 = GPS L5, 4 ants, 12 PRNs, "
                          "5 taps @ 50 MHz; 3 = the per-GPU shard of 16 ants x 32 PRNs @ 50 MHz; 4 = 64 ants x 64 channels, "
@@ -177,6 +181,43 @@ def cpu_baseline(args, host_re, host_im, prm, shifts, fs, system):
         "value_1_thread": round(rate_1t, 3), "by_threads": {str(k): round(v, 3) for k, v in rates.items()},
         "host_threads": cores, "cpu_model": cpu_model(),
     }
+
+
+def cpu_sweep(out_path: str, seconds: float = 0.25):
+    """The reference's committed sweep drives "processor" => ["CPU"] (scripts/run_benchmarks_gpsl1.jl:6; CPU branch
+    src/benchmarks.jl:35-80: Tracking.downconvert_and_correlate! on ONE thread): the same grid here on the oracle's
+    FP32 4-pass port (the reported CPU baseline; the reference's Julia path cannot run), prn 1, 1500 Hz, phases 0,
+    0.5-chip spacing, minimum over repeated calls as BenchmarkTools' "Minimum"."""
+    import oracle  # CPU-baseline leg: the only use of the oracle in this file besides the parity spot check
+
+    grids = [("GPSL1", [2 ** e for e in range(11, 19)], [1, 4], [3, 7]), ("GPSL5", [2 ** e for e in range(15, 19)], [1, 4], [3])]
+    rows = []
+    for gnss, ns, ms, ls in grids:
+        lc, fc, _ = oracle.SYSTEMS[gnss]
+        codes = oracle.codes(gnss, 1)
+        for n in ns:
+            fs = n / 1e-3
+            for m in ms:
+                re, im = oracle.gen_signal(codes, 0, fc, fs, 1500.0, 0.0, 0.0, n, m)
+                prm = oracle.make_params(0, fc, 1500.0, 0.0, 0.0, shape=(1, 1))
+                for l in ls:
+                    sh = oracle.sample_shifts(l, fs, fc)
+                    oracle.dc_f32(re, im, codes, prm, fs, sh, N=n, threads=1, native=True)
+                    times, t_end = [], time.perf_counter() + seconds
+                    while time.perf_counter() < t_end or len(times) < 5:
+                        t0 = time.perf_counter_ns()
+                        oracle.dc_f32(re, im, codes, prm, fs, sh, N=n, threads=1, native=True)
+                        times.append(time.perf_counter_ns() - t0)
+                    t = np.asarray(times, dtype=np.float64)
+                    rows.append({"processor": "CPU", "GNSS": gnss, "num_samples": n, "num_ants": m, "num_correlators": l,
+                                 "algorithm": "cpu_port_1_thread", "Minimum": float(t.min()), "Median": float(np.median(t)),
+                                 "Mean": float(t.mean()), "samples": int(t.size), "CPU_model": cpu_model(),
+                                 "real_time_factor": 1e-3 / (t.min() * 1e-9)})
+                    print(f"CPU {gnss} N={n:7d} M={m} L={l}  min {t.min() / 1e3:9.2f} us  RTF {1e-3 / (t.min() * 1e-9):8.2f}", flush=True)
+    os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+    with open(out_path, "w") as f:
+        json.dump(rows, f, indent=1)
+    return rows
 
 
 def algorithmic_flops(B, N, M, L, K) -> float:
@@ -303,6 +344,9 @@ def parity_check(g, m):
 
 def main():
     args = parse_args()
+    if args.cpu_sweep:
+        cpu_sweep(args.cpu_sweep)
+        return
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
         # no external launcher: become the launcher.  Nothing above has touched the GPU (torch is not even imported).

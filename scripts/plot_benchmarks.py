@@ -3,7 +3,12 @@
 (GNSS, antennas, correlators), with the 1 ms real-time line -- from the JSON of scripts/run_benchmarks_sweep.py;
 optionally the reduction / code-replica panels (src/plots.jl:1-139) from scripts/benchmark_reduction.py.
 
-usage: python scripts/plot_benchmarks.py sweep.json out.png [reduction_replica.json out2.png]"""
+The CPU series (the reference's sweep drives "processor" => ["CPU"], scripts/run_benchmarks_gpsl1.jl:6) comes from
+`python bench.py --cpu-sweep cpu.json` (the CPU-baseline leg of bench.py: the oracle's 1-thread FP32 4-pass port) and is
+drawn when a third JSON is given, so the single-block crossover against the CPU is visible as in
+paper/figures/desktopplotscrop.png.
+
+usage: python scripts/plot_benchmarks.py sweep.json out.png [reduction_replica.json out2.png] [--cpu cpu.json]"""
 import json
 import sys
 
@@ -13,7 +18,7 @@ matplotlib.use("Agg")
 import matplotlib.pyplot as plt  # noqa: E402
 
 
-def sweep_figure(rows, out):
+def sweep_figure(rows, out, cpu_rows=()):
     panels = [("GPSL1", 1, 3), ("GPSL1", 4, 3), ("GPSL1", 4, 7), ("GPSL5", 1, 3), ("GPSL5", 4, 3), ("GPSL1", 1, 7)]
     fig, axes = plt.subplots(2, 3, figsize=(15, 8))
     for ax, (gnss, m, l) in zip(axes.ravel(), panels):
@@ -22,6 +27,10 @@ def sweep_figure(rows, out):
             pts = sorted((r["num_samples"] / 1e-3, r["Minimum"] * 1e-9) for r in sel if r["algorithm"] == alg)
             if pts:
                 ax.plot([p[0] for p in pts], [p[1] for p in pts], style, label=f"MI355X {alg} (minimum)")
+        cpu = sorted((r["num_samples"] / 1e-3, r["Minimum"] * 1e-9) for r in cpu_rows
+                     if r["GNSS"] == gnss and r["num_ants"] == m and r["num_correlators"] == l)
+        if cpu:
+            ax.plot([p[0] for p in cpu], [p[1] for p in cpu], "^-", color="tab:red", label="host CPU, 1 thread (FP32 4-pass port, minimum)")
         ax.axhline(1e-3, color="k", lw=0.8)
         ax.text(0.02, 0.93, "1 ms = real time", transform=ax.transAxes, fontsize=8)
         ax.set_xscale("log")
@@ -59,6 +68,12 @@ def aux_figure(res, out):
 
 
 if __name__ == "__main__":
-    sweep_figure(json.load(open(sys.argv[1])), sys.argv[2])
-    if len(sys.argv) > 4:
-        aux_figure(json.load(open(sys.argv[3])), sys.argv[4])
+    argv = list(sys.argv[1:])
+    cpu_rows = []
+    if "--cpu" in argv:
+        i = argv.index("--cpu")
+        cpu_rows = json.load(open(argv[i + 1]))
+        del argv[i:i + 2]
+    sweep_figure(json.load(open(argv[0])), argv[1], cpu_rows)
+    if len(argv) > 3:
+        aux_figure(json.load(open(argv[2])), argv[3])
