@@ -67,7 +67,7 @@ def build_libgat(force: bool = False, verbose: bool = False, extra_flags: tuple[
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         # flags that only touch the fused vector kernel (-DGAT_DC_*): every other object is shared with the main build
-        shared = dc_only and not src.startswith("gat_dc_f")
+        shared = dc_only and not src.startswith("gat_dc_f") and src != "gat_api.cpp"  # the planner shares gat_internal.h
         obj = os.path.join(base_objdir if shared else objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if shared:

@@ -136,16 +136,17 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     // 16-byte vector loads need every group start 16-byte aligned: plane bases and all strides
     // multiples of the samples one 16-byte load holds (4 / 2 / 4 / 8 by format)
     const int spv = dc_group_samples(4, fmt);
+    const long long plane_bytes = fmt == GAT_LAYOUT_PLANAR ? 4 : fmt == GAT_LAYOUT_INTERLEAVED ? 8 : fmt == GAT_LAYOUT_INTERLEAVED_I16 ? 4 : 2;
     int vec = 1;
+    // ... and whole groups only (the block's ragged end is then served by the buffer range check), in a block that a
+    // 32-bit descriptor length can describe
     if (aligned16(sig->re) && (!planar || aligned16(sig->im)) && sig->ant_stride % spv == 0 &&
-        sig->block_stride % spv == 0 && sig->chan_stride % spv == 0)
+        sig->block_stride % spv == 0 && sig->chan_stride % spv == 0 && sig->num_samples % spv == 0 &&
+        sig->num_samples * plane_bytes < (1ll << 31))
         vec = 4;
 
     const long long N = sig->num_samples;
-    // The vector kernel addresses a wave's antennas as one 32-bit scalar offset each from the tile's first antenna:
-    // streams whose antenna planes lie 4 GB or more apart, and unaligned input (scalar loads), run one antenna per wave
-    const long long sample_bytes_plane = fmt == GAT_LAYOUT_PLANAR ? 4 : fmt == GAT_LAYOUT_INTERLEAVED ? 8 : fmt == GAT_LAYOUT_INTERLEAVED_I16 ? 4 : 2;
-    if (vec != 4 || (long long)(MT - 1) * sig->ant_stride * sample_bytes_plane + N * sample_bytes_plane >= (1ll << 32)) MT = 1;
+    if (vec != 4) MT = 1; // unaligned input (scalar loads) is served one antenna per wave
 
     // ---- matrix-core paths: antenna-rich shapes whose (channel, tap) columns fill a useful part of
     // a 32-column tile run on the matrix cores -- the split-bf16 kernel (gat_mfma_bf16.hip) by default,

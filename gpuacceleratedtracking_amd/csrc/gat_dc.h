@@ -182,7 +182,7 @@ struct SampleIO {
 };
 
 
-// Occupancy hint: instances with up to 40 accumulator registers come out at 150-170 registers; asking for three waves
+// Occupancy hint: instances with up to 40 accumulator registers come out at 125-165 registers; asking for three waves
 // per SIMD (<= 168) costs them nothing, while the four-antenna five-tap instance otherwise lands ONE register over
 // that step.  No bound for the larger instances, and never a tighter one: the allocator then spills into the step loop
 // (measured in both rounds: 1.2-3x slower).
@@ -251,9 +251,10 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
 
     const int c_begin = split * a.chunks_per_split;
     const int c_end = min(c_begin + a.chunks_per_split, a.total_chunks);
-    // steps whose chunk lies completely inside the block take the vector path; the ragged last chunk (and everything
-    // when the input is not 16-byte aligned: VEC == 1) takes the per-group path
-    const int c_full = VEC == 4 ? max(c_begin, min(c_end, N / CHUNK)) : c_begin;
+    // VEC == 4 (16-byte aligned input, N a multiple of the group size): EVERY chunk takes the vector path -- the lanes
+    // of the ragged last chunk that lie beyond the block read zeros (buffer range check, no memory traffic).
+    // VEC == 1 (unaligned input): everything takes the per-sample path.
+    const int c_full = VEC == 4 ? c_end : c_begin;
     int staged_prn[KT];
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk) staged_prn[kk] = -1;
@@ -344,19 +345,21 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
 #pragma unroll
                 for (int l = 0; l < L; ++l) acc[kk][m][l] = f32x2{0.f, 0.f};
 
-        // Sample loads are raw buffer loads: ONE descriptor per plane based at sample 0 of this block for antenna 0 of
-        // the wave's tile, a 32-bit lane offset shared by every load of a step and a scalar offset per antenna (the
-        // host guarantees (MT - 1) * antenna stride < 4 GB, else it launches with MT = 1).  The cache policy is a
-        // template parameter: a wave-uniform `if (keep) plain else non-temporal` pair of ordinary loads is merged by the
-        // compiler into plain loads (the hint is only metadata; that cost 7 % at configs[1]), and the same branch
-        // around buffer loads breaks the step into many basic blocks (+ 50 registers).
+        // Sample loads are raw buffer loads through a descriptor per (antenna, plane) of exactly ONE block's length,
+        // built from wave-uniform values next to each load (two scalar adds): a 32-bit lane offset shared by every load
+        // of a step, and lanes beyond the block's end read zeros without touching memory -- the ragged last chunk
+        // needs no special path (measured on gfx950: the range check is per dword and covers voffset + soffset, so
+        // the antenna goes into the descriptor base, not into soffset).  The cache policy is a template parameter: a
+        // wave-uniform `if (keep) plain else non-temporal` pair of ordinary loads is merged by the compiler into plain
+        // loads (the hint is only metadata; that cost 7 % at configs[1]), and the same branch around buffer loads
+        // breaks the step into many basic blocks (+ 50 registers).
         const size_t base = (size_t)b * a.block_stride + (size_t)kg * a.chan_stride /* != 0 only with KT == 1 */ +
                             (size_t)((ag * AW + at_w) * MT) * a.ant_stride;
-        const __amdgpu_buffer_rsrc_t rs_re = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char *>(static_cast<const char *>(a.re) + base * EB), 0, -1, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_im = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char *>(static_cast<const char *>(FMT == GAT_LAYOUT_PLANAR ? a.im : a.re) + base * EB), 0, -1, 0x00020000);
-        const unsigned ant_bytes = (unsigned)((size_t)a.ant_stride * EB);
+        const char *const p_re = static_cast<const char *>(a.re) + base * EB;
+        const char *const p_im = static_cast<const char *>(FMT == GAT_LAYOUT_PLANAR ? a.im : a.re) + base * EB;
+        const size_t ant_bytes = (size_t)a.ant_stride * EB;
+        const size_t blk_bytes = (size_t)a.block_stride * EB;
+        const int blk_len = N * EB; // bytes of one antenna's block: the descriptors' num_records (host: < 2^31)
 
         // chips of the sample at segment-relative position rel, for the L taps
         auto get_chips = [&](float (&chip)[L], int rel, const float *rep) {
@@ -419,13 +422,18 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
                 ac[l][1] = __builtin_fmaf(chip[l], di, ac[l][1]);
             }
         };
-        // 16-byte loads of antenna m's group at byte offset `off` of the block (KEEP: plain loads that stay in L2 for the
-        // other channel groups, otherwise non-temporal: aux bit 1)
-        auto load_ant = [&](i32x4 (&raw)[IO::NV], int m, unsigned off) {
-            const unsigned so = (unsigned)m * ant_bytes;
+        // 16-byte loads of antenna m's group at byte offset `off` of the block that starts at (bre, bim) (KEEP: plain
+        // loads that stay in L2 for the other channel groups, otherwise non-temporal: aux bit 1)
+        auto load_ant = [&](i32x4 (&raw)[IO::NV], int m, const char *bre, const char *bim, unsigned off) {
             constexpr int aux = KEEP ? 0 : 2;
-            raw[0] = (i32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_re, off, so, aux);
-            if constexpr (IO::NV == 2) raw[1] = (i32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_im, off, so, aux);
+            const __amdgpu_buffer_rsrc_t rr =
+                __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(bre + (size_t)m * ant_bytes), 0, blk_len, 0x00020000);
+            raw[0] = (i32x4)__builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, aux);
+            if constexpr (IO::NV == 2) {
+                const __amdgpu_buffer_rsrc_t ri =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(bim + (size_t)m * ant_bytes), 0, blk_len, 0x00020000);
+                raw[1] = (i32x4)__builtin_amdgcn_raw_buffer_load_b128(ri, off, 0, aux);
+            }
         };
         // the S phasors of one group: carried phasor + S-1 rotations
         auto group_phasors = [&](float (&pr)[S], float (&pi)[S], int kk, int g) {
@@ -497,7 +505,7 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
 #pragma unroll
             for (int g = 0; g < G; ++g)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) load_ant(raw[g][m], m, (unsigned)(c_begin * CHUNK + g * GSTRIDE + rel0) * EB);
+                for (int m = 0; m < MT; ++m) load_ant(raw[g][m], m, p_re, p_im, (unsigned)(c_begin * CHUNK + g * GSTRIDE + rel0) * EB);
         }
         preloaded = next_block;
         for (int c0 = c_begin; c0 < c_end; c0 += SEG) {
@@ -521,12 +529,14 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
             const int cf = min(c1, c_full);
             for (int c = c0; c < cf; ++c) {
                 const int srel = (c - c0) * CHUNK; // position of the step inside the segment
-                // next: the following chunk; after the last whole chunk the first chunk of the next block this workgroup
-                // walks (same descriptor, one block stride on); else a harmless re-load of the block's first bytes
+                // next: the following chunk; after the last chunk the first chunk of the next block this workgroup walks;
+                // else an offset beyond the block: the loads return zeros without touching memory
                 const bool more = c + 1 < c_full;
+                const bool hop = !more && next_block; // wave-uniform
+                const char *const n_re = hop ? p_re + blk_bytes : p_re, *const n_im = hop ? p_im + blk_bytes : p_im;
                 const unsigned next_off = more ? (unsigned)((c + 1) * CHUNK + rel0) * EB
-                                          : (next_block ? (unsigned)a.block_stride * EB + (unsigned)(c_begin * CHUNK + rel0) * EB : 0u);
-                const unsigned next_g = more || next_block ? (unsigned)(GSTRIDE * EB) : 0u;
+                                          : (hop ? (unsigned)(c_begin * CHUNK + rel0) * EB : (unsigned)blk_len);
+                const unsigned next_g = more || hop ? (unsigned)(GSTRIDE * EB) : 0u;
 #pragma unroll
                 for (int kk = 0; kk < KT; ++kk) {
                     // The samples of the next step are fetched during the pass of the LAST channel slot (every other pass
@@ -548,7 +558,7 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
                                     IO::get(raw[g][m], j, xr, xi);
                                     accumulate(acc[kk][m], xr, xi, pr[j], pi[j], chip[j]);
                                 }
-                                if (refill) load_ant(raw[g][m], m, next_off + g * next_g);
+                                if (refill) load_ant(raw[g][m], m, n_re, n_im, next_off + g * next_g);
                                 // antenna by antenna: left alone the scheduler wipes off all antennas first (their
                                 // products and the refilled sample registers are then live together: + 30 registers)
                                 __builtin_amdgcn_sched_barrier(0);
@@ -562,51 +572,21 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
 #pragma unroll
                         for (int g = 0; g < G; ++g)
 #pragma unroll
-                            for (int m = 0; m < MT; ++m) load_ant(raw[g][m], m, next_off + g * next_g);
+                            for (int m = 0; m < MT; ++m) load_ant(raw[g][m], m, n_re, n_im, next_off + g * next_g);
                     }
                     if (KT > 1) __builtin_amdgcn_sched_barrier(0); // one channel's chips and phasors at a time
                 }
             }
-            // ---- ragged tail (at most one chunk when the input is 16-byte aligned) / unaligned input ----------------
+            // ---- unaligned input (VEC == 1): one sample at a time with scalar loads -----------------------------------
+            if constexpr (VEC != 4) {
 #pragma unroll 1
-            for (int c = max(c0, cf); c < c1; ++c) {
-                const int srel = (c - c0) * CHUNK;
-#pragma unroll 1
-                for (int g = 0; g < G; ++g) {
-                    const int n = c * CHUNK + g * GSTRIDE + rel0;
-                    const int rel = srel + rel0 + g * GSTRIDE;
-                    if (VEC == 4 && n + S <= N) {
-                        i32x4 rawt[MT][IO::NV];
-#pragma unroll
-                        for (int m = 0; m < MT; ++m) load_ant(rawt[m], m, (unsigned)n * EB);
+                for (int c = max(c0, cf); c < c1; ++c) {
+                    const int n = c * CHUNK + rel0; // S == 1, G == 1
+                    if (n < N) {
 #pragma unroll
                         for (int kk = 0; kk < KT; ++kk) {
                             if (KT > 1 && !((valid_mask >> kk) & 1u)) continue;
-                            float pr[S], pi[S];
-                            const double th = __builtin_fma((double)n, s_const[kk].step, s_const[kk].phi);
-                            sincos_cycles(th - __builtin_rint(th), pr[0], pi[0]);
-#pragma unroll
-                            for (int j = 1; j < S; ++j) {
-                                pr[j] = __builtin_fmaf(pr[j - 1], wr_k[kk], -(pi[j - 1] * wi_k[kk]));
-                                pi[j] = __builtin_fmaf(pr[j - 1], wi_k[kk], pi[j - 1] * wr_k[kk]);
-                            }
-#pragma unroll
-                            for (int j = 0; j < S; ++j) {
-                                float chip[L];
-                                get_chips(chip, rel + j, s_rep + kk * 4 * RPS);
-#pragma unroll
-                                for (int m = 0; m < MT; ++m) {
-                                    float xr, xi;
-                                    IO::get(rawt[m], j, xr, xi);
-                                    accumulate(acc[kk][m], xr, xi, pr[j], pi[j], chip);
-                                }
-                            }
-                        }
-                    } else if (n < N) {
-#pragma unroll
-                        for (int kk = 0; kk < KT; ++kk) {
-                            if (KT > 1 && !((valid_mask >> kk) & 1u)) continue;
-                            scalar_run(kk, n, min(n + S, N), rel, s_rep + kk * 4 * RPS);
+                            scalar_run(kk, n, n + 1, (c - c0) * CHUNK + rel0, s_rep + kk * 4 * RPS);
                         }
                     }
                 }

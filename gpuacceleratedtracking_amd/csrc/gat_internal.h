@@ -70,6 +70,9 @@ struct DcLaunch {
     unsigned grid;
     unsigned lds_bytes;
 };
+#ifndef GAT_DC_SEG_ENTRIES
+#define GAT_DC_SEG_ENTRIES 8192
+#endif
 // Most steps whose code replica one workgroup produces at once (a "segment").  One channel per workgroup: ~8192 entries
 // (39 KB of LDS) when a wave carries 3-4 antennas -- those instances are limited to 3 workgroups per CU by registers
 // anyway, and longer segments mean fewer barriers (configs[1]: 0.846 vs 0.822 of HBM) --, ~4096 entries (25 KB) for 1-2
@@ -77,7 +80,7 @@ struct DcLaunch {
 // looping workgroup.  The host may ask for fewer (short blocks).
 constexpr int dc_segment_steps(int chunk, int kt, int mt)
 {
-    const int s = (kt == 1 ? (mt >= 3 ? 8192 : 4096) : 8192 / kt) / chunk;
+    const int s = (kt == 1 ? (mt >= 3 ? GAT_DC_SEG_ENTRIES : 4096) : 8192 / kt) / chunk;
     return s < 2 ? 2 : (s > 8 ? 8 : s);
 }
 // Floats per plane of the 4-plane replica of one segment: segment samples + kMaxReplicaSpan taps + room for every
