@@ -73,6 +73,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-shard-config3", action="store_true", help="N > 1: skip the configs[3] shard measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--block-ms", type=float, default=1.0, help="duration of one integration block (fs = N / block)")
+    ap.add_argument("--ant-pad", type=int, default=0,
+                    help="extra samples between the antennas' streams in the synthetic stream (experiments on memory-channel "
+                         "mapping; the default 0 is the contiguous [M x B*N] layout)")
     ap.add_argument("--cpu-sweep", metavar="OUT.json", default=None,
                     help="CPU-baseline leg only (no GPU): time the oracle's FP32 4-pass port, 1 thread, on the reference's "
                          "single-block sweep grid (scripts/run_benchmarks_gpsl1.jl / _gpsl5.jl with processor = CPU) and "
@@ -280,7 +283,7 @@ def measure(args, g, torch, dist, world, rank, shape_kw, steps, warmup, settle, 
     # channel sharding: rank r correlates PRNs [r*K, (r+1)*K) of the constellation on a replicated signal
     plan = g.shard_channels(K * world, world, rank)
     op, desc, sig, prm = g.build_stream(shape_kw["gnss"], N, M, L, K, B, layout=layout, first_prn=plan.lo, flags=flags,
-                                        block_seconds=shape_kw["block_ms"] * 1e-3)
+                                        block_seconds=shape_kw["block_ms"] * 1e-3, ant_pad=args.ant_pad)
     ctx = op.ctx
     fs = N / (shape_kw["block_ms"] * 1e-3)
 

@@ -225,7 +225,7 @@ def algorithmic_bytes(num_blocks, num_samples, num_ants, num_taps, num_channels,
 
 def build_stream(system_name: str, num_samples: int, num_ants: int, num_taps: int, num_channels: int,
                  num_blocks: int, layout: int = _lib.GAT_LAYOUT_PLANAR, first_prn: int = 0, flags: int = 0,
-                 device=None, block_seconds: float = 1e-3, amplitude: float | None = None):
+                 device=None, block_seconds: float = 1e-3, amplitude: float | None = None, ant_pad: int = 0):
     """Allocate + synthesise the device-resident stream and the operator.  Returns
     (op, desc, (re, im), params)."""
     system = GNSSDICT[system_name](use_gpu=True)
@@ -237,7 +237,7 @@ def build_stream(system_name: str, num_samples: int, num_ants: int, num_taps: in
         if layout >= _lib.GAT_LAYOUT_INTERLEAVED_I16:
             amplitude /= num_channels
     re, im = gen_signal_stream(system, prm_sig, fs, num_samples, num_ants, layout=layout, device=device,
-                               amplitude=amplitude)
+                               amplitude=amplitude, ant_pad=ant_pad)
     op = StreamCorrelator(system, num_samples, num_ants, num_blocks, num_channels, shifts, fs, flags=flags,
                           device=device)
     op.set_params(prm)

@@ -537,44 +537,72 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
                 const unsigned next_off = more ? (unsigned)((c + 1) * CHUNK + rel0) * EB
                                           : (hop ? (unsigned)(c_begin * CHUNK + rel0) * EB : (unsigned)blk_len);
                 const unsigned next_g = more || hop ? (unsigned)(GSTRIDE * EB) : 0u;
+                if constexpr (KT == 1) {
+                    // the samples of the next step are fetched antenna by antenna, into the registers that antenna's samples
+                    // of this step have just left
 #pragma unroll
-                for (int kk = 0; kk < KT; ++kk) {
-                    // The samples of the next step are fetched during the pass of the LAST channel slot (every other pass
-                    // re-reads the registers).  Always: a slot without a channel (K not a multiple of KT, last channel
-                    // group only) still issues the loads -- a conditional refill would make the compiler copy the array.
-                    const bool refill = kk == KT - 1; // compile-time after unrolling
-                    if (KT == 1 || ((valid_mask >> kk) & 1u)) {
+                    for (int g = 0; g < G; ++g) {
+                        const int rel = srel + rel0 + g * GSTRIDE;
+                        float pr[S], pi[S], chip[S][L];
+                        group_phasors(pr, pi, 0, g);
+                        get_chips_group(chip, rel, s_rep);
 #pragma unroll
-                        for (int g = 0; g < G; ++g) {
-                            const int rel = srel + rel0 + g * GSTRIDE;
-                            float pr[S], pi[S], chip[S][L];
-                            group_phasors(pr, pi, kk, g);
-                            get_chips_group(chip, rel, s_rep + kk * 4 * RPS);
+                        for (int m = 0; m < MT; ++m) {
 #pragma unroll
-                            for (int m = 0; m < MT; ++m) {
-#pragma unroll
-                                for (int j = 0; j < S; ++j) {
-                                    float xr, xi;
-                                    IO::get(raw[g][m], j, xr, xi);
-                                    accumulate(acc[kk][m], xr, xi, pr[j], pi[j], chip[j]);
-                                }
-                                if (refill) load_ant(raw[g][m], m, n_re, n_im, next_off + g * next_g);
-                                // antenna by antenna: left alone the scheduler wipes off all antennas first (their
-                                // products and the refilled sample registers are then live together: + 30 registers)
-                                __builtin_amdgcn_sched_barrier(0);
+                            for (int j = 0; j < S; ++j) {
+                                float xr, xi;
+                                IO::get(raw[g][m], j, xr, xi);
+                                accumulate(acc[0][m], xr, xi, pr[j], pi[j], chip[j]);
                             }
-                            // carry the group's phasor to the next step
+                            load_ant(raw[g][m], m, n_re, n_im, next_off + g * next_g);
+                            // antenna by antenna: left alone the scheduler wipes off all antennas first (their
+                            // products and the refilled sample registers are then live together: + 30 registers)
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        // carry the group's phasor to the next step
+                        const float t = __builtin_fmaf(car_r[0][g], cwr_k[0], -(car_i[0][g] * cwi_k[0]));
+                        car_i[0][g] = __builtin_fmaf(car_r[0][g], cwi_k[0], car_i[0][g] * cwr_k[0]);
+                        car_r[0][g] = t;
+                    }
+                } else {
+                    // Several channels on register-resident samples: the chips and phasors of ALL channels of the step are
+                    // fetched first, then ANTENNA by antenna -- all channels of antenna m, then antenna m's registers are
+                    // refilled for the next step, so that its load has a whole step of arithmetic to land.  (Channel by
+                    // channel the refills could only start in the last channel's pass: the 16-antenna shard of
+                    // configs[3] spent 3/4 of every step with no load in flight.)  A slot without a channel (K not a
+                    // multiple of KT, last channel group only) just skips its arithmetic.
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const int rel = srel + rel0 + g * GSTRIDE;
+                        float pr[KT][S], pi[KT][S], chip[KT][S][L];
+#pragma unroll
+                        for (int kk = 0; kk < KT; ++kk) {
+                            group_phasors(pr[kk], pi[kk], kk, g);
+                            get_chips_group(chip[kk], rel, s_rep + kk * 4 * RPS);
+                        }
+#pragma unroll
+                        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+                            for (int kk = 0; kk < KT; ++kk) {
+                                if ((valid_mask >> kk) & 1u) {
+#pragma unroll
+                                    for (int j = 0; j < S; ++j) {
+                                        float xr, xi;
+                                        IO::get(raw[g][m], j, xr, xi);
+                                        accumulate(acc[kk][m], xr, xi, pr[kk][j], pi[kk][j], chip[kk][j]);
+                                    }
+                                }
+                            }
+                            load_ant(raw[g][m], m, n_re, n_im, next_off + g * next_g);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+#pragma unroll
+                        for (int kk = 0; kk < KT; ++kk) { // carry the group's phasors to the next step
                             const float t = __builtin_fmaf(car_r[kk][g], cwr_k[kk], -(car_i[kk][g] * cwi_k[kk]));
                             car_i[kk][g] = __builtin_fmaf(car_r[kk][g], cwi_k[kk], car_i[kk][g] * cwr_k[kk]);
                             car_r[kk][g] = t;
                         }
-                    } else if (refill) {
-#pragma unroll
-                        for (int g = 0; g < G; ++g)
-#pragma unroll
-                            for (int m = 0; m < MT; ++m) load_ant(raw[g][m], m, n_re, n_im, next_off + g * next_g);
                     }
-                    if (KT > 1) __builtin_amdgcn_sched_barrier(0); // one channel's chips and phasors at a time
                 }
             }
             // ---- unaligned input (VEC == 1): one sample at a time with scalar loads -----------------------------------

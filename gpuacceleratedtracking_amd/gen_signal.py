@@ -66,12 +66,14 @@ _LAYOUT_DTYPE = {_lib.GAT_LAYOUT_INTERLEAVED: torch.float32, _lib.GAT_LAYOUT_INT
 
 def gen_signal_stream(system: GNSSSystem, params: np.ndarray, sampling_frequency: float, num_samples: int,
                       num_ants: int = 1, layout: int = _lib.GAT_LAYOUT_PLANAR, device=None,
-                      amplitude: float = 1.0):
+                      amplitude: float = 1.0, ant_pad: int = 0):
     """Batched form used by the stream benchmark: ``params`` is [B, K] (carrier phase in
     RADIANS, as ``start_carrier_phase`` in src/gen_signal.jl:88); block b holds the sum of its K
     channels times ``amplitude``.  Returns tensors: planar (re [M, B*N], im [M, B*N]) float32;
     interleaved layouts (x [M, B*N, 2], None) of float32 / int16 / int8 (integer layouts store
-    ``rint(amplitude * x)`` saturated -- what an ADC front-end delivers)."""
+    ``rint(amplitude * x)`` saturated -- what an ADC front-end delivers).  ``ant_pad``: extra samples between
+    the antennas' streams (the returned tensors are views [M, B*N(, 2)] of a padded allocation): antenna planes
+    whose distance is a large power-of-two multiple collide on the same memory channels."""
     ctx = get_context(device)
     ctx.set_codes(system.codes)
     params = np.ascontiguousarray(params, dtype=_lib.PARAMS_DTYPE)
@@ -80,13 +82,14 @@ def gen_signal_stream(system: GNSSSystem, params: np.ndarray, sampling_frequency
     B, K = params.shape
     m = _as_int(num_ants)
     dparams = ctx.params_to_device(params)
+    row = B * num_samples + int(ant_pad)
     if layout == _lib.GAT_LAYOUT_PLANAR:
-        re = torch.empty((m, B * num_samples), dtype=torch.float32, device=ctx.device)
-        im = torch.empty_like(re)
+        re = torch.empty((m, row), dtype=torch.float32, device=ctx.device)[:, :B * num_samples]
+        im = torch.empty((m, row), dtype=torch.float32, device=ctx.device)[:, :B * num_samples]
     else:
-        re = torch.empty((m, B * num_samples, 2), dtype=_LAYOUT_DTYPE[layout], device=ctx.device)
+        re = torch.empty((m, row, 2), dtype=_LAYOUT_DTYPE[layout], device=ctx.device)[:, :B * num_samples]
         im = None
-    ctx.gen_signal(re, im, layout, num_samples, m, B * num_samples, num_samples, B, K, dparams,
+    ctx.gen_signal(re, im, layout, num_samples, m, row, num_samples, B, K, dparams,
                    sampling_frequency, amplitude)
     return re, im
 

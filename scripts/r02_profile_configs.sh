@@ -14,7 +14,8 @@ stats() { # tag args...
 import csv, json, sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 d=json.loads(open(sys.argv[2]).read().strip().splitlines()[-1]); r=d["roofline"]
-top=max(rows,key=lambda x: float(x["TotalDurationNs"]))
+cand=[x for x in rows if "dc_kernel" in x["Name"] or "mfma_" in x["Name"]]
+top=max(cand or rows,key=lambda x: float(x["TotalDurationNs"]))
 print("%-10s %-60s calls %s avg %.1f us | bench: %.4f ms/launch %s frac %.3f (hbm %.3f)" % (sys.argv[3], top["Name"][:60], top["Calls"], float(top["AverageNs"])/1e3, r["kernel_ms_per_launch"], r["bound"], r["frac"], r["hbm_frac"]))
 PY
 }
@@ -39,10 +40,15 @@ stats c4 --baseline-config 3
 stats c5 --baseline-config 4
 stats c2_i16 --steps 50 --warmup 10 --layout i16
 stats c2_i8 --steps 50 --warmup 10 --layout i8
-for cfg in "c2 " "c3 --baseline-config 2" "c4 --baseline-config 3" "c5 --baseline-config 4"; do
-  set -- $cfg; tag=$1; shift
-  pmc ${tag}_fetch "FETCH_SIZE" "$@"
-  pmc ${tag}_write "WRITE_SIZE" "$@"
-  pmc ${tag}_sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY" "$@"
-  pmc ${tag}_sq2 "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS" "$@"
-done
+all4() { # tag bench-args...
+  t=$1; shift
+  pmc ${t}_fetch "FETCH_SIZE" "$@"
+  pmc ${t}_write "WRITE_SIZE" "$@"
+  pmc ${t}_sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY" "$@"
+  pmc ${t}_sq2 "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS" "$@"
+}
+all4 c2
+all4 c3 --baseline-config 2
+all4 c4 --baseline-config 3
+all4 c5 --baseline-config 4
+all4 c1shape --num-samples 4000 --num-ants 1 --blocks 16384
