@@ -47,6 +47,7 @@ struct gat_ctx {
     unsigned long long *dbg_ptr = nullptr; // diagnostic builds only
     int max_ant_tile = kMaxAntTile; // env GAT_MAX_ANT_TILE (experiments)
     int max_aw = 4, max_kt = 4, max_bpw = 16; // env GAT_DC_AW / GAT_DC_KT / GAT_DC_BPW: caps of the vector kernel's geometry
+    int wgs_per_cu = 8;                       // env GAT_DC_WGS_PER_CU: workgroups per CU the split planner aims for
     int mc_mode = 1; // GAT_MC_* kernel selection (gat_set_matrix_core); env GAT_NO_MFMA=1 starts at 0
     std::string err;
     gat_launch_info last{};
@@ -341,7 +342,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     const long long chunk = dc_chunk(vec, fmt, aw);
     const long long chunks = (N + chunk - 1) / chunk;
     const long long groups = (long long)B * KG * AG;
-    const long long target = 8ll * c->num_cus;
+    const long long target = (long long)c->wgs_per_cu * c->num_cus;
     long long splits = std::max<long long>(1, (target + groups - 1) / groups);
     splits = std::min(splits, chunks);
     // tiny blocks (latency regime): a second launch costs more than a few serial steps
@@ -409,7 +410,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     cfg.vec = vec;
     cfg.format = fmt;
     cfg.grid = (unsigned)grid_wgs;
-    a.seg_steps = (int)std::min<long long>(dc_segment_steps((int)chunk, kt, MT), cps);
+    const int seg_max = dc_segment_steps((int)chunk, kt, MT);
     cfg.lds_bytes = (unsigned)dc_lds_bytes(kt, MT, c->code_row_stride, (int)chunk);
 
     // Taps in any order: tap_index maps each tap of a launch back to its position in the caller's list
@@ -425,13 +426,21 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             a.tap_index[l] = order[t0 + std::min(l, cfg.taps - 1)];
         }
         a.rep_span = a.shifts[cfg.taps - 1] - a.shifts[0];
-        a.tap_step = cfg.taps > 1 ? a.shifts[1] - a.shifts[0] : 0;
-        for (int l = 1; l < cfg.taps; ++l)
-            if (a.shifts[l] - a.shifts[0] != l * a.tap_step) a.tap_step = -1;
-        // replica producers: kThreads / kt threads per channel, a quarter of them per plane; slots per thread and segment
-        const int per_plane = kThreads / kt / 4;
-        const long long seg_slots = (a.seg_steps * chunk + a.rep_span + 3) / 4;
-        a.rep_run = (int)((seg_slots + per_plane - 1) / per_plane);
+        // Replica layout in LDS (gat_dc.h): linear, one 8-byte-aligned vector read per tap and 4 samples.  Taps at an
+        // even distance from the first read the replica itself; any tap at an odd distance needs the copy stored one
+        // entry further, and the segment shrinks so that both fit the channel's share of LDS.
+        bool odd = false;
+        for (int l = 0; l < cfg.taps; ++l) odd |= ((a.shifts[l] - a.shifts[0]) & 1) != 0;
+        int seg = seg_max;
+        const int chan_floats = dc_rep_chan_floats((int)chunk, kt, MT);
+        if (odd)
+            while (seg > 1 && 2 * dc_rep_copy_floats(seg, (int)chunk, a.rep_span) > chan_floats) --seg;
+        a.seg_steps = (int)std::min<long long>(seg, cps);
+        a.rep_copy_stride = odd ? dc_rep_copy_floats(a.seg_steps, (int)chunk, a.rep_span) : 0;
+        for (int l = 0; l < kMaxTapsPerLaunch; ++l) {
+            const int d = a.shifts[l] - a.shifts[0];
+            a.tap_off[l] = (d & 1) ? a.rep_copy_stride + d - 1 : d;
+        }
         GAT_HIP(c, launch_dc(a, cfg, c->stream));
         t0 = t1;
     }
@@ -525,6 +534,7 @@ GAT_API int32_t gat_create(int32_t device, void *hip_stream, gat_ctx **out_ctx)
     if (const char *e = std::getenv("GAT_DC_AW")) c->max_aw = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("GAT_DC_KT")) c->max_kt = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("GAT_DC_BPW")) c->max_bpw = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("GAT_DC_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("GAT_MC_MODE")) c->mc_mode = (e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
         delete c;

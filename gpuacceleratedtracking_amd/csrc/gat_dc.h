@@ -18,13 +18,14 @@
 //     the samples stay in registers while the workgroup loops over its channels (AW = 4 only: measured, a channel
 //     loop over a single antenna tile never beat separate channel workgroups sharing the tile through L2);
 //   * code replica: produced for a SEGMENT of up to 8 steps at once into LDS ([steps*CHUNK + tap span] chips per
-//     channel), by an EXACT walk (gat_phase.h): one double-precision anchor per producer run, then 32.32 fixed-point
+//     channel), by an EXACT walk (gat_phase.h): one double-precision anchor per producer thread, then 32.32 fixed-point
 //     steps, branch-free; a batch holding a step that is not proven equal to the reference's floor is re-evaluated with
 //     the reference's expression -- bit-identical chip edges to the CPU oracle at ~1/2 of the vector instructions and
 //     none of the double-precision ones of evaluating floor(ratio*(n+shift)+tau) per sample.  Two barriers per segment,
-//     none in the step loop.  Stored as 4 interleaved planes (entry i at plane i&3, slot i>>2) so that lanes owning
-//     samples 4*lane + j read consecutive dwords (no bank conflict); a producer thread fills consecutive slots of
-//     ONE plane;
+//     none in the step loop.  Stored linearly (entry i <-> sample + first tap + i): the chips of a lane's S consecutive
+//     samples for one tap are ONE vector read (ds_read2_b64: 16 bytes at 8-byte alignment; consecutive lanes read
+//     consecutive 16 bytes).  A tap at an odd distance from the first reads a second copy stored one entry further
+//     (measured on gfx950: a ds_read_b128 at a 4-byte-aligned address works but takes 11x the cycles);
 //   * carrier: one phasor per group, anchored in double precision at every segment start, carried from step to step
 //     by one complex rotation, S-1 rotations inside the group; no per-(antenna, tap) double-precision sincos as in
 //     the reference (src/algorithms.jl:172);
@@ -211,10 +212,10 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
     struct ChanConst { double ratio, tau, step, phi; }; // per channel slot: read at segment starts and on ragged ends
     ChanConst *s_const = reinterpret_cast<ChanConst *>(smem);                          // [KT]
     float *s_part = reinterpret_cast<float *>(smem + KT * sizeof(ChanConst));          // [KT][4][64]
-    float *s_rep = s_part + KT * 4 * 64;                                               // [KT][4][RPS]
+    float *s_rep = s_part + KT * 4 * 64;                                               // [KT][RCH]
     const int SEG = a.seg_steps;        // steps whose replica is produced at once (<= dc_segment_steps(CHUNK, KT, MT))
-    constexpr int RPS = dc_rep_plane_stride(CHUNK, KT, MT); // floats per replica plane
-    int8_t *s_code = reinterpret_cast<int8_t *>(s_rep + KT * 4 * RPS);                 // [KT][code_row_stride]
+    constexpr int RCH = dc_rep_chan_floats(CHUNK, KT, MT); // floats per channel: the replica (+ its shifted copy)
+    int8_t *s_code = reinterpret_cast<int8_t *>(s_rep + KT * RCH);                     // [KT][code_row_stride]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -242,12 +243,10 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
     const float inv_lc = 1.0f / (float)Lc;
     const int shift0 = a.shifts[0];
 
-    // replica producer role of this thread: channel slot gk (wave-uniform), plane gp, slots [gs0, gs0 + run)
-    // of every segment; entry i = 4 * slot + plane <-> sample (segment start) + shift0 + i
+    // replica producer role of this thread: channel slot gk (wave-uniform), entries gr, gr + RPC, gr + 2 RPC, ... of
+    // every segment (consecutive lanes store consecutive floats); entry i <-> sample (segment start) + shift0 + i
     const int gk = uni(tid / RPC);
-    const int gp = tid & 3;
-    const int run = a.rep_run; // slots per producer thread and segment
-    const int gs0 = ((tid % RPC) >> 2) * run;
+    const int gr = tid % RPC;
 
     const int c_begin = split * a.chunks_per_split;
     const int c_end = min(c_begin + a.chunks_per_split, a.total_chunks);
@@ -327,8 +326,9 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
         {
             const ChanConst cc = s_const[gk];
             const double span = __builtin_fabs(cc.tau) + cc.ratio * (double)(N + a.max_abs_shift) + 1.0;
-            const ChipWalkConst wc = chip_walk_setup(cc.ratio, span, 4 * run + 4, 4, Lc);
-            const unsigned long long r4 = uni(wc.rate) * 4ull;
+            // a producer walks RPC samples per step, at most one segment (+ overshoot) away from its anchor
+            const ChipWalkConst wc = chip_walk_setup(cc.ratio, span, SEG * CHUNK + a.rep_span + 5 * RPC, RPC, Lc);
+            const unsigned long long r4 = uni(wc.rate) * (unsigned long long)RPC;
             w_rate_lo = (unsigned)r4;
             w_rate_hi = (unsigned)(r4 >> 32);
             w_margin = uni(wc.margin);
@@ -361,53 +361,39 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
         const size_t blk_bytes = (size_t)a.block_stride * EB;
         const int blk_len = N * EB; // bytes of one antenna's block: the descriptors' num_records (host: < 2^31)
 
-        // chips of the sample at segment-relative position rel, for the L taps
+        // chips of the sample at segment-relative position rel, for the L taps (scalar path)
         auto get_chips = [&](float (&chip)[L], int rel, const float *rep) {
 #pragma unroll
-            for (int l = 0; l < L; ++l) {
-                const int i = rel + (a.shifts[l] - shift0);
-                chip[l] = rep[(i & 3) * RPS + (i >> 2)];
-            }
+            for (int l = 0; l < L; ++l) chip[l] = rep[rel + (a.shifts[l] - shift0)];
         };
-        // chips of the S samples of one group (first sample at segment-relative position rel, a multiple of 4) for the
-        // L taps.  Entry (rel + j + o) sits in plane (j + o) & 3 -- the same for every lane -- at slot rel/4 + (j + o)/4.
-        // For evenly spaced taps (o_l = l * step: every E/P/L... correlator) the planes follow from step & 3 alone: a
-        // wave-uniform 4-way switch makes every read an immediate offset from ONE lane address per tap (the plain form
-        // costs 4-5 vector instructions of address arithmetic per read: a quarter of the step loop at 5 taps).
-        // The reads are inline assembly (left to itself the compiler sinks the cases' reads into one block and turns the
-        // immediates back into per-read additions).  It does not count asm loads: each case waits for its reads
-        // (lgkmcnt) and passes every destination through an empty statement after the wait BEFORE the case ends, so
-        // neither a consumer nor a register copy at the merge can come before the data.
-        auto fetch_chips = [&](auto tag, float (&chip)[S][L], unsigned pl) {
-            constexpr int A = decltype(tag)::value; // tap spacing & 3
-#pragma unroll
-            for (int l = 0; l < L; ++l) {
-                const unsigned p = pl + (unsigned)((l * a.tap_step) >> 2) * 4u;
-#pragma unroll
-                for (int j = 0; j < S; ++j)
-                    asm volatile("ds_read_b32 %0, %1 offset:%2"
-                                 : "=v"(chip[j][l])
-                                 : "v"(p), "i"((((j + l * A) & 3) * RPS + ((j + ((l * A) & 3)) >> 2)) * 4)
-                                 : "memory");
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int j = 0; j < S; ++j)
-#pragma unroll
-                for (int l = 0; l < L; ++l) asm volatile("" : "+v"(chip[j][l]));
-        };
+        // chips of the S samples of one group (first sample at segment-relative position rel, a multiple of S) for the
+        // L taps: one 8-byte-aligned vector read per tap and 4 samples -- tap_off[l] is the tap's distance from the first
+        // when that is even, else (distance - 1) into the copy stored one entry further (host: gat_api.cpp).
         auto get_chips_group = [&](float (&chip)[S][L], int rel, const float *rep) {
-            if (S % 4 == 0 && a.tap_step >= 0) { // wave-uniform
-                const unsigned pl = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)(rep + (rel >> 2));
-                switch (a.tap_step & 3) {
-                case 0: fetch_chips(std::integral_constant<int, 0>{}, chip, pl); break;
-                case 1: fetch_chips(std::integral_constant<int, 1>{}, chip, pl); break;
-                case 2: fetch_chips(std::integral_constant<int, 2>{}, chip, pl); break;
-                default: fetch_chips(std::integral_constant<int, 3>{}, chip, pl); break;
-                }
-            } else {
+#if defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 2)
+            for (int j = 0; j < S; ++j) for (int l = 0; l < L; ++l) chip[j][l] = __int_as_float(0x3f800000 + ((rel + j + l) & 1));
+            return;
+#endif
+            typedef float f32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
+            typedef float f32x2a8 __attribute__((ext_vector_type(2), aligned(8)));
 #pragma unroll
-                for (int j = 0; j < S; ++j) get_chips(chip[j], rel + j, rep);
+            for (int l = 0; l < L; ++l) {
+                const float *p = rep + rel + a.tap_off[l];
+                if constexpr (S % 4 == 0) {
+#pragma unroll
+                    for (int q = 0; q < S / 4; ++q) {
+                        const f32x4a8 v = *reinterpret_cast<const f32x4a8 *>(p + 4 * q);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) chip[4 * q + j][l] = v[j];
+                    }
+                } else if constexpr (S == 2) {
+                    const f32x2a8 v = *reinterpret_cast<const f32x2a8 *>(p);
+                    chip[0][l] = v[0];
+                    chip[1][l] = v[1];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < S; ++j) chip[j][l] = rep[rel + j + (a.shifts[l] - shift0)];
+                }
             }
         };
         // one sample of one antenna: conj(carrier) wipe-off (src/algorithms.jl:175-176), L taps.  Plain scalar FMAs:
@@ -425,6 +411,9 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
         // 16-byte loads of antenna m's group at byte offset `off` of the block that starts at (bre, bim) (KEEP: plain
         // loads that stay in L2 for the other channel groups, otherwise non-temporal: aux bit 1)
         auto load_ant = [&](i32x4 (&raw)[IO::NV], int m, const char *bre, const char *bim, unsigned off) {
+#if defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 1)
+            off &= 0x3ff0u; // every load hits the same 16 KB (cache-resident): the arithmetic without the HBM stream
+#endif
             constexpr int aux = KEEP ? 0 : 2;
             const __amdgpu_buffer_rsrc_t rr =
                 __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(bre + (size_t)m * ant_bytes), 0, blk_len, 0x00020000);
@@ -461,23 +450,32 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
             }
         };
         // The replica of one SEGMENT (SEG steps): entry i of a channel <-> sample c0*CHUNK + shift0 + i
-        // (src/algorithms.jl:753-757), i < seg_cnt = steps*CHUNK + tap span.  A producer thread owns `run` consecutive
-        // slots of one plane: ONE exact double-precision anchor, then the 32.32 walk (gat_phase.h) 4 samples at a
-        // time, branch-free; a batch with an unproven entry is redone with the reference's expression.
+        // (src/algorithms.jl:753-757), i < seg_cnt = steps*CHUNK + tap span.  Producer thread gr of a channel owns
+        // entries gr, gr + RPC, ...: ONE exact double-precision anchor, then the 32.32 walk (gat_phase.h) RPC samples
+        // at a time in batches of 4, branch-free; a batch with an unproven entry is redone with the reference's
+        // expression.  Every thread takes the same number of steps (the overshoot lands in the copy's spare room).
         auto fill_segment = [&](int c0, int seg_cnt) {
+#if defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 4)
+            return;
+#endif
             if (!g_valid) return;
-            float *rep = s_rep + gk * 4 * RPS + gp * RPS + gs0;
+            float *rep = s_rep + gk * RCH + gr;
+            const bool two = a.rep_copy_stride != 0;              // wave-uniform
+            float *rep1 = rep + a.rep_copy_stride - 1;            // copy[i] = entry i + 1
             const int8_t *tab = s_code + (size_t)gk * a.code_row_stride;
-            const int i0 = 4 * gs0 + gp;
-            if (i0 >= seg_cnt + 4) return; // nothing of this run is read (wave-divergent only at the segment's end)
-            const int x0 = c0 * CHUNK + shift0 + i0;
+            const int run = (seg_cnt + RPC - 1) / RPC;            // entries per producer thread (wave-uniform)
+            const int x0 = c0 * CHUNK + shift0 + gr;
             const double ratio = s_const[gk].ratio, tau = s_const[gk].tau;
             // exact anchor (src/algorithms.jl:179-182)
             const double p0 = code_phase(ratio, tau, x0);
             const double fl0 = __builtin_floor(p0);
             unsigned frac = (unsigned)((p0 - fl0) * 4294967296.0); // p - floor(p) is exact; truncation
             unsigned idx = (unsigned)floormod_fast((int)fl0, Lc, inv_lc);
-            rep[0] = (float)tab[idx];
+            {
+                const float v = (float)tab[idx];
+                rep[0] = v;
+                if (two && gr > 0) rep1[0] = v;
+            }
             for (int j0 = 1; j0 < run; j0 += 4) {
                 unsigned id[4];
                 bool amb = w_exact;
@@ -493,11 +491,15 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
                 }
                 if (__builtin_expect(amb, 0)) { // some entry of the batch is not proven (or nothing is): evaluate exactly
 #pragma unroll 1
-                    for (int u = 0; u < 4; ++u) id[u] = (unsigned)chip_index(ratio, tau, x0 + 4 * (j0 + u), Lc, inv_lc);
+                    for (int u = 0; u < 4; ++u) id[u] = (unsigned)chip_index(ratio, tau, x0 + RPC * (j0 + u), Lc, inv_lc);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (j0 + u < run) rep[j0 + u] = (float)tab[id[u]]; // wave-uniform bound; the planes hold every run whole
+                    if (j0 + u < run) { // wave-uniform bound
+                        const float v = (float)tab[id[u]];
+                        rep[(j0 + u) * RPC] = v;
+                        if (two) rep1[(j0 + u) * RPC] = v;
+                    }
             }
         };
 
@@ -510,7 +512,9 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
         preloaded = next_block;
         for (int c0 = c_begin; c0 < c_end; c0 += SEG) {
             const int c1 = min(c0 + SEG, c_end);
+#if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 8))
             if (c0 > c_begin) __syncthreads(); // everybody has finished reading the previous segment's replica
+#endif
             fill_segment(c0, (c1 - c0) * CHUNK + a.rep_span);
             // exact carrier anchors of this lane's groups at the segment start (src/algorithms.jl:172)
 #pragma unroll
@@ -520,7 +524,9 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
                     const double th = __builtin_fma((double)(c0 * CHUNK + g * GSTRIDE + rel0), s_const[kk].step, s_const[kk].phi);
                     sincos_cycles(th - __builtin_rint(th), car_r[kk][g], car_i[kk][g]);
                 }
+#if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 8))
             __syncthreads();
+#endif
 
             // ---- whole chunks.  The samples of step c+1 are loaded while step c is consumed: antenna by antenna, into
             // the registers that antenna's samples of step c have just left (loads in flight all the time, no second
@@ -554,10 +560,14 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
                                 IO::get(raw[g][m], j, xr, xi);
                                 accumulate(acc[0][m], xr, xi, pr[j], pi[j], chip[j]);
                             }
+#if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 16))
                             load_ant(raw[g][m], m, n_re, n_im, next_off + g * next_g);
+#endif
                             // antenna by antenna: left alone the scheduler wipes off all antennas first (their
                             // products and the refilled sample registers are then live together: + 30 registers)
+#if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 32))
                             __builtin_amdgcn_sched_barrier(0);
+#endif
                         }
                         // carry the group's phasor to the next step
                         const float t = __builtin_fmaf(car_r[0][g], cwr_k[0], -(car_i[0][g] * cwi_k[0]));
@@ -570,7 +580,8 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
                     // refilled for the next step, so that its load has a whole step of arithmetic to land.  (Channel by
                     // channel the refills could only start in the last channel's pass: the 16-antenna shard of
                     // configs[3] spent 3/4 of every step with no load in flight.)  A slot without a channel (K not a
-                    // multiple of KT, last channel group only) just skips its arithmetic.
+                    // multiple of KT, last channel group only) runs on the last channel's parameters and whatever its
+                    // replica slot holds; nothing of it is written (a branch per channel and antenna cost more).
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         const int rel = srel + rel0 + g * GSTRIDE;
@@ -578,23 +589,25 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
 #pragma unroll
                         for (int kk = 0; kk < KT; ++kk) {
                             group_phasors(pr[kk], pi[kk], kk, g);
-                            get_chips_group(chip[kk], rel, s_rep + kk * 4 * RPS);
+                            get_chips_group(chip[kk], rel, s_rep + kk * RCH);
                         }
 #pragma unroll
                         for (int m = 0; m < MT; ++m) {
 #pragma unroll
                             for (int kk = 0; kk < KT; ++kk) {
-                                if ((valid_mask >> kk) & 1u) {
 #pragma unroll
-                                    for (int j = 0; j < S; ++j) {
-                                        float xr, xi;
-                                        IO::get(raw[g][m], j, xr, xi);
-                                        accumulate(acc[kk][m], xr, xi, pr[kk][j], pi[kk][j], chip[kk][j]);
-                                    }
+                                for (int j = 0; j < S; ++j) {
+                                    float xr, xi;
+                                    IO::get(raw[g][m], j, xr, xi);
+                                    accumulate(acc[kk][m], xr, xi, pr[kk][j], pi[kk][j], chip[kk][j]);
                                 }
                             }
+#if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 16))
                             load_ant(raw[g][m], m, n_re, n_im, next_off + g * next_g);
+#endif
+#if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 32))
                             __builtin_amdgcn_sched_barrier(0);
+#endif
                         }
 #pragma unroll
                         for (int kk = 0; kk < KT; ++kk) { // carry the group's phasors to the next step
@@ -614,7 +627,7 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
 #pragma unroll
                         for (int kk = 0; kk < KT; ++kk) {
                             if (KT > 1 && !((valid_mask >> kk) & 1u)) continue;
-                            scalar_run(kk, n, n + 1, (c - c0) * CHUNK + rel0, s_rep + kk * 4 * RPS);
+                            scalar_run(kk, n, n + 1, (c - c0) * CHUNK + rel0, s_rep + kk * RCH);
                         }
                     }
                 }

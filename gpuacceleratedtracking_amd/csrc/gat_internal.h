@@ -51,12 +51,12 @@ struct DcArgs {
     int Ltot;              // taps of the whole call (output indexing)
     int max_abs_shift;     // max |shift| over ALL taps of the call (range check)
     int rep_span;          // shifts[last] - shifts[0] of THIS launch's taps (replica halo)
-    int rep_run;           // replica slots one producer thread fills per segment
     int seg_steps;         // steps per segment (replica produced at once), <= dc_segment_steps()
-    int tap_step;          // shifts[l] - shifts[0] == l * tap_step for every tap of this launch, or -1 (uneven spacing)
+    int rep_copy_stride;   // floats between the replica and its copy shifted by one entry (taps at odd offsets), 0: one copy
     int keep_l2;           // 1: plain loads (several channel groups share the tile through L2), 0: non-temporal
     unsigned flags;
     int shifts[kMaxTapsPerLaunch];    // ascending
+    int tap_off[kMaxTapsPerLaunch];   // float offset of tap l's chips from the lane's group base: even (8-byte aligned reads)
     int tap_index[kMaxTapsPerLaunch]; // position of each tap in the caller's list
 };
 
@@ -83,17 +83,22 @@ constexpr int dc_segment_steps(int chunk, int kt, int mt)
     const int s = (kt == 1 ? (mt >= 3 ? GAT_DC_SEG_ENTRIES : 4096) : 8192 / kt) / chunk;
     return s < 2 ? 2 : (s > 8 ? 8 : s);
 }
-// Floats per plane of the 4-plane replica of one segment: segment samples + kMaxReplicaSpan taps + room for every
-// producer run to be stored whole (up to 64 producer threads per plane, < 4 spare slots each ... 256).  Compile-time:
-// every chip read of the step loop is an immediate offset from one lane base.
-constexpr int dc_rep_plane_stride(int chunk, int kt, int mt)
+// Floats of LDS per channel for one segment's replica: entry i <-> sample (segment start) + shifts[0] + i, linear, so
+// that the chips of a lane's S consecutive samples are ONE 8-byte-aligned vector read per tap (ds_read2_b64).  Taps at
+// an odd distance from the first read a second copy shifted by one entry (rep_copy_stride floats further); the host
+// then halves the segment so that both fit here.  Room: segment samples + kMaxReplicaSpan taps + one entry per
+// producer thread of overshoot; at least one step with two copies.
+constexpr int dc_rep_copy_floats(int steps, int chunk, int span) { return (steps * chunk + span + kThreads + 2 + 1) & ~1; }
+constexpr int dc_rep_chan_floats(int chunk, int kt, int mt)
 {
-    return (((dc_segment_steps(chunk, kt, mt) * chunk + kMaxReplicaSpan + 3) / 4 + 256 + 23) / 32) * 32 + 8;
+    const int one = dc_rep_copy_floats(dc_segment_steps(chunk, kt, mt), chunk, kMaxReplicaSpan);
+    const int two = 2 * dc_rep_copy_floats(1, chunk, kMaxReplicaSpan);
+    return ((one > two ? one : two) + 7) & ~7;
 }
 // dynamic LDS of one dc_kernel workgroup: per-channel constants, reduction scratch, one segment's replica, chip tables
 constexpr size_t dc_lds_bytes(int kt, int mt, int code_row_stride, int chunk)
 {
-    return (size_t)kt * 32 + (size_t)kt * 4 * 64 * sizeof(float) + (size_t)kt * 4 * dc_rep_plane_stride(chunk, kt, mt) * sizeof(float) +
+    return (size_t)kt * 32 + (size_t)kt * 4 * 64 * sizeof(float) + (size_t)kt * dc_rep_chan_floats(chunk, kt, mt) * sizeof(float) +
            (size_t)kt * code_row_stride;
 }
 // does an instance of dc_kernel exist for this combination (gat_dc.h: dc_instance)

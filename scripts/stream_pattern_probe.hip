@@ -5,6 +5,7 @@
 // Build: hipcc -O3 --offload-arch=gfx950 scripts/stream_pattern_probe.hip -o /tmp/spp
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -36,6 +37,34 @@ __global__ void __launch_bounds__(256) read_pattern(const f4 *__restrict__ in, s
     if (s == 123.456f) out[0] = s;
 }
 
+// pattern b with a bounded window of bytes in flight: DEPTH steps (8 x 16 B per lane each) are outstanding per wave, and
+// the launch's dynamic LDS (unused) limits the workgroups per CU -- what does a window of W KB per CU stream at?
+template <int DEPTH>
+__global__ void __launch_bounds__(256) read_window(const f4 *__restrict__ in, size_t plane_f4, int N4, float *out)
+{
+    extern __shared__ float pad[];
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t b = blockIdx.x;
+    const f4 *base = in + (size_t)(8 * wave) * plane_f4 + b * N4 + lane;
+    f4 v[DEPTH][8];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) v[d][p] = __builtin_nontemporal_load(base + (size_t)p * plane_f4 + d * 64);
+    for (int c = DEPTH * 64; c + DEPTH * 64 <= N4; c += DEPTH * 64) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                acc.x += v[d][p].x; acc.y += v[d][p].y; acc.z += v[d][p].z; acc.w += v[d][p].w;
+                v[d][p] = __builtin_nontemporal_load(base + (size_t)p * plane_f4 + c + d * 64); // refill what was just consumed
+            }
+    }
+    float s = acc.x + acc.y + acc.z + acc.w;
+    if (s == 123.456f) out[0] = s + pad[0];
+}
+
 template <typename F> static float time_ms(F f, int reps)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -47,16 +76,51 @@ template <typename F> static float time_ms(F f, int reps)
     return t[t.size() / 2];
 }
 
-int main()
+// flat grid-stride read of the whole buffer: the ceiling a pattern-free reader reaches on this box
+__global__ void __launch_bounds__(256) read_flat(const f4 *__restrict__ in, size_t n_f4, float *out)
 {
-    // configs[3] shard: 32 planes (16 antennas x re/im) x 512 blocks x 50 000 samples (12 500 float4) = 3.28 GB
-    const int P = 32, B = 512, N4 = 12500;
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i + 768 < n_f4; i += stride) {
+        f4 v[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) v[p] = __builtin_nontemporal_load(in + i + p * 256);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { acc.x += v[p].x; acc.y += v[p].y; acc.z += v[p].z; acc.w += v[p].w; }
+    }
+    float s = acc.x + acc.y + acc.z + acc.w;
+    if (s == 123.456f) out[0] = s;
+}
+
+int main(int argc, char **argv)
+{
+    // default = configs[3] shard: 32 planes (16 antennas x re/im) x 512 blocks x 50 000 samples (12 500 float4) = 3.28 GB
+    // configs[1]: ./spp 8 4096 5000
+    const int P = argc > 1 ? atoi(argv[1]) : 32, B = argc > 2 ? atoi(argv[2]) : 512, N4 = argc > 3 ? atoi(argv[3]) : 12500;
     const size_t plane_f4 = (size_t)B * N4;
     f4 *d; float *o;
     CK(hipMalloc(&d, P * plane_f4 * sizeof(f4))); CK(hipMalloc(&o, 4));
     CK(hipMemset(d, 0, P * plane_f4 * sizeof(f4)));
     const double gb = (double)P * plane_f4 * 16 / 1e9;
     // (a) 8 planes per workgroup, 4 KB per plane and step: grid (B, 4)
+    for (int wgs : {2048, 4096, 8192, 16384}) {
+        float tf = time_ms([&] { hipLaunchKernelGGL(read_flat, dim3(wgs), dim3(256), 0, 0, d, P * plane_f4, o); }, 20);
+        printf("flat grid-stride read, %d workgroups: %.4f ms  %.0f GB/s\n", wgs, tf, gb / tf * 1e3);
+    }
+    for (int sp : {1, 2, 4, 8}) { // pattern a with every block cut into sp sample ranges
+        float t = time_ms([&] { hipLaunchKernelGGL(read_pattern<false>, dim3(B * sp, P / 8), dim3(256), 0, 0, d, plane_f4, N4 / sp, 8, o); }, 20);
+        printf("pattern a, blocks cut in %d (grid %d): %.4f ms  %.0f GB/s\n", sp, B * sp * P / 8, t, gb / t * 1e3);
+    }
+    if (P != 32) return 0;
+    for (int lds_kb : {66, 40, 20}) { // 2, 3-4, 8 workgroups per CU
+        float t1 = time_ms([&] { hipLaunchKernelGGL(read_window<1>, dim3(B * 4), dim3(256), lds_kb * 1024, 0, d, plane_f4, N4 / 4, o); }, 20);
+        float t2 = time_ms([&] { hipLaunchKernelGGL(read_window<2>, dim3(B * 4), dim3(256), lds_kb * 1024, 0, d, plane_f4, N4 / 4, o); }, 20);
+        float t3 = time_ms([&] { hipLaunchKernelGGL(read_window<3>, dim3(B * 4), dim3(256), lds_kb * 1024, 0, d, plane_f4, N4 / 4, o); }, 20);
+        const double rd1 = (double)B * 4 * 32 * (N4 / 4 / 64 * 64) * 16 / 1e9;
+        const double rd2 = (double)B * 4 * 32 * (N4 / 4 / 128 * 128) * 16 / 1e9, rd3 = (double)B * 4 * 32 * (N4 / 4 / 192 * 192) * 16 / 1e9;
+        printf("pattern b window, %d KB LDS per workgroup: 1 step in flight %.4f ms %.0f GB/s | 2 steps %.4f ms %.0f GB/s | 3 steps %.4f ms %.0f GB/s\n",
+               lds_kb, t1, rd1 / t1 * 1e3, t2, rd2 / t2 * 1e3, t3, rd3 / t3 * 1e3);
+    }
     float ta = time_ms([&] { hipLaunchKernelGGL(read_pattern<false>, dim3(B, 4), dim3(256), 0, 0, d, plane_f4, N4, 8, o); }, 20);
     // (b) 32 planes per workgroup, 1 KB per plane and step, block split in 4 sample ranges to keep the grid equal: emulate with grid (B*4) of N4/4
     float tb = time_ms([&] { hipLaunchKernelGGL(read_pattern<true>, dim3(B, 1), dim3(256), 0, 0, d, plane_f4, N4, 32, o); }, 20);
