@@ -408,6 +408,32 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
                 ac[l][1] = __builtin_fmaf(chip[l], di, ac[l][1]);
             }
         };
+        // the S samples of one antenna's group (one channel per workgroup): all wipe-off products first, then the tap
+        // multiply-adds -- every instruction then has its operands ready when it issues (written sample by sample the
+        // compiler forms the products right in front of their first use; configs[2] 1.36 -> 1.30 ms).  Not for the
+        // channel-looping instances: six more live registers there (configs[3] shard 0.70 -> 0.725 ms).
+        auto accumulate_group = [&](f32x2 (&ac)[L], const i32x4 (&rw)[IO::NV], const float (&pr)[S], const float (&pi)[S],
+                                    const float (&chip)[S][L]) {
+            float xr[S], xi[S], tr[S], ti[S], dr[S], di[S];
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                IO::get(rw, j, xr[j], xi[j]);
+                tr[j] = xi[j] * pi[j];
+                ti[j] = -(xr[j] * pi[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < S; ++j) {
+                dr[j] = __builtin_fmaf(xr[j], pr[j], tr[j]);
+                di[j] = __builtin_fmaf(xi[j], pr[j], ti[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < S; ++j)
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    ac[l][0] = __builtin_fmaf(chip[j][l], dr[j], ac[l][0]);
+                    ac[l][1] = __builtin_fmaf(chip[j][l], di[j], ac[l][1]);
+                }
+        };
         // 16-byte loads of antenna m's group at byte offset `off` of the block that starts at (bre, bim) (KEEP: plain
         // loads that stay in L2 for the other channel groups, otherwise non-temporal: aux bit 1)
         auto load_ant = [&](i32x4 (&raw)[IO::NV], int m, const char *bre, const char *bim, unsigned off) {
@@ -554,12 +580,7 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
                         get_chips_group(chip, rel, s_rep);
 #pragma unroll
                         for (int m = 0; m < MT; ++m) {
-#pragma unroll
-                            for (int j = 0; j < S; ++j) {
-                                float xr, xi;
-                                IO::get(raw[g][m], j, xr, xi);
-                                accumulate(acc[0][m], xr, xi, pr[j], pi[j], chip[j]);
-                            }
+                            accumulate_group(acc[0][m], raw[g][m], pr, pi, chip);
 #if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 16))
                             load_ant(raw[g][m], m, n_re, n_im, next_off + g * next_g);
 #endif

@@ -12,6 +12,7 @@ cd /tmp
 ARGS="--steps 4 --warmup 1 --settle 2 --no-cpu-baseline $*"
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --kernel-trace --output-format csv -d "$OUT/p1" -- python3 "$REPO/bench.py" $ARGS > "$OUT/b1.json" 2> "$OUT/p1.log"
 timeout -k 10 200 rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d "$OUT/p2" -- python3 "$REPO/bench.py" $ARGS > "$OUT/b2.json" 2> "$OUT/p2.log"
+timeout -k 10 200 rocprofv3 --pmc SQ_INST_LEVEL_VMEM SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LEVEL_WAVES SQ_IFETCH SQ_INSTS_SMEM SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$OUT/p3" -- python3 "$REPO/bench.py" $ARGS > "$OUT/b3.json" 2> "$OUT/p3.log"
 python3 - "$OUT" "$LIB $TAG" <<'PY'
 import csv, glob, os, sys
 out = sys.argv[1]
