@@ -48,6 +48,8 @@ struct gat_ctx {
     int max_ant_tile = kMaxAntTile; // env GAT_MAX_ANT_TILE (experiments)
     int max_aw = 4, max_kt = 4, max_bpw = 16; // env GAT_DC_AW / GAT_DC_KT / GAT_DC_BPW: caps of the vector kernel's geometry
     int wgs_per_cu = 8;                       // env GAT_DC_WGS_PER_CU: workgroups per CU the split planner aims for
+    int one_wave = 1;                         // env GAT_DC_ONE_WAVE=0: never use one-wave workgroups
+    long long one_wave_min = -1;              // env GAT_DC_ONE_WAVE_MIN: fewest (block, channel, tile) groups for them (default 32 per CU)
     int mc_mode = 1; // GAT_MC_* kernel selection (gat_set_matrix_core); env GAT_NO_MFMA=1 starts at 0
     std::string err;
     gat_launch_info last{};
@@ -339,10 +341,20 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     const int AG = AT / aw;
     const int KG = (K + kt - 1) / kt;
 
-    const long long chunk = dc_chunk(vec, fmt, aw);
-    const long long chunks = (N + chunk - 1) / chunk;
     const long long groups = (long long)B * KG * AG;
-    const long long target = (long long)c->wgs_per_cu * c->num_cus;
+    // One-wave workgroups: short blocks (a few steps of a four-wave workgroup) of one- or two-antenna tiles in a stream
+    // long enough to fill the chip with single waves.  Per block the set-up (parameters, rotations, walk constants) is
+    // then done by one wave instead of four, and no wave waits at a workgroup barrier.
+    int nw = 4;
+    if (c->one_wave && vec == 4 && aw == 1 && kt == 1 && MT <= 2 && c->code_row_stride <= 2048 &&
+        (N + dc_chunk(vec, fmt, 1) - 1) / dc_chunk(vec, fmt, 1) <= 8 &&
+        groups >= (c->one_wave_min >= 0 ? c->one_wave_min : 32ll * c->num_cus) &&
+        c->max_aw >= 4 /* the (1, 1, 1) tiling of the A/B tests keeps the four-wave geometry */ &&
+        dc_has_instance(MT, max_taps, vec, 1, 1, 1))
+        nw = 1;
+    const long long chunk = dc_chunk(vec, fmt, aw, nw);
+    const long long chunks = (N + chunk - 1) / chunk;
+    const long long target = (long long)c->wgs_per_cu * c->num_cus * (nw == 1 ? 4 : 1);
     long long splits = std::max<long long>(1, (target + groups - 1) / groups);
     splits = std::min(splits, chunks);
     // tiny blocks (latency regime): a second launch costs more than a few serial steps
@@ -353,8 +365,8 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     // and the workgroup launch are paid once) while the chip stays filled 16 workgroups deep per CU
     long long bpw = 1;
     if (splits == 1 && c->max_bpw > 1) {
-        const long long by_fill = std::max<long long>(1, groups / (16ll * c->num_cus));
-        const long long by_len = std::max<long long>(1, 16 / chunks);
+        const long long by_fill = std::max<long long>(1, groups / (16ll * c->num_cus * (nw == 1 ? 4 : 1)));
+        const long long by_len = std::max<long long>(1, (nw == 1 ? 64 : 16) / chunks);
         bpw = std::min<long long>(std::min(by_fill, by_len), c->max_bpw);
     }
     const long long BG = (B + bpw - 1) / bpw;
@@ -407,10 +419,13 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     cfg.ant_tile = MT;
     cfg.aw = aw;
     cfg.kt = kt;
+    cfg.nw = nw;
     cfg.vec = vec;
     cfg.format = fmt;
     cfg.grid = (unsigned)grid_wgs;
-    const int seg_max = dc_segment_steps((int)chunk, kt, MT);
+    int ow_seg = kOneWaveSegSteps;
+    if (const char *e = std::getenv("GAT_DC_OW_SEG")) ow_seg = std::max(1, std::atoi(e)); // development: A/B of the segment length
+    const int seg_max = nw == 1 ? ow_seg : dc_segment_steps((int)chunk, kt, MT);
     cfg.lds_bytes = (unsigned)dc_lds_bytes(kt, MT, c->code_row_stride, (int)chunk);
 
     // Taps in any order: tap_index maps each tap of a launch back to its position in the caller's list
@@ -432,11 +447,19 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         bool odd = false;
         for (int l = 0; l < cfg.taps; ++l) odd |= ((a.shifts[l] - a.shifts[0]) & 1) != 0;
         int seg = seg_max;
-        const int chan_floats = dc_rep_chan_floats((int)chunk, kt, MT);
-        if (odd)
-            while (seg > 1 && 2 * dc_rep_copy_floats(seg, (int)chunk, a.rep_span) > chan_floats) --seg;
-        a.seg_steps = (int)std::min<long long>(seg, cps);
-        a.rep_copy_stride = odd ? dc_rep_copy_floats(a.seg_steps, (int)chunk, a.rep_span) : 0;
+        if (nw == 1) { // the replica's LDS is sized for this launch: segment + tap span + one entry per producer lane
+            a.seg_steps = (int)std::min<long long>(seg, cps);
+            const int one = dc_rep_copy_floats(a.seg_steps, (int)chunk, a.rep_span, 64);
+            a.rep_copy_stride = odd ? one : 0;
+            a.rep_chan_floats = ((odd ? 2 : 1) * one + 7) & ~7;
+            cfg.lds_bytes = (unsigned)dc_lds_bytes_one_wave(a.rep_chan_floats, c->code_row_stride);
+        } else {
+            const int chan_floats = dc_rep_chan_floats((int)chunk, kt, MT);
+            if (odd)
+                while (seg > 1 && 2 * dc_rep_copy_floats(seg, (int)chunk, a.rep_span) > chan_floats) --seg;
+            a.seg_steps = (int)std::min<long long>(seg, cps);
+            a.rep_copy_stride = odd ? dc_rep_copy_floats(a.seg_steps, (int)chunk, a.rep_span) : 0;
+        }
         for (int l = 0; l < kMaxTapsPerLaunch; ++l) {
             const int d = a.shifts[l] - a.shifts[0];
             a.tap_off[l] = (d & 1) ? a.rep_copy_stride + d - 1 : d;
@@ -450,7 +473,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
                                    c->stream));
 
     c->last.workgroups = (int32_t)cfg.grid;
-    c->last.threads = kThreads;
+    c->last.threads = 64 * nw;
     c->last.splits = (int32_t)splits;
     c->last.ant_tile = MT * aw;
     c->last.vec = vec;
@@ -535,6 +558,8 @@ GAT_API int32_t gat_create(int32_t device, void *hip_stream, gat_ctx **out_ctx)
     if (const char *e = std::getenv("GAT_DC_KT")) c->max_kt = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("GAT_DC_BPW")) c->max_bpw = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("GAT_DC_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("GAT_DC_ONE_WAVE")) c->one_wave = std::atoi(e) != 0;
+    if (const char *e = std::getenv("GAT_DC_ONE_WAVE_MIN")) c->one_wave_min = std::atoll(e);
     if (const char *e = std::getenv("GAT_MC_MODE")) c->mc_mode = (e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
         delete c;

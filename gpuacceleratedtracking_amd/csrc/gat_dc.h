@@ -189,19 +189,24 @@ struct SampleIO {
 // (measured in both rounds: 1.2-3x slower).
 constexpr int dc_min_waves(int mt, int l, int kt) { return 2 * mt * l * kt <= 40 ? 3 : 1; }
 
-template <int MT, int L, int VEC, int FMT, int AW, int KT, bool KEEP>
-__global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(const DcArgs a)
+template <int MT, int L, int VEC, int FMT, int AW, int KT, bool KEEP, int NW>
+__global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(const DcArgs a)
 {
+    // NW = 4 waves per workgroup, or 1: short blocks in a long stream (a few steps per block) spend their time in the
+    // per-block set-up, which all four waves of a workgroup repeat, and at its three barriers; a one-wave workgroup
+    // does the set-up once per block and never waits for another wave.
+    constexpr int T = 64 * NW;          // threads per workgroup
     using IO = SampleIO<FMT>;
     // A lane owns G groups of S consecutive samples per step; one group = one 16-byte load per plane.
     constexpr int S = dc_group_samples(VEC, FMT);
     constexpr int G = dc_groups(VEC, FMT);
-    constexpr int SUBS = 4 / AW;        // sample sub-chunks per workgroup (waves that share an antenna tile)
+    constexpr int SUBS = NW / AW;       // sample sub-chunks per workgroup (waves that share an antenna tile)
     constexpr int VT = 64 * SUBS;       // lanes that share an antenna tile
     constexpr int GSTRIDE = VT * S;
     constexpr int CHUNK = GSTRIDE * G;
-    static_assert(CHUNK == dc_chunk(VEC, FMT, AW), "host and device disagree on the chunk size");
-    constexpr int RPC = kThreads / KT;  // replica producer threads per channel (>= 64: a wave serves one channel)
+    static_assert(CHUNK == dc_chunk(VEC, FMT, AW, NW), "host and device disagree on the chunk size");
+    static_assert(NW == 4 || (NW == 1 && AW == 1 && KT == 1), "one-wave workgroups: one antenna tile, one channel");
+    constexpr int RPC = T / KT;         // replica producer threads per channel (>= 64: a wave serves one channel)
     constexpr int NV = 2 * MT * L;      // values of one channel's reduction, id = (l*MT + m)*2 + {0: re, 1: im}
     constexpr int EB = (FMT == GAT_LAYOUT_PLANAR) ? 4 : IO::BYTES; // bytes per sample in one plane
     static_assert(NV <= 64, "one value per lane after the butterfly");
@@ -211,10 +216,11 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     struct ChanConst { double ratio, tau, step, phi; }; // per channel slot: read at segment starts and on ragged ends
     ChanConst *s_const = reinterpret_cast<ChanConst *>(smem);                          // [KT]
-    float *s_part = reinterpret_cast<float *>(smem + KT * sizeof(ChanConst));          // [KT][4][64]
-    float *s_rep = s_part + KT * 4 * 64;                                               // [KT][RCH]
+    float *s_part = reinterpret_cast<float *>(smem + KT * sizeof(ChanConst));          // [KT][NW][64]
+    float *s_rep = s_part + KT * NW * 64;                                              // [KT][RCH]
     const int SEG = a.seg_steps;        // steps whose replica is produced at once (<= dc_segment_steps(CHUNK, KT, MT))
-    constexpr int RCH = dc_rep_chan_floats(CHUNK, KT, MT); // floats per channel: the replica (+ its shifted copy)
+    // floats per channel: the replica (+ its shifted copy); one-wave workgroups: sized by the host for this launch
+    const int RCH = NW == 1 ? a.rep_chan_floats : dc_rep_chan_floats(CHUNK, KT, MT);
     int8_t *s_code = reinterpret_cast<int8_t *>(s_rep + KT * RCH);                     // [KT][code_row_stride]
 
     const int tid = threadIdx.x;
@@ -312,7 +318,7 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
             for (int kk = 0; kk < KT; ++kk) {
                 const i32x4 *g = reinterpret_cast<const i32x4 *>(a.codes + (size_t)prn_k[kk] * a.code_row_stride);
                 i32x4 *d = reinterpret_cast<i32x4 *>(s_code + (size_t)kk * a.code_row_stride);
-                for (int i = tid; i < (Lc + 15) / 16; i += kThreads) d[i] = g[i];
+                for (int i = tid; i < (Lc + 15) / 16; i += T) d[i] = g[i];
                 staged_prn[kk] = prn_k[kk];
             }
         }
@@ -668,17 +674,17 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
                 }
             Butterfly<NV, 32>::run(v, lane);
             // lanes sharing an index hold bit-identical sums
-            s_part[(kk * 4 + wave) * 64 + Butterfly<NV, 32>::index(lane)] = v[0];
+            s_part[(kk * NW + wave) * 64 + Butterfly<NV, 32>::index(lane)] = v[0];
         }
         __syncthreads();
 
-        for (int o = tid; o < KT * AW * NV; o += kThreads) {
+        for (int o = tid; o < KT * AW * NV; o += T) {
             const int kk = o / (AW * NV);
             const int r = o - kk * (AW * NV);
             const int at = r / NV, vi = r - (r / NV) * NV;
             const int k = kg * KT + kk;
             if (k >= a.K) continue;
-            const float *p = s_part + (kk * 4 + at) * 64 + vi; // wave = sub * AW + at
+            const float *p = s_part + (kk * NW + at) * 64 + vi; // wave = sub * AW + at
             float tot;
             if constexpr (SUBS == 4) tot = (p[0] + p[64]) + (p[128] + p[192]);
             else if constexpr (SUBS == 2) tot = p[0] + p[AW * 64];
@@ -709,8 +715,10 @@ __global__ void __launch_bounds__(kThreads, dc_min_waves(MT, L, KT)) dc_kernel(c
 // ------------------------------------------------------------------------------------------------------------
 // Which instances exist.  Register accumulators 2 * MT * L * KT <= 64; antenna-parallel waves (AW > 1) need full
 // 4-antenna tiles; unaligned input (VEC == 1, scalar loads) is served one antenna per workgroup.
-constexpr bool dc_instance(int mt, int l, int vec, int aw, int kt)
+constexpr bool dc_instance(int mt, int l, int vec, int aw, int kt, int nw = 4)
 {
+    // one-wave workgroups: short blocks of one- and two-antenna tiles
+    if (nw != 4 && !(nw == 1 && vec == 4 && aw == 1 && kt == 1 && mt <= 2)) return false;
 #ifdef GAT_DC_DEV // development builds: only the instances the BASELINE shapes use (compiles in seconds)
     if (!((mt == 1 || mt == 4) && (l == 3 || l == 5) && vec == 4)) return false;
 #endif
@@ -723,18 +731,25 @@ constexpr bool dc_instance(int mt, int l, int vec, int aw, int kt)
     return (kt == 1 || kt == 2 || kt == 4) && mt * l * kt <= 48;
 }
 
-template <int FMT, int MT, int L, int VEC, int AW, int KT>
-static hipError_t launch_dc_one(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
+template <int FMT, int MT, int L, int VEC, int AW, int KT, int NW>
+static hipError_t launch_dc_nw(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
 {
-    if constexpr (dc_instance(MT, L, VEC, AW, KT)) {
+    if constexpr (dc_instance(MT, L, VEC, AW, KT, NW)) {
         if (VEC == 4 && a.keep_l2)
-            hipLaunchKernelGGL((dc_kernel<MT, L, VEC, FMT, AW, KT, VEC == 4>), dim3(cfg.grid), dim3(kThreads), cfg.lds_bytes, s, a);
+            hipLaunchKernelGGL((dc_kernel<MT, L, VEC, FMT, AW, KT, VEC == 4, NW>), dim3(cfg.grid), dim3(64 * NW), cfg.lds_bytes, s, a);
         else
-            hipLaunchKernelGGL((dc_kernel<MT, L, VEC, FMT, AW, KT, false>), dim3(cfg.grid), dim3(kThreads), cfg.lds_bytes, s, a);
+            hipLaunchKernelGGL((dc_kernel<MT, L, VEC, FMT, AW, KT, false, NW>), dim3(cfg.grid), dim3(64 * NW), cfg.lds_bytes, s, a);
         return hipGetLastError();
     } else {
         return hipErrorInvalidValue;
     }
+}
+
+template <int FMT, int MT, int L, int VEC, int AW, int KT>
+static hipError_t launch_dc_one(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
+{
+    if (cfg.nw == 1) return launch_dc_nw<FMT, MT, L, VEC, AW, KT, 1>(a, cfg, s);
+    return launch_dc_nw<FMT, MT, L, VEC, AW, KT, 4>(a, cfg, s);
 }
 
 template <int FMT, int MT, int L>

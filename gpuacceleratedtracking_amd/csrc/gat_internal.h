@@ -28,8 +28,9 @@ constexpr int dc_groups(int vec, int fmt)
 {
     return vec != 4 ? 1 : fmt == GAT_LAYOUT_PLANAR ? GAT_PLANAR_GROUPS : fmt == GAT_LAYOUT_INTERLEAVED ? 2 : 1;
 }
-// samples one workgroup covers per step: the 4 / aw waves that share an antenna tile, 64 lanes each
-constexpr int dc_chunk(int vec, int fmt, int aw = 1) { return (kThreads / aw) * dc_group_samples(vec, fmt) * dc_groups(vec, fmt); }
+// samples one workgroup covers per step: the nw / aw waves that share an antenna tile, 64 lanes each (nw = 4 waves per
+// workgroup, or 1: one-wave workgroups for short blocks, see gat_dc.h)
+constexpr int dc_chunk(int vec, int fmt, int aw = 1, int nw = 4) { return (64 * nw / aw) * dc_group_samples(vec, fmt) * dc_groups(vec, fmt); }
 
 // Arguments of the fused correlator kernel (passed by value in the kernarg segment).
 struct DcArgs {
@@ -53,6 +54,7 @@ struct DcArgs {
     int rep_span;          // shifts[last] - shifts[0] of THIS launch's taps (replica halo)
     int seg_steps;         // steps per segment (replica produced at once), <= dc_segment_steps()
     int rep_copy_stride;   // floats between the replica and its copy shifted by one entry (taps at odd offsets), 0: one copy
+    int rep_chan_floats;   // one-wave workgroups: floats of LDS per channel replica (sized for this launch's taps)
     int keep_l2;           // 1: plain loads (several channel groups share the tile through L2), 0: non-temporal
     unsigned flags;
     int shifts[kMaxTapsPerLaunch];    // ascending
@@ -64,6 +66,7 @@ struct DcLaunch {
     int ant_tile; // MT: antennas per wave
     int aw;       // antenna tiles (waves) per workgroup: 1, 2, 4
     int kt;       // channels per workgroup: 1, 2, 4
+    int nw;       // waves per workgroup: 4, or 1 (short blocks: one wave per block, no workgroup barrier to wait at)
     int taps;     // L of this launch
     int vec;      // 4 or 1
     int format;   // GAT_LAYOUT_*
@@ -88,7 +91,7 @@ constexpr int dc_segment_steps(int chunk, int kt, int mt)
 // an odd distance from the first read a second copy shifted by one entry (rep_copy_stride floats further); the host
 // then halves the segment so that both fit here.  Room: segment samples + kMaxReplicaSpan taps + one entry per
 // producer thread of overshoot; at least one step with two copies.
-constexpr int dc_rep_copy_floats(int steps, int chunk, int span) { return (steps * chunk + span + kThreads + 2 + 1) & ~1; }
+constexpr int dc_rep_copy_floats(int steps, int chunk, int span, int threads = kThreads) { return (steps * chunk + span + threads + 2 + 1) & ~1; }
 constexpr int dc_rep_chan_floats(int chunk, int kt, int mt)
 {
     const int one = dc_rep_copy_floats(dc_segment_steps(chunk, kt, mt), chunk, kMaxReplicaSpan);
@@ -102,7 +105,13 @@ constexpr size_t dc_lds_bytes(int kt, int mt, int code_row_stride, int chunk)
            (size_t)kt * code_row_stride;
 }
 // does an instance of dc_kernel exist for this combination (gat_dc.h: dc_instance)
-bool dc_has_instance(int ant_tile, int taps, int vec, int aw, int kt);
+bool dc_has_instance(int ant_tile, int taps, int vec, int aw, int kt, int nw = 4);
+// one-wave workgroups: steps per segment and LDS bytes (replica sized for the launch's own tap span)
+constexpr int kOneWaveSegSteps = 4;
+constexpr size_t dc_lds_bytes_one_wave(int rep_chan_floats, int code_row_stride)
+{
+    return 32 + 64 * sizeof(float) + (size_t)rep_chan_floats * sizeof(float) + (size_t)code_row_stride;
+}
 
 // Arguments of the matrix-core kernel (gat_mfma.hip): 16-antenna tiles, planar f32 input.
 constexpr int kMfmaMaxTaps = 16;     // 2 * CT * L <= 32 columns with CT >= 1

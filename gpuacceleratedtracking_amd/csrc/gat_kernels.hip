@@ -287,7 +287,7 @@ extern template hipError_t launch_dc_fmt<GAT_LAYOUT_INTERLEAVED>(const DcArgs &,
 extern template hipError_t launch_dc_fmt<GAT_LAYOUT_INTERLEAVED_I16>(const DcArgs &, const DcLaunch &, hipStream_t);
 extern template hipError_t launch_dc_fmt<GAT_LAYOUT_INTERLEAVED_I8>(const DcArgs &, const DcLaunch &, hipStream_t);
 
-bool dc_has_instance(int ant_tile, int taps, int vec, int aw, int kt) { return dc_instance(ant_tile, taps, vec, aw, kt); }
+bool dc_has_instance(int ant_tile, int taps, int vec, int aw, int kt, int nw) { return dc_instance(ant_tile, taps, vec, aw, kt, nw); }
 
 hipError_t launch_dc(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
 {

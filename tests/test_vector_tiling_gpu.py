@@ -162,3 +162,44 @@ def test_exact_walk_survives_adversarial_code_phases(gat, vector_ctx):
         op(d_re, d_im)
         got = op.result()
         assert np.array_equal(got.real.astype(np.float64), ref.real), tiling
+
+
+ONE_WAVE_SHAPES = [
+    # system, N, M, L, K, B  -- short blocks of one- and two-antenna tiles: one wave per (block, channel, tile)
+    ("GPSL1", 4000, 1, 3, 1, 40),    # configs[0] shape in a stream
+    ("GPSL1", 2048, 2, 3, 3, 17),    # two antennas per wave, 3 channel groups
+    ("GPSL1", 1001, 1, 5, 2, 9),     # ragged: 1001 is no multiple of the group size -> scalar path keeps four waves
+    ("GPSL1", 1000, 1, 4, 1, 33),    # 4 taps; several segments per block (4 steps each)
+    ("GPSL1", 6000, 2, 7, 2, 5),     # 7 taps
+    ("GPSL1", 260, 1, 3, 1, 64),     # barely more than one step
+]
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2, 3], ids=["planar", "interleaved", "i16", "i8"])
+@pytest.mark.parametrize("shape", ONE_WAVE_SHAPES, ids=[f"N{s[1]}-M{s[2]}-L{s[3]}-K{s[4]}-B{s[5]}" for s in ONE_WAVE_SHAPES])
+def test_one_wave_workgroups_match_the_oracle(gat, shape, layout, monkeypatch):
+    """Short blocks in a long stream run one wave per block (gat_dc.h, NW = 1).  The planner takes that path from 32
+    groups per CU on; GAT_DC_ONE_WAVE_MIN=1 (read when a context is created) takes it for these small cases too."""
+    import torch
+    monkeypatch.setenv("GAT_DC_ONE_WAVE_MIN", "1")
+    ctx = gat.Context(torch.cuda.current_device())
+    try:
+        ctx.set_matrix_core(gat.GAT_MC_VECTOR)
+        system, N, M, L, K, B = shape
+        case = make_case(zlib.crc32(repr(shape).encode()), system=system, N=N, M=M, L=L, K=K, B=B)
+        if layout >= 2:  # integer front-end samples: quantise the case itself so that the oracle sees the same numbers
+            s = 100.0 if layout == 2 else 20.0
+            case["re"] = np.rint(case["re"] * s).astype(np.float32)
+            case["im"] = np.rint(case["im"] * s).astype(np.float32)
+        got, info = run_case(gat, ctx, case, layout=layout)
+        group = {0: 4, 1: 2, 2: 4, 3: 8}[layout]
+        assert info["threads"] == (64 if N % group == 0 else 256), info
+        check_close(got, oracle_result(case), what=f"{shape} {info}")
+        # and the four-wave geometry on the same inputs: same chip edges, same sums up to summation order
+        ctx.set_vector_tiling(1, 1, 1)
+        ref, info4 = run_case(gat, ctx, case, layout=layout)
+        assert info4["threads"] == 256, info4
+        scale = np.abs(ref).max(axis=(2, 3), keepdims=True)
+        assert np.max(np.abs(got - ref) / scale) < 2e-6
+    finally:
+        ctx.close()
