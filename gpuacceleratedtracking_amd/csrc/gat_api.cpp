@@ -150,6 +150,14 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
 
     const long long N = sig->num_samples;
     if (vec != 4) MT = 1; // unaligned input (scalar loads) is served one antenna per wave
+    // the vector kernel reaches a wave's MT antennas through ONE descriptor per plane (antenna = scalar offset): the
+    // tile's span of bytes must stay below 2^31 (a lane offset of 2^31 then means "beyond every record")
+    while (MT > 1 && ((long long)(MT - 1) * sig->ant_stride + N) * plane_bytes >= (1ll << 31)) {
+        int next = 1;
+        for (int mt = MT - 1; mt >= 1; --mt)
+            if (M % mt == 0) { next = mt; break; }
+        MT = next;
+    }
 
     // ---- matrix-core paths: antenna-rich shapes whose (channel, tap) columns fill a useful part of
     // a 32-column tile run on the matrix cores -- the split-bf16 kernel (gat_mfma_bf16.hip) by default,

@@ -351,11 +351,13 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
 #pragma unroll
                 for (int l = 0; l < L; ++l) acc[kk][m][l] = f32x2{0.f, 0.f};
 
-        // Sample loads are raw buffer loads through a descriptor per (antenna, plane) of exactly ONE block's length,
-        // built from wave-uniform values next to each load (two scalar adds): a 32-bit lane offset shared by every load
-        // of a step, and lanes beyond the block's end read zeros without touching memory -- the ragged last chunk
-        // needs no special path (measured on gfx950: the range check is per dword and covers voffset + soffset, so
-        // the antenna goes into the descriptor base, not into soffset).  The cache policy is a template parameter: a
+        // Sample loads are raw buffer loads through ONE descriptor per plane that spans the wave's MT antennas of this
+        // block (built once per step from wave-uniform values); the antenna is the instruction's scalar offset, the lane
+        // offset is shared by every load of a step.  Lanes beyond the block's end get the offset 2^31: beyond every
+        // record (the host keeps a tile's span below 2^31), they read zeros without touching memory -- the ragged
+        // last chunk needs no special path (measured on gfx950: the range check is per dword and covers voffset +
+        // soffset).  (A descriptor per (antenna, plane) of one block's length needs no lane mask but ~6 scalar
+        // instructions per load: a fifth of all instructions of the four-antenna five-tap step.)  The cache policy is a template parameter: a
         // wave-uniform `if (keep) plain else non-temporal` pair of ordinary loads is merged by the compiler into plain
         // loads (the hint is only metadata; that cost 7 % at configs[1]), and the same branch around buffer loads
         // breaks the step into many basic blocks (+ 50 registers).
@@ -365,7 +367,11 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
         const char *const p_im = static_cast<const char *>(FMT == GAT_LAYOUT_PLANAR ? a.im : a.re) + base * EB;
         const size_t ant_bytes = (size_t)a.ant_stride * EB;
         const size_t blk_bytes = (size_t)a.block_stride * EB;
-        const int blk_len = N * EB; // bytes of one antenna's block: the descriptors' num_records (host: < 2^31)
+        const int blk_len = N * EB; // bytes of one antenna's block
+        const unsigned tile_len = (unsigned)((MT - 1) * ant_bytes) + (unsigned)blk_len; // the descriptors' num_records (host: < 2^31)
+        constexpr unsigned kNoRecord = 0x80000000u;
+        auto plane_rsrc = [&](const char *p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p), 0, (int)tile_len, 0x00020000); };
+        auto lane_offset = [&](unsigned off) { return off < (unsigned)blk_len ? off : kNoRecord; };
 
         // chips of the sample at segment-relative position rel, for the L taps (scalar path)
         auto get_chips = [&](float (&chip)[L], int rel, const float *rep) {
@@ -442,19 +448,14 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
         };
         // 16-byte loads of antenna m's group at byte offset `off` of the block that starts at (bre, bim) (KEEP: plain
         // loads that stay in L2 for the other channel groups, otherwise non-temporal: aux bit 1)
-        auto load_ant = [&](i32x4 (&raw)[IO::NV], int m, const char *bre, const char *bim, unsigned off) {
+        auto load_ant = [&](i32x4 (&raw)[IO::NV], int m, __amdgpu_buffer_rsrc_t rr, __amdgpu_buffer_rsrc_t ri, unsigned off) {
 #if defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 1)
             off &= 0x3ff0u; // every load hits the same 16 KB (cache-resident): the arithmetic without the HBM stream
 #endif
             constexpr int aux = KEEP ? 0 : 2;
-            const __amdgpu_buffer_rsrc_t rr =
-                __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(bre + (size_t)m * ant_bytes), 0, blk_len, 0x00020000);
-            raw[0] = (i32x4)__builtin_amdgcn_raw_buffer_load_b128(rr, off, 0, aux);
-            if constexpr (IO::NV == 2) {
-                const __amdgpu_buffer_rsrc_t ri =
-                    __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(bim + (size_t)m * ant_bytes), 0, blk_len, 0x00020000);
-                raw[1] = (i32x4)__builtin_amdgcn_raw_buffer_load_b128(ri, off, 0, aux);
-            }
+            const int soff = (int)((unsigned)m * (unsigned)ant_bytes); // wave-uniform
+            raw[0] = (i32x4)__builtin_amdgcn_raw_buffer_load_b128(rr, off, soff, aux);
+            if constexpr (IO::NV == 2) raw[1] = (i32x4)__builtin_amdgcn_raw_buffer_load_b128(ri, off, soff, aux);
         };
         // the S phasors of one group: carried phasor + S-1 rotations
         auto group_phasors = [&](float (&pr)[S], float (&pi)[S], int kk, int g) {
@@ -536,10 +537,13 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
         };
 
         if (c_begin < c_full && !preloaded) {
+            const __amdgpu_buffer_rsrc_t rr = plane_rsrc(p_re), ri = plane_rsrc(p_im);
 #pragma unroll
-            for (int g = 0; g < G; ++g)
+            for (int g = 0; g < G; ++g) {
+                const unsigned off = lane_offset((unsigned)(c_begin * CHUNK + g * GSTRIDE + rel0) * EB);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) load_ant(raw[g][m], m, p_re, p_im, (unsigned)(c_begin * CHUNK + g * GSTRIDE + rel0) * EB);
+                for (int m = 0; m < MT; ++m) load_ant(raw[g][m], m, rr, ri, off);
+            }
         }
         preloaded = next_block;
         for (int c0 = c_begin; c0 < c_end; c0 += SEG) {
@@ -575,6 +579,10 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
                 const unsigned next_off = more ? (unsigned)((c + 1) * CHUNK + rel0) * EB
                                           : (hop ? (unsigned)(c_begin * CHUNK + rel0) * EB : (unsigned)blk_len);
                 const unsigned next_g = more || hop ? (unsigned)(GSTRIDE * EB) : 0u;
+                const __amdgpu_buffer_rsrc_t n_rr = plane_rsrc(n_re), n_ri = plane_rsrc(n_im);
+                unsigned n_off[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) n_off[g] = lane_offset(next_off + g * next_g);
                 if constexpr (KT == 1) {
                     // the samples of the next step are fetched antenna by antenna, into the registers that antenna's samples
                     // of this step have just left
@@ -588,7 +596,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
                         for (int m = 0; m < MT; ++m) {
                             accumulate_group(acc[0][m], raw[g][m], pr, pi, chip);
 #if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 16))
-                            load_ant(raw[g][m], m, n_re, n_im, next_off + g * next_g);
+                            load_ant(raw[g][m], m, n_rr, n_ri, n_off[g]);
 #endif
                             // antenna by antenna: left alone the scheduler wipes off all antennas first (their
                             // products and the refilled sample registers are then live together: + 30 registers)
@@ -630,7 +638,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
                                 }
                             }
 #if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 16))
-                            load_ant(raw[g][m], m, n_re, n_im, next_off + g * next_g);
+                            load_ant(raw[g][m], m, n_rr, n_ri, n_off[g]);
 #endif
 #if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 32))
                             __builtin_amdgcn_sched_barrier(0);

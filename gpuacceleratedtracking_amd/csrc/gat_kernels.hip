@@ -287,8 +287,6 @@ extern template hipError_t launch_dc_fmt<GAT_LAYOUT_INTERLEAVED>(const DcArgs &,
 extern template hipError_t launch_dc_fmt<GAT_LAYOUT_INTERLEAVED_I16>(const DcArgs &, const DcLaunch &, hipStream_t);
 extern template hipError_t launch_dc_fmt<GAT_LAYOUT_INTERLEAVED_I8>(const DcArgs &, const DcLaunch &, hipStream_t);
 
-bool dc_has_instance(int ant_tile, int taps, int vec, int aw, int kt, int nw) { return dc_instance(ant_tile, taps, vec, aw, kt, nw); }
-
 hipError_t launch_dc(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
 {
     if (!dc_instance(cfg.ant_tile, cfg.taps, cfg.vec, cfg.aw, cfg.kt)) return hipErrorInvalidValue;
