@@ -176,13 +176,14 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         while (nct > 1 && nct * CT > 20) nct >>= 1; // both kernels keep at most 20 channel slots per workgroup
         // kernel choice: 3 / 1 (auto) -> split-bf16 when its tile fits in LDS, 2 -> f32 MFMA.  GAT_MC_AUTO picks a matrix
         // kernel only where it measured faster than the vector kernel (scripts/r02_planner_scan.sh, profiles/r02/
-        // r02d_planner_scan.txt; N = 50 000, 3 taps): with float samples the re-tiled vector kernel (16 antennas per
-        // workgroup, channel loop over register-resident samples) wins at 16 antennas for every channel count and at
-        // 32 / 64 antennas up to ~4-8 channels, so the split-bf16 kernel takes M >= 32 with M * K >= 512; from int8
-        // pairs (single-term path, half the MFMAs) it wins from 24 (channel, tap, re/im) columns on at every M.  The
-        // f32-MFMA kernel serves only code tables that are not +-1, at large antenna x channel products.
+        // r02h_planner_scan.txt; N = 50 000, 3 taps): with float samples the round-2 vector kernel (16 antennas per
+        // workgroup, channel loop over register-resident samples, lean step loop) wins or ties up to 24 channels at 64
+        // antennas, 32 at 32 and 16 at 128, so the split-bf16 kernel takes M >= 32 with K >= 32 and M * K >= 2048
+        // (64 x 32: 0.53 vs 0.58 ms, 32 x 64: 0.84 vs 0.99, 64 x 64: 0.75 vs 1.03); from int8 pairs (single-term
+        // path, half the MFMAs) it wins from 24 (channel, tap, re/im) columns on at every M.  The f32-MFMA kernel
+        // serves only code tables that are not +-1, at large antenna x channel products.
         const bool int8_in = fmt == GAT_LAYOUT_INTERLEAVED_I8;
-        const bool auto_bf16 = 2ll * L * K >= 24 && (int8_in || (M >= 32 && (long long)M * K >= 512));
+        const bool auto_bf16 = 2ll * L * K >= 24 && (int8_in || (M >= 32 && K >= 32 && (long long)M * K >= 2048));
         const bool auto_f32 = 2ll * L * K >= 24 && (long long)M * K >= 2048;
         const bool want_bf16 = c->mc_mode == 3 || (c->mc_mode == 1 && auto_bf16);
         const bool want_f32 = c->mc_mode == 2 || (c->mc_mode == 1 && auto_f32);

@@ -3,7 +3,7 @@
 # (FETCH_SIZE / WRITE_SIZE in separate runs; SQ counters) -> gpurun_out/r02p/
 set -o pipefail
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/r02p; mkdir -p $OUT
+OUT=$REPO/gpurun_out/${GAT_PROFILE_TAG:-r02p}; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 stats() { # tag args...
@@ -46,6 +46,7 @@ all4() { # tag bench-args...
   pmc ${t}_write "WRITE_SIZE" "$@"
   pmc ${t}_sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY" "$@"
   pmc ${t}_sq2 "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS" "$@"
+  pmc ${t}_clk "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_SMEM SQ_IFETCH" "$@"  # GRBM_GUI_ACTIVE / 8 XCDs / kernel time = shader clock
 }
 all4 c2
 all4 c3 --baseline-config 2

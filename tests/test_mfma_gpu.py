@@ -52,15 +52,16 @@ GRID = [
     ("GPSL1", 9000, 64, 3, 3, 1, 0),  # 4 row tiles, 18 of 32 columns: below the auto threshold (vector kernel faster)
     ("GPSL1", 70004, 48, 3, 10, 1),   # 3 antenna tiles of one row tile each, ragged last step
     ("GPSL5", 30000, 64, 5, 12, 1),   # L5: 12 channels x 5 taps = 4 channel tiles of CT = 3
+    ("GPSL1", 12000, 64, 3, 32, 1),   # above the auto threshold (M >= 32, K >= 32, M * K >= 2048): split-bf16 by default
 ]
 
 
 @pytest.mark.parametrize("cfg", GRID, ids=lambda c: f"{c[0]}-N{c[1]}-M{c[2]}-L{c[3]}-K{c[4]}-B{c[5]}")
 def test_mfma_parity(g, cfg):
     system, N, M, L, K, B = cfg[:6]
-    # GAT_MC_AUTO (float samples): the split-bf16 kernel from 24 (channel, tap, re/im) columns on when M >= 32 and
-    # M * K >= 512; below that the re-tiled vector kernel measured faster (profiles/r02/r02d_planner_scan.txt)
-    auto_kind = cfg[6] if len(cfg) > 6 else (2 if (2 * L * K >= 24 and M >= 32 and M * K >= 512) else 0)
+    # GAT_MC_AUTO (float samples): the split-bf16 kernel when M >= 32, K >= 32 and M * K >= 2048; below that the
+    # round-2 vector kernel measured as fast or faster (profiles/r02/r02h_planner_scan.txt)
+    auto_kind = cfg[6] if len(cfg) > 6 else (2 if (2 * L * K >= 24 and M >= 32 and K >= 32 and M * K >= 2048) else 0)
     forced = 2 if not (L == 1 and K == 16) else 1  # GAT_MC_BF16_SPLIT takes every shape whose tile fits
     fs = {"GPSL1": 8e6, "GPSL5": 25e6}[system] if L <= 5 else 2.5e6
     case = make_case(zlib.crc32(repr(cfg).encode()), system=system, N=N, M=M, L=L, K=K, B=B, fs=fs, if_hz=1.1e6)
