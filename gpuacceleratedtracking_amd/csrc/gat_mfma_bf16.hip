@@ -118,17 +118,27 @@ struct FragSet {
     u32x4 w;
     unsigned m;
     u32x2 xa[RT];
+#if defined(GAT_ABLATE) && (GAT_ABLATE & 64)
+    u32x2 wl;
+#endif
 };
 template <int RT>
 struct FragSet<RT, true> {
     u32x4 w;
     u32x2 m;
     u32x4 xa[RT];
+#if defined(GAT_ABLATE) && (GAT_ABLATE & 64)
+    u32x2 wl;
+#endif
 };
 template <int J, int RT, bool X1>
 __device__ __forceinline__ void frag_issue(FragSet<RT, X1> &s, unsigned w_addr, unsigned r_addr, const unsigned (&x_addr)[RT])
 {
+#if defined(GAT_ABLATE) && (GAT_ABLATE & 64) // diagnostic: half the W fragment bytes (results wrong)
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(s.wl) : "v"(w_addr), "n"(J * 16));
+#else
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(s.w) : "v"(w_addr), "n"(J * 16));
+#endif
     if constexpr (X1) {
         asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(s.m) : "v"(r_addr), "n"(2 * J), "n"(2 * J + 1));
 #pragma unroll
@@ -170,6 +180,9 @@ __device__ __forceinline__ void mfma_slice(f32x16 (&acc)[RT == 1 ? 2 : RT], Frag
     frag_wait<RT, X1, newer *(2 + RT)>(cur);
     if constexpr (J + D < NM) frag_issue<J + D, RT, X1>(fs[(J + D) % (D + 1)], w_addr, r_addr, x_addr);
     u32x4 w = cur.w;
+#if defined(GAT_ABLATE) && (GAT_ABLATE & 64)
+    if constexpr (!X1) w = u32x4{cur.wl[0], cur.wl[1], cur.wl[0], cur.wl[1]};
+#endif
     if constexpr (X1) { // chip signs of the lane's two samples
         const unsigned m0 = cur.m[0], m1 = cur.m[1];
         w[0] ^= m0;
