@@ -3,9 +3,13 @@
 // Launch planning for the fused correlator (DESIGN.md "Kernels"):
 //   ant_tile MT = largest of {4,3,2,1} dividing M          (register accumulators 2*MT*L <= 64)
 //   vec      = 4 when every plane base/stride is 16-byte aligned, else 1
+//   aw, kt   = antenna tiles (waves) and channels per workgroup: 16 antennas share one replica, up to 4 channels loop
+//              over register-resident samples
+//   nw       = waves per workgroup: 4, or 1 for short blocks of 1-2 antenna tiles in a long stream
 //   splits   = workgroups per (block, channel, antenna tile): 1 once B*K*M/MT already fills the
 //              chip (>= 8 workgroups per CU), otherwise the block's samples are split and a
 //              finalize launch sums the per-split partials in fixed order.
+//   matrix-core kernels where they measured faster (auto rule below).
 #include <algorithm>
 #include <cmath>
 #include <cstdio>

@@ -6,7 +6,8 @@
 //   R[m,l,k,b] = sum_n x[n,m,b] * conj(exp(j2pi(n*f/fs + phi))) * c_k[floor(fc/fs*(n+shift_l)+tau) mod Lc]
 //
 // How (CDNA4-first, not the reference's shared-memory tree per sample):
-//   * workgroup = 4 wave64 on one (integration block, antenna group, sample split) and KT channels.  Wave w owns
+//   * workgroup = 4 wave64 (or ONE, for short blocks in a long stream: NW below) on one (integration block, antenna
+//     group, sample split) and KT channels.  Wave w owns
 //     antenna tile (w % AW) -- MT <= 4 antennas -- and sample sub-chunk (w / AW): with AW = 4 the four waves walk the
 //     SAME samples on 16 antennas and share one code replica;
 //   * every lane owns S consecutive samples per group and loads them as ONE 16-byte buffer load per antenna plane
@@ -325,7 +326,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
         __syncthreads(); // s_const and the tables are in place
 
         // ---- replica producer: walk constants of this thread's channel ----------------------------------------
-        // one producer step advances 4 samples (the next slot of the thread's plane)
+        // one producer step advances RPC samples (the thread's next entry)
         unsigned w_rate_lo, w_rate_hi, w_margin;
         bool w_exact;
         const bool g_valid = (valid_mask >> gk) & 1u;
