@@ -54,6 +54,7 @@ struct gat_ctx {
     int wgs_per_cu = 8;                       // env GAT_DC_WGS_PER_CU: workgroups per CU the split planner aims for
     int one_wave = 1;                         // env GAT_DC_ONE_WAVE=0: never use one-wave workgroups
     long long one_wave_min = -1;              // env GAT_DC_ONE_WAVE_MIN: fewest (block, channel, tile) groups for them (default 32 per CU)
+    int one_wave_seg = kOneWaveSegSteps;      // env GAT_DC_OW_SEG: steps per replica segment of a one-wave workgroup
     int mc_mode = 1; // GAT_MC_* kernel selection (gat_set_matrix_core); env GAT_NO_MFMA=1 starts at 0
     std::string err;
     gat_launch_info last{};
@@ -436,9 +437,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     cfg.vec = vec;
     cfg.format = fmt;
     cfg.grid = (unsigned)grid_wgs;
-    int ow_seg = kOneWaveSegSteps;
-    if (const char *e = std::getenv("GAT_DC_OW_SEG")) ow_seg = std::max(1, std::atoi(e)); // development: A/B of the segment length
-    const int seg_max = nw == 1 ? ow_seg : dc_segment_steps((int)chunk, kt, MT);
+    const int seg_max = nw == 1 ? c->one_wave_seg : dc_segment_steps((int)chunk, kt, MT);
     cfg.lds_bytes = (unsigned)dc_lds_bytes(kt, MT, c->code_row_stride, (int)chunk);
 
     // Taps in any order: tap_index maps each tap of a launch back to its position in the caller's list
@@ -573,6 +572,7 @@ GAT_API int32_t gat_create(int32_t device, void *hip_stream, gat_ctx **out_ctx)
     if (const char *e = std::getenv("GAT_DC_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("GAT_DC_ONE_WAVE")) c->one_wave = std::atoi(e) != 0;
     if (const char *e = std::getenv("GAT_DC_ONE_WAVE_MIN")) c->one_wave_min = std::atoll(e);
+    if (const char *e = std::getenv("GAT_DC_OW_SEG")) c->one_wave_seg = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("GAT_MC_MODE")) c->mc_mode = (e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
         delete c;
