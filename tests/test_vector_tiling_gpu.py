@@ -203,3 +203,33 @@ def test_one_wave_workgroups_match_the_oracle(gat, shape, layout, monkeypatch):
         assert np.max(np.abs(got - ref) / scale) < 2e-6
     finally:
         ctx.close()
+
+
+def test_antenna_tile_whose_span_exceeds_a_descriptor(gat, vector_ctx):
+    """A wave reaches its antennas through one buffer descriptor per plane (antenna = scalar offset, lanes past the
+    block end get the offset 2^31): the host must tile fewer antennas per wave when (MT - 1) * ant_stride + N samples do
+    not fit 2^31 bytes.  Four antennas 200 M samples apart (0.8 GB): two per wave still fit, four do not."""
+    import torch
+    shape = ("GPSL1", 6000, 4, 3, 2, 1)
+    system, N, M, L, K, B = shape
+    case = make_case(zlib.crc32(repr(shape).encode()), system=system, N=N, M=M, L=L, K=K, B=B)
+    dev = vector_ctx.device
+    stride = 200_000_000
+    re = torch.zeros((M - 1) * stride + N, dtype=torch.float32, device=dev)
+    im = torch.zeros_like(re)
+    for m in range(M):
+        re[m * stride:m * stride + N] = torch.from_numpy(case["re"][m]).to(dev)
+        im[m * stride:m * stride + N] = torch.from_numpy(case["im"][m]).to(dev)
+    sysobj = gat.GNSSDICT[system](use_gpu=True)
+    op = gat.StreamCorrelator(sysobj, N, M, B, K, case["shifts"], case["fs"], ctx=vector_ctx)
+    p = case["prm"]
+    op.set_params(gat.make_params(p["prn0"], p["code_freq_hz"], p["carrier_freq_hz"], p["code_phase_chips"],
+                                  p["carrier_phase_cycles"]))
+    from gpuacceleratedtracking_amd import _lib
+    desc = _lib.SignalDesc(re.data_ptr(), im.data_ptr(), gat.GAT_LAYOUT_PLANAR, M, N, stride, N, 0)
+    op.launch(desc)
+    got, info = op.result(), vector_ctx.last_launch_info()
+    assert info["matrix_core"] == 0 and info["ant_tile"] == 2, info  # 3 * 0.8 GB + N > 2^31 > 1 * 0.8 GB + N
+    check_close(got, oracle_result(case), what=f"wide antenna stride {info}")
+    del re, im
+    torch.cuda.empty_cache()
