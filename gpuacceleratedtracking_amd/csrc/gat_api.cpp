@@ -185,11 +185,12 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         // workgroup, channel loop over register-resident samples, lean step loop) wins or ties up to 24 channels at 64
         // antennas, 32 at 32 and 16 at 128, so the split-bf16 kernel takes M >= 32 with K >= 32 and M * K >= 2048
         // (64 x 32: 0.53 vs 0.58 ms, 32 x 64: 0.84 vs 0.99, 64 x 64: 0.75 vs 1.03); from int8 pairs (single-term
-        // path, half the MFMAs) it wins from 24 (channel, tap, re/im) columns on at every M.  The f32-MFMA kernel
-        // serves only code tables that are not +-1, at large antenna x channel products.
+        // path, half the MFMAs) it wins from 24 (channel, tap, re/im) columns on at every M.  The f32-MFMA kernel is
+        // never chosen by itself any more: the round-2 vector kernel is faster everywhere (configs[4]: 2.45 vs 4.19 ms,
+        // 64 antennas x 32 channels: 0.58 vs 0.92 ms); it runs on request (GAT_MC_F32).
         const bool int8_in = fmt == GAT_LAYOUT_INTERLEAVED_I8;
         const bool auto_bf16 = 2ll * L * K >= 24 && (int8_in || (M >= 32 && K >= 32 && (long long)M * K >= 2048));
-        const bool auto_f32 = 2ll * L * K >= 24 && (long long)M * K >= 2048;
+        const bool auto_f32 = false;
         const bool want_bf16 = c->mc_mode == 3 || (c->mc_mode == 1 && auto_bf16);
         const bool want_f32 = c->mc_mode == 2 || (c->mc_mode == 1 && auto_f32);
         int kind = 0, rt = 1, rep_stride_m = 0;

@@ -289,9 +289,10 @@ GAT_API int32_t gat_memset(gat_ctx *ctx, void *dst_dev, int32_t value, size_t by
 GAT_API int32_t gat_timer_start(gat_ctx *ctx);
 GAT_API int32_t gat_timer_stop(gat_ctx *ctx, float *elapsed_ms);
 
-/* Kernel selection.  By default (GAT_MC_AUTO) antenna-rich shapes (M % 16 == 0, at least 24 (channel, tap,
- * re/im) columns) run on the matrix cores with the split-bf16 kernel (gat_mfma_bf16.hip: both operands as
- * hi+mid+lo bf16 terms, f32-equivalent accuracy; every sample format), everything else on the vector kernel.
+/* Kernel selection.  By default (GAT_MC_AUTO) the library runs the split-bf16 matrix-core kernel (gat_mfma_bf16.hip:
+ * both operands as hi+mid+lo bf16 terms, f32-equivalent accuracy; every sample format) where it measured faster than
+ * the vector kernel -- M % 16 == 0 and at least 24 (channel, tap, re/im) columns, then: float / int16 samples from 32
+ * antennas x 32 channels on (antennas x channels >= 2048), int8 pairs always --, everything else on the vector kernel.
  * GAT_MC_VECTOR forces the vector kernel (A/B measurements, bit-comparisons), GAT_MC_F32 the
  * f32-MFMA kernel (gat_mfma.hip), GAT_MC_BF16_SPLIT the split-bf16 kernel only (shapes neither
  * matrix kernel takes fall through to the vector kernel in every mode). */
