@@ -65,6 +65,29 @@ __global__ void __launch_bounds__(256) read_window(const f4 *__restrict__ in, si
     if (s == 123.456f) out[0] = s + pad[0];
 }
 
+// one-wave workgroups, one block each (the configs[0]-shape geometry): 2 planes, G KB contiguous per plane and step
+template <int G>
+__global__ void __launch_bounds__(64) read_onewave(const f4 *__restrict__ re, const f4 *__restrict__ im, int N4, float *out)
+{
+    extern __shared__ float pad[];
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const size_t b = blockIdx.x;
+    const f4 *pr = re + b * N4 + threadIdx.x, *pi = im + b * N4 + threadIdx.x;
+    f4 v[2][G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { v[0][g] = __builtin_nontemporal_load(pr + g * 64); v[1][g] = __builtin_nontemporal_load(pi + g * 64); }
+    for (int c = 64 * G; c + 64 * G <= N4; c += 64 * G) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            acc.x += v[0][g].x + v[1][g].x; acc.y += v[0][g].y + v[1][g].y; acc.z += v[0][g].z + v[1][g].z; acc.w += v[0][g].w + v[1][g].w;
+            v[0][g] = __builtin_nontemporal_load(pr + c + g * 64);
+            v[1][g] = __builtin_nontemporal_load(pi + c + g * 64);
+        }
+    }
+    float s = acc.x + acc.y + acc.z + acc.w;
+    if (s == 123.456f) out[0] = s + pad[0];
+}
+
 template <typename F> static float time_ms(F f, int reps)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -103,6 +126,17 @@ int main(int argc, char **argv)
     CK(hipMemset(d, 0, P * plane_f4 * sizeof(f4)));
     const double gb = (double)P * plane_f4 * 16 / 1e9;
     // (a) 8 planes per workgroup, 4 KB per plane and step: grid (B, 4)
+    if (P == 2) { // configs[0] shape: ./spp 2 16384 1000 (re and im planes of one antenna, 16384 blocks of 1000 float4)
+        const f4 *re = d, *im = d + plane_f4;
+        for (int lds_kb : {5, 8}) {
+            float t1 = time_ms([&] { hipLaunchKernelGGL(read_onewave<1>, dim3(B), dim3(64), lds_kb * 1024 + 700, 0, re, im, N4, o); }, 20);
+            float t2 = time_ms([&] { hipLaunchKernelGGL(read_onewave<2>, dim3(B), dim3(64), lds_kb * 1024 + 700, 0, re, im, N4, o); }, 20);
+            float t4 = time_ms([&] { hipLaunchKernelGGL(read_onewave<4>, dim3(B), dim3(64), lds_kb * 1024 + 700, 0, re, im, N4, o); }, 20);
+            const double r1 = 2.0 * B * (N4 / 64 * 64) * 16 / 1e9, r2 = 2.0 * B * (N4 / 128 * 128) * 16 / 1e9, r4 = 2.0 * B * (N4 / 256 * 256) * 16 / 1e9;
+            printf("one wave per block, %d KB LDS per wave: 1 KB per plane-step %.4f ms %.0f GB/s | 2 KB %.4f ms %.0f GB/s | 4 KB %.4f ms %.0f GB/s\n",
+                   lds_kb, t1, r1 / t1 * 1e3, t2, r2 / t2 * 1e3, t4, r4 / t4 * 1e3);
+        }
+    }
     for (int wgs : {2048, 4096, 8192, 16384}) {
         float tf = time_ms([&] { hipLaunchKernelGGL(read_flat, dim3(wgs), dim3(256), 0, 0, d, P * plane_f4, o); }, 20);
         printf("flat grid-stride read, %d workgroups: %.4f ms  %.0f GB/s\n", wgs, tf, gb / tf * 1e3);
