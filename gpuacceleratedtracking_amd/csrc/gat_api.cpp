@@ -55,6 +55,7 @@ struct gat_ctx {
     int one_wave = 1;                         // env GAT_DC_ONE_WAVE=0: never use one-wave workgroups
     long long one_wave_min = -1;              // env GAT_DC_ONE_WAVE_MIN: fewest (block, channel, tile) groups for them (default 32 per CU)
     int one_wave_seg = kOneWaveSegSteps;      // env GAT_DC_OW_SEG: steps per replica segment of a one-wave workgroup
+    int max_depth = 2;                        // env GAT_DC_DEPTH: cap of the sample prefetch depth (register sets per wave)
     int mc_mode = 1; // GAT_MC_* kernel selection (gat_set_matrix_core); env GAT_NO_MFMA=1 starts at 0
     std::string err;
     gat_launch_info last{};
@@ -320,6 +321,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             c->last.matrix_core = kind;
             c->last.channels_per_wg = kind == 2 ? m.nslots : nct * CT;
             c->last.blocks_per_wg = 1;
+            c->last.prefetch_depth = 0;
             return GAT_OK;
         }
     }
@@ -435,6 +437,9 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     cfg.aw = aw;
     cfg.kt = kt;
     cfg.nw = nw;
+    // Two register sets of samples (steps c+1 and c+2 in flight): the streaming regime of the four-antenna <= 3-tap tile
+    // only -- every byte read once (one channel group), a workgroup owns whole blocks (no split), >= 2 steps per block.
+    const bool deep_ok = c->max_depth >= 2 && vec == 4 && splits == 1 && KG == 1 && sig->chan_stride == 0 && chunks >= 2;
     cfg.vec = vec;
     cfg.format = fmt;
     cfg.grid = (unsigned)grid_wgs;
@@ -461,6 +466,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         for (int l = 0; l < cfg.taps; ++l) odd |= ((a.shifts[l] - a.shifts[0]) & 1) != 0;
         int seg = seg_max;
         if (nw == 1) { // the replica's LDS is sized for this launch: segment + tap span + one entry per producer lane
+            cfg.depth = 1;
             a.seg_steps = (int)std::min<long long>(seg, cps);
             const int one = dc_rep_copy_floats(a.seg_steps, (int)chunk, a.rep_span, 64);
             a.rep_copy_stride = odd ? one : 0;
@@ -470,7 +476,12 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             const int chan_floats = dc_rep_chan_floats((int)chunk, kt, MT);
             if (odd)
                 while (seg > 1 && 2 * dc_rep_copy_floats(seg, (int)chunk, a.rep_span) > chan_floats) --seg;
-            a.seg_steps = (int)std::min<long long>(seg, cps);
+            cfg.depth = 1;
+            if (deep_ok && seg >= 2 && dc_has_instance(MT, cfg.taps, vec, aw, kt, nw, 2)) {
+                cfg.depth = 2;
+                seg -= seg % 2; // whole groups of two steps per segment; the kernel pads the block's last group
+            }
+            a.seg_steps = (int)std::min<long long>(seg, (cps + cfg.depth - 1) / cfg.depth * cfg.depth);
             a.rep_copy_stride = odd ? dc_rep_copy_floats(a.seg_steps, (int)chunk, a.rep_span) : 0;
         }
         for (int l = 0; l < kMaxTapsPerLaunch; ++l) {
@@ -494,6 +505,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     c->last.finalize_launched = fin ? 1 : 0;
     c->last.channels_per_wg = kt;
     c->last.blocks_per_wg = (int32_t)bpw;
+    c->last.prefetch_depth = cfg.depth;
     return GAT_OK;
 }
 
@@ -574,6 +586,7 @@ GAT_API int32_t gat_create(int32_t device, void *hip_stream, gat_ctx **out_ctx)
     if (const char *e = std::getenv("GAT_DC_ONE_WAVE")) c->one_wave = std::atoi(e) != 0;
     if (const char *e = std::getenv("GAT_DC_ONE_WAVE_MIN")) c->one_wave_min = std::atoll(e);
     if (const char *e = std::getenv("GAT_DC_OW_SEG")) c->one_wave_seg = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("GAT_DC_DEPTH")) c->max_depth = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("GAT_MC_MODE")) c->mc_mode = (e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
         delete c;

@@ -190,7 +190,7 @@ struct SampleIO {
 // (measured in both rounds: 1.2-3x slower).
 constexpr int dc_min_waves(int mt, int l, int kt) { return 2 * mt * l * kt <= 40 ? 3 : 1; }
 
-template <int MT, int L, int VEC, int FMT, int AW, int KT, bool KEEP, int NW>
+template <int MT, int L, int VEC, int FMT, int AW, int KT, bool KEEP, int NW, int D>
 __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(const DcArgs a)
 {
     // NW = 4 waves per workgroup, or 1: short blocks in a long stream (a few steps per block) spend their time in the
@@ -261,10 +261,19 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
     // of the ragged last chunk that lie beyond the block read zeros (buffer range check, no memory traffic).
     // VEC == 1 (unaligned input): everything takes the per-sample path.
     const int c_full = VEC == 4 ? c_end : c_begin;
+    // D register sets of samples: set d holds the steps d, d + D, ... of a block; while a step is consumed the following
+    // D - 1 are in flight, and a set is refilled with step + D as soon as it is done (D = 2: the host picks it for the
+    // streaming regime of the configs[1] family only, dc_depth_max).  The step loop runs whole groups of D steps in a
+    // fixed order -- the compiler's count of outstanding loads at every wait is then exact (with a conditional last step it
+    // assumes the worst order and waits for the newest loads too, which takes the depth away again); a step past the end
+    // of the block reads zeros (range check) against a replica that exists there as well (the host uses D = 2 only when a
+    // workgroup owns whole blocks: no other workgroup reads those samples).
+    static_assert(D == 1 || (D == 2 && VEC == 4), "prefetch depth");
+    const int c_stop = VEC == 4 ? c_begin + (c_end - c_begin + D - 1) / D * D : c_begin;
     int staged_prn[KT];
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk) staged_prn[kk] = -1;
-    i32x4 raw[G][MT][IO::NV]; // the samples of the step being consumed / in flight for the next one
+    i32x4 raw[D][G][MT][IO::NV]; // the samples of the step being consumed / in flight for the following ones
     bool preloaded = false;   // the previous block's last step has already fetched this block's first chunk
 
     for (int bb = 0; bb < a.blocks_per_wg; ++bb) {
@@ -540,15 +549,23 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
         if (c_begin < c_full && !preloaded) {
             const __amdgpu_buffer_rsrc_t rr = plane_rsrc(p_re), ri = plane_rsrc(p_im);
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const unsigned off = lane_offset((unsigned)(c_begin * CHUNK + g * GSTRIDE + rel0) * EB);
+            for (int d = 0; d < D; ++d)
 #pragma unroll
-                for (int m = 0; m < MT; ++m) load_ant(raw[g][m], m, rr, ri, off);
-            }
+                for (int g = 0; g < G; ++g) {
+                    const unsigned off = lane_offset((unsigned)((c_begin + d) * CHUNK + g * GSTRIDE + rel0) * EB);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        load_ant(raw[d][g][m], m, rr, ri, off);
+                        // the order of the step loop's refills: the scheduler would group the preload by plane, and the
+                        // compiler's wait counts at the loop head are exact only if both orders agree
+                        if constexpr (D > 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
         }
         preloaded = next_block;
-        for (int c0 = c_begin; c0 < c_end; c0 += SEG) {
-            const int c1 = min(c0 + SEG, c_end);
+        const int c_last = VEC == 4 ? c_stop : c_end;
+        for (int c0 = c_begin; c0 < c_last; c0 += SEG) {
+            const int c1 = min(c0 + SEG, c_last);
 #if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 8))
             if (c0 > c_begin) __syncthreads(); // everybody has finished reading the previous segment's replica
 #endif
@@ -569,16 +586,18 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
             // the registers that antenna's samples of step c have just left (loads in flight all the time, no second
             // register set).  The prefetch is unconditional -- a conditional one makes the compiler copy the whole
             // register array around the branch; after the last whole chunk every lane re-loads the block's first bytes.
-            const int cf = min(c1, c_full);
-            for (int c = c0; c < cf; ++c) {
+            const int cf = VEC == 4 ? c1 : c_begin; // c1 <= c_stop: a multiple of D steps from c0 (SEG is one: host)
+            // one step: the samples of chunk c sit in register set DI, which is refilled with chunk c + D
+            auto step = [&](auto di, int c) {
+                constexpr int DI = decltype(di)::value;
                 const int srel = (c - c0) * CHUNK; // position of the step inside the segment
-                // next: the following chunk; after the last chunk the first chunk of the next block this workgroup walks;
-                // else an offset beyond the block: the loads return zeros without touching memory
-                const bool more = c + 1 < c_full;
+                // refill: chunk c + D of this block; past its end chunk DI of the next block this workgroup walks (the last
+                // D steps of a block cover every set once); else an offset beyond the block: zeros, no memory traffic
+                const bool more = c + D < c_stop;
                 const bool hop = !more && next_block; // wave-uniform
                 const char *const n_re = hop ? p_re + blk_bytes : p_re, *const n_im = hop ? p_im + blk_bytes : p_im;
-                const unsigned next_off = more ? (unsigned)((c + 1) * CHUNK + rel0) * EB
-                                          : (hop ? (unsigned)(c_begin * CHUNK + rel0) * EB : (unsigned)blk_len);
+                const unsigned next_off = more ? (unsigned)((c + D) * CHUNK + rel0) * EB
+                                          : (hop ? (unsigned)((c_begin + DI) * CHUNK + rel0) * EB : (unsigned)blk_len);
                 const unsigned next_g = more || hop ? (unsigned)(GSTRIDE * EB) : 0u;
                 const __amdgpu_buffer_rsrc_t n_rr = plane_rsrc(n_re), n_ri = plane_rsrc(n_im);
                 unsigned n_off[G];
@@ -595,9 +614,9 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
                         get_chips_group(chip, rel, s_rep);
 #pragma unroll
                         for (int m = 0; m < MT; ++m) {
-                            accumulate_group(acc[0][m], raw[g][m], pr, pi, chip);
+                            accumulate_group(acc[0][m], raw[DI][g][m], pr, pi, chip);
 #if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 16))
-                            load_ant(raw[g][m], m, n_rr, n_ri, n_off[g]);
+                            load_ant(raw[DI][g][m], m, n_rr, n_ri, n_off[g]);
 #endif
                             // antenna by antenna: left alone the scheduler wipes off all antennas first (their
                             // products and the refilled sample registers are then live together: + 30 registers)
@@ -634,12 +653,12 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
 #pragma unroll
                                 for (int j = 0; j < S; ++j) {
                                     float xr, xi;
-                                    IO::get(raw[g][m], j, xr, xi);
+                                    IO::get(raw[DI][g][m], j, xr, xi);
                                     accumulate(acc[kk][m], xr, xi, pr[kk][j], pi[kk][j], chip[kk][j]);
                                 }
                             }
 #if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 16))
-                            load_ant(raw[g][m], m, n_rr, n_ri, n_off[g]);
+                            load_ant(raw[DI][g][m], m, n_rr, n_ri, n_off[g]);
 #endif
 #if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 32))
                             __builtin_amdgcn_sched_barrier(0);
@@ -653,6 +672,10 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
                         }
                     }
                 }
+            };
+            for (int c = c0; c < cf; c += D) {
+                step(std::integral_constant<int, 0>{}, c);
+                if constexpr (D > 1) step(std::integral_constant<int, 1>{}, c + 1);
             }
             // ---- unaligned input (VEC == 1): one sample at a time with scalar loads -----------------------------------
             if constexpr (VEC != 4) {
@@ -724,8 +747,9 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
 // ------------------------------------------------------------------------------------------------------------
 // Which instances exist.  Register accumulators 2 * MT * L * KT <= 64; antenna-parallel waves (AW > 1) need full
 // 4-antenna tiles; unaligned input (VEC == 1, scalar loads) is served one antenna per workgroup.
-constexpr bool dc_instance(int mt, int l, int vec, int aw, int kt, int nw = 4)
+constexpr bool dc_instance(int mt, int l, int vec, int aw, int kt, int nw = 4, int depth = 1)
 {
+    if (depth != 1 && !(vec == 4 && depth == dc_depth_max(mt, l, aw, kt, nw))) return false;
     // one-wave workgroups: short blocks of one- and two-antenna tiles
     if (nw != 4 && !(nw == 1 && vec == 4 && aw == 1 && kt == 1 && mt <= 2)) return false;
 #ifdef GAT_DC_DEV // development builds: only the instances the BASELINE shapes use (compiles in seconds)
@@ -744,10 +768,18 @@ template <int FMT, int MT, int L, int VEC, int AW, int KT, int NW>
 static hipError_t launch_dc_nw(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
 {
     if constexpr (dc_instance(MT, L, VEC, AW, KT, NW)) {
+        if constexpr (dc_instance(MT, L, VEC, AW, KT, NW, 2)) { // two sample sets: streaming regime only (non-temporal loads)
+            if (cfg.depth == 2) {
+                if (a.keep_l2) return hipErrorInvalidValue;
+                hipLaunchKernelGGL((dc_kernel<MT, L, VEC, FMT, AW, KT, false, NW, 2>), dim3(cfg.grid), dim3(64 * NW), cfg.lds_bytes, s, a);
+                return hipGetLastError();
+            }
+        }
+        if (cfg.depth != 1) return hipErrorInvalidValue;
         if (VEC == 4 && a.keep_l2)
-            hipLaunchKernelGGL((dc_kernel<MT, L, VEC, FMT, AW, KT, VEC == 4, NW>), dim3(cfg.grid), dim3(64 * NW), cfg.lds_bytes, s, a);
+            hipLaunchKernelGGL((dc_kernel<MT, L, VEC, FMT, AW, KT, VEC == 4, NW, 1>), dim3(cfg.grid), dim3(64 * NW), cfg.lds_bytes, s, a);
         else
-            hipLaunchKernelGGL((dc_kernel<MT, L, VEC, FMT, AW, KT, false, NW>), dim3(cfg.grid), dim3(64 * NW), cfg.lds_bytes, s, a);
+            hipLaunchKernelGGL((dc_kernel<MT, L, VEC, FMT, AW, KT, false, NW, 1>), dim3(cfg.grid), dim3(64 * NW), cfg.lds_bytes, s, a);
         return hipGetLastError();
     } else {
         return hipErrorInvalidValue;

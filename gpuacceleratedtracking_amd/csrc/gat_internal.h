@@ -67,6 +67,7 @@ struct DcLaunch {
     int aw;       // antenna tiles (waves) per workgroup: 1, 2, 4
     int kt;       // channels per workgroup: 1, 2, 4
     int nw;       // waves per workgroup: 4, or 1 (short blocks: one wave per block, no workgroup barrier to wait at)
+    int depth;    // register sets of samples per wave (steps in flight): 1, or 2 (dc_depth_max)
     int taps;     // L of this launch
     int vec;      // 4 or 1
     int format;   // GAT_LAYOUT_*
@@ -105,9 +106,13 @@ constexpr size_t dc_lds_bytes(int kt, int mt, int code_row_stride, int chunk)
            (size_t)kt * code_row_stride;
 }
 // does an instance of dc_kernel exist for this combination (gat_dc.h: dc_instance)
-bool dc_has_instance(int ant_tile, int taps, int vec, int aw, int kt, int nw = 4);
+bool dc_has_instance(int ant_tile, int taps, int vec, int aw, int kt, int nw = 4, int depth = 1);
 // one-wave workgroups: steps per segment and LDS bytes (replica sized for the launch's own tap span)
 constexpr int kOneWaveSegSteps = 4;
+// Deepest sample prefetch an instance family is built with.  Two register sets (steps c+1 and c+2 in flight) exist for
+// the four-antenna, <= 3-tap, one-channel tile only -- the configs[1] family, streaming every byte once at the HBM rate:
+// measured + 1.3 % there on fast and slow boxes alike; every other family measured no gain or a loss.
+constexpr int dc_depth_max(int mt, int l, int aw, int kt, int nw) { return nw == 4 && aw == 1 && kt == 1 && mt == 4 && l <= 3 ? 2 : 1; }
 constexpr size_t dc_lds_bytes_one_wave(int rep_chan_floats, int code_row_stride)
 {
     return 32 + 64 * sizeof(float) + (size_t)rep_chan_floats * sizeof(float) + (size_t)code_row_stride;

@@ -316,6 +316,7 @@ typedef struct gat_launch_info {
     int32_t matrix_core; /* 0: the vector kernel ran, 1: the f32-MFMA kernel, 2: the split-bf16 MFMA kernel */
     int32_t channels_per_wg; /* channels one workgroup loops over (signal held in registers / LDS meanwhile)  */
     int32_t blocks_per_wg;   /* consecutive integration blocks one workgroup loops over                       */
+    int32_t prefetch_depth;  /* vector kernel: register sets of samples per wave (steps in flight); else 0      */
 } gat_launch_info;
 GAT_API int32_t gat_last_launch_info(const gat_ctx *ctx, gat_launch_info *out);
 

@@ -233,3 +233,67 @@ def test_antenna_tile_whose_span_exceeds_a_descriptor(gat, vector_ctx):
     check_close(got, oracle_result(case), what=f"wide antenna stride {info}")
     del re, im
     torch.cuda.empty_cache()
+
+
+DEEP_SHAPES = [
+    # system, N, M, L, K, B -- four antennas, <= 3 taps, one channel, no split: two register sets of samples per wave
+    ("GPSL1", 20000, 4, 3, 1, 2100),   # configs[1] itself in a stream long enough not to be split (20 steps per block)
+    ("GPSL1", 3000, 4, 3, 1, 7),       # 3 steps: the block's last group of two is padded with a zero step
+    ("GPSL1", 2048, 4, 2, 1, 5),       # exactly 2 steps, 2 taps
+    ("GPSL1", 4096, 4, 1, 1, 3),       # 4 steps, one tap
+    ("GPSL1", 3000, 4, 3, 1, 9000),    # short blocks in a long stream: several blocks per workgroup, prefetch across blocks
+    ("GPSL1", 1028, 4, 3, 1, 4),       # 2 steps, the second one nearly empty
+]
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2, 3], ids=["planar", "interleaved", "i16", "i8"])
+@pytest.mark.parametrize("shape", DEEP_SHAPES, ids=[f"N{s[1]}-L{s[3]}-B{s[5]}" for s in DEEP_SHAPES])
+def test_two_sample_sets_match_the_oracle_and_one_set(gat, shape, layout, monkeypatch):
+    """The streaming regime of the four-antenna tile keeps two steps of samples in flight (gat_dc.h, D = 2): against
+    the oracle (first and last blocks of long streams) and against the same launch with one set (GAT_DC_DEPTH=1, read
+    when a context is created): same chips, same order of summation -> bit-identical."""
+    import torch
+    system, N, M, L, K, B = shape
+    if layout == 3 and N % 8:
+        pytest.skip("int8 groups hold 8 samples")
+    big = B > 100
+    rng = np.random.default_rng(zlib.crc32(repr(shape).encode()))
+    case = make_case(zlib.crc32(repr(shape).encode()), system=system, N=N, M=M, L=L, K=K, B=min(B, 6))
+    if layout >= 2:
+        s = 100.0 if layout == 2 else 20.0
+        case["re"] = np.rint(case["re"] * s).astype(np.float32)
+        case["im"] = np.rint(case["im"] * s).astype(np.float32)
+    nb = case["B"]
+    if big:  # tile the small case's blocks over the long stream (parameters repeat with them)
+        reps = (B + nb - 1) // nb
+        for key in ("re", "im"):
+            case[key] = np.tile(case[key].reshape(M, nb, N), (1, reps, 1))[:, :B].reshape(M, B * N)
+        case["prm"] = np.tile(case["prm"], (reps, 1))[:B]
+        case["B"] = B
+    outs = []
+    for depth in ("2", "1"):
+        monkeypatch.setenv("GAT_DC_DEPTH", depth)
+        ctx = gat.Context(torch.cuda.current_device())
+        try:
+            ctx.set_matrix_core(gat.GAT_MC_VECTOR)
+            got, info = run_case(gat, ctx, case, layout=layout)
+            steps = -(-N // (2048 if layout == 3 else 1024))  # a block of one step has nothing to prefetch
+            assert info["prefetch_depth"] == (int(depth) if steps >= 2 else 1) and info["splits"] == 1, info
+            if big:
+                assert info["blocks_per_wg"] > 1 or N >= 20000, info
+            outs.append(got)
+        finally:
+            ctx.close()
+    assert np.array_equal(outs[0], outs[1])
+    small = dict(case)
+    if big:  # oracle on the first blocks and the last ones
+        for sel in (slice(0, nb), slice(B - nb, B)):
+            sub = dict(case)
+            sub["B"] = nb
+            idx = np.arange(B)[sel]
+            sub["re"] = case["re"].reshape(M, B, N)[:, idx].reshape(M, nb * N)
+            sub["im"] = case["im"].reshape(M, B, N)[:, idx].reshape(M, nb * N)
+            sub["prm"] = case["prm"][idx]
+            check_close(outs[0][sel], oracle_result(sub), what=f"{shape} layout {layout} blocks {sel}")
+    else:
+        check_close(outs[0], oracle_result(small), what=f"{shape} layout {layout}")
