@@ -768,7 +768,8 @@ template <int FMT, int MT, int L, int VEC, int AW, int KT, int NW>
 static hipError_t launch_dc_nw(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
 {
     if constexpr (dc_instance(MT, L, VEC, AW, KT, NW)) {
-        if constexpr (dc_instance(MT, L, VEC, AW, KT, NW, 2)) { // two sample sets: streaming regime only (non-temporal loads)
+        // two sample sets: streaming regime of float samples only (non-temporal loads)
+        if constexpr (dc_instance(MT, L, VEC, AW, KT, NW, 2) && (FMT == GAT_LAYOUT_PLANAR || FMT == GAT_LAYOUT_INTERLEAVED)) {
             if (cfg.depth == 2) {
                 if (a.keep_l2) return hipErrorInvalidValue;
                 hipLaunchKernelGGL((dc_kernel<MT, L, VEC, FMT, AW, KT, false, NW, 2>), dim3(cfg.grid), dim3(64 * NW), cfg.lds_bytes, s, a);

@@ -278,7 +278,8 @@ def test_two_sample_sets_match_the_oracle_and_one_set(gat, shape, layout, monkey
             ctx.set_matrix_core(gat.GAT_MC_VECTOR)
             got, info = run_case(gat, ctx, case, layout=layout)
             steps = -(-N // (2048 if layout == 3 else 1024))  # a block of one step has nothing to prefetch
-            assert info["prefetch_depth"] == (int(depth) if steps >= 2 else 1) and info["splits"] == 1, info
+            want = int(depth) if steps >= 2 and layout <= 1 else 1  # float samples only (the planner's rule)
+            assert info["prefetch_depth"] == want and info["splits"] == 1, info
             if big:
                 assert info["blocks_per_wg"] > 1 or N >= 20000, info
             outs.append(got)
