@@ -2,7 +2,7 @@
 """profiles/pmc_traffic.json from the summary of scripts/r02_profile_configs.sh (the `<tag>_fetch {...}` / `<tag>_write {...}`
 lines): HBM bytes per launch = 2 * FETCH_SIZE KB (gfx950 correction of MI355X_MICROARCH.md for 16-B/lane streaming reads)
 + WRITE_SIZE KB, against bench.py's algorithmic bytes of the same workload.
-usage: scripts/make_pmc_traffic.py profiles/r02/r02k_final_rocprofv3_and_pmc_summary.txt"""
+usage: scripts/make_pmc_traffic.py profiles/r02/r02r_final_rocprofv3_and_pmc_summary.txt"""
 import ast
 import json
 import re
