@@ -88,8 +88,9 @@ def parse_args(argv=None):
     if args.baseline_config is not None:
         for k, v in PRESETS[args.baseline_config].items():
             setattr(args, k, v)
-        if args.baseline_config != 1:  # long launches: fewer timed steps keep the run short
-            args.steps, args.warmup, args.settle = min(args.steps, 20), min(args.warmup, 3), min(args.settle, 4)
+        # (round 3: the presets used to cut settle / warm-up / steps to 4 / 3 / 20 "to keep the run short"; that measured the
+        # first 18 ms after an idle device -- 0.667 ms per launch at the configs[3] shard where the steady state, from ~100
+        # launches on, is 0.58 ms: profiles/r03/r03c_power_probe.txt.  All shapes now get the default settle + warm-up.)
     return args
 
 
@@ -177,10 +178,20 @@ def cpu_baseline(args, host_re, host_im, prm, shifts, fs, system):
         rates[t] = n * N * args.channels / dt / 1e6
     used = max(rates, key=rates.get)
     best, rate_1t = rates[used], rates[1]
+    # one thread, per pass (code replica / carrier replica / downconvert / correlate): where the 4-pass structure spends
+    # its time on this host, in microseconds per (block, channel)
+    nprof = min(64, max_blk)
+    oracle.dc_f32_profile(host_re[:, :nprof * N], host_im[:, :nprof * N], codes, oprm[:nprof], fs, shifts, N=N, native=True)
+    _, secs = oracle.dc_f32_profile(host_re[:, :nprof * N], host_im[:, :nprof * N], codes, oprm[:nprof], fs, shifts, N=N,
+                                    native=True)
+    per_pass = {k: round(float(v) / (nprof * args.channels) * 1e6, 3)
+                for k, v in zip(("code_replica", "carrier_replica", "downconvert", "correlate"), secs)}
     return {
         "value": round(best, 3), "unit": "Msamples/s", "cores": used, "kind": "port",
         "sample": f"first {max_blk} of {args.blocks} blocks of the same stream, repeated for {args.cpu_seconds / len(cands):.1f} s per thread count "
-                  f"(N={N}, M={M}, L={args.num_taps}, K={args.channels}); oracle FP32 4-pass, gcc -O3 -march=native, OpenMP",
+                  f"(N={N}, M={M}, L={args.num_taps}, K={args.channels}); oracle FP32 4-pass (integer code / carrier NCOs, "
+                  f"all four passes vectorised), gcc -O3 -march=native, OpenMP over (block, channel)",
+        "per_pass_us": per_pass,
         "value_1_thread": round(rate_1t, 3), "by_threads": {str(k): round(v, 3) for k, v in rates.items()},
         "host_threads": cores, "cpu_model": cpu_model(),
     }

@@ -51,7 +51,7 @@ struct gat_ctx {
     unsigned long long *dbg_ptr = nullptr; // diagnostic builds only
     int max_ant_tile = kMaxAntTile; // env GAT_MAX_ANT_TILE (experiments)
     int max_aw = 4, max_kt = 4, max_bpw = 16; // env GAT_DC_AW / GAT_DC_KT / GAT_DC_BPW: caps of the vector kernel's geometry
-    int wgs_per_cu = 8;                       // env GAT_DC_WGS_PER_CU: workgroups per CU the split planner aims for
+    int wgs_per_cu = 0;                       // env GAT_DC_WGS_PER_CU: workgroups per CU the split planner aims for (0: by instance)
     int one_wave = 1;                         // env GAT_DC_ONE_WAVE=0: never use one-wave workgroups
     long long one_wave_min = -1;              // env GAT_DC_ONE_WAVE_MIN: fewest (block, channel, tile) groups for them (default 32 per CU)
     int one_wave_seg = kOneWaveSegSteps;      // env GAT_DC_OW_SEG: steps per replica segment of a one-wave workgroup
@@ -70,6 +70,8 @@ constexpr size_t kMaxLoopGraphs = 4;
 // kernel-selection knobs).
 void drop_loop_graphs(gat_ctx *c)
 {
+    // gat_tracking_run(GAT_FLAG_GRAPH) is asynchronous: a recorded graph may still be executing on the stream
+    if (!c->loop_graphs.empty()) (void)hipStreamSynchronize(c->stream);
     for (auto &g : c->loop_graphs)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     c->loop_graphs.clear();
@@ -96,6 +98,13 @@ int32_t hipfail(gat_ctx *c, hipError_t e, const char *where)
     } while (0)
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// host mirror of the kernels' code_span_bad (gat_phase.h): what passes here is not poisoned there
+bool code_span_ok(double ratio, double tau, double reach, int Lc)
+{
+    const double span = std::fabs(tau) + std::fabs(ratio) * reach + 1.0;
+    return span < 1073741824.0 && (Lc <= 0 || span < 2097152.0 * (double)Lc) && ratio >= 0.0;
+}
 
 int32_t ensure_partial(gat_ctx *c, size_t bytes)
 {
@@ -371,7 +380,11 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         nw = 1;
     const long long chunk = dc_chunk(vec, fmt, aw, nw);
     const long long chunks = (N + chunk - 1) / chunk;
-    const long long target = (long long)c->wgs_per_cu * c->num_cus * (nw == 1 ? 4 : 1);
+    // Workgroups per CU the split aims for: 8 -- except for the channel-looping instances (KT >= 2: 170-250 registers,
+    // two workgroups resident per CU), where a finer split only adds partial sums, a second launch and workgroup starts
+    // (configs[3] shard, 512 tiles: 2 / 4 / 8 per CU = 0.667 / 0.675 / 0.687 ms, profiles/r03/r03a_c4_split.txt).
+    const int per_cu = c->wgs_per_cu > 0 ? c->wgs_per_cu : (kt >= 2 ? 2 : 8);
+    const long long target = (long long)per_cu * c->num_cus * (nw == 1 ? 4 : 1);
     long long splits = std::max<long long>(1, (target + groups - 1) / groups);
     splits = std::min(splits, chunks);
     // tiny blocks (latency regime): a second launch costs more than a few serial steps
@@ -750,9 +763,7 @@ GAT_API int32_t gat_downconvert_and_correlate(gat_ctx *c, const gat_signal_desc 
         if (p.code_freq_hz < 0.0) return fail(c, GAT_ERR_RANGE, "negative code frequency");
         if (std::fabs(p.carrier_freq_hz / fs) >= 1.0e15 || std::fabs(p.carrier_phase_cycles) >= 1.0e15)
             return fail(c, GAT_ERR_RANGE, "carrier frequency / phase out of range");
-        const double span = std::fabs(p.code_phase_chips) +
-                            std::fabs(p.code_freq_hz / fs) * (double)(sig->num_samples + max_shift) + 1.0;
-        if (span >= 1073741824.0 || (c->Lc > 0 && span / c->Lc >= 2097152.0))
+        if (!code_span_ok(p.code_freq_hz / fs, p.code_phase_chips, (double)(sig->num_samples + max_shift), c->Lc))
             return fail(c, GAT_ERR_RANGE, "code phase span too large");
     }
     if (n > c->params_cap) {
@@ -779,6 +790,8 @@ static int32_t gen_code_replica_impl(gat_ctx *c, float *rep, int64_t count, int3
     if (prn < 0 || prn >= c->P) return fail(c, GAT_ERR_RANGE, "prn outside the code table");
     if (!(fs > 0.0) || !std::isfinite(fc) || !std::isfinite(tau)) return fail(c, GAT_ERR_ARG, "bad frequency / phase");
     if (count + std::llabs((long long)first_shift) >= (1ll << 30)) return fail(c, GAT_ERR_RANGE, "replica too long");
+    if (!f32_coordinates && !code_span_ok(fc / fs, tau, (double)count + (double)std::llabs((long long)first_shift), c->Lc))
+        return fail(c, GAT_ERR_RANGE, "code phase span too large");
     GAT_HIP(c, hipSetDevice(c->device));
     GAT_HIP(c, launch_gen_code_replica(rep, count, c->d_codes + (size_t)prn * c->code_row_stride, c->Lc, fc, fs, tau,
                                        first_shift, f32_coordinates, c->stream));
@@ -823,6 +836,11 @@ GAT_API int32_t gat_downconvert_and_accumulate(gat_ctx *c, const gat_signal_desc
     if (!(fs > 0.0) || !std::isfinite(p->code_freq_hz) || !(p->code_freq_hz >= 0.0) || !std::isfinite(p->carrier_freq_hz) ||
         !std::isfinite(p->code_phase_chips) || !std::isfinite(p->carrier_phase_cycles))
         return fail(c, GAT_ERR_ARG, "bad frequency / phase");
+    long long max_shift = 0;
+    for (int l = 0; l < L; ++l) max_shift = std::max<long long>(max_shift, std::llabs((long long)shifts[l]));
+    if (sig->num_samples + max_shift >= (1ll << 30)) return fail(c, GAT_ERR_RANGE, "num_samples + |shift| must stay below 2^30");
+    if (!code_span_ok(p->code_freq_hz / fs, p->code_phase_chips, (double)(sig->num_samples + max_shift), c->Lc))
+        return fail(c, GAT_ERR_RANGE, "code phase span too large");
     GAT_HIP(c, hipSetDevice(c->device));
     // the tap list goes through the library's parameter scratch (device memory the kernel can read)
     const size_t need = ((size_t)L * sizeof(int32_t) + sizeof(gat_channel_params) - 1) / sizeof(gat_channel_params);
@@ -960,7 +978,10 @@ GAT_API int32_t gat_tracking_run(gat_ctx *c, const gat_signal_desc *sig, int32_t
             size_t lru = 0;
             for (size_t i = 1; i < c->loop_graphs.size(); ++i)
                 if (c->loop_graphs[i].last_use < c->loop_graphs[lru].last_use) lru = i;
-            if (c->loop_graphs[lru].exec) (void)hipGraphExecDestroy(c->loop_graphs[lru].exec);
+            if (c->loop_graphs[lru].exec) {
+                (void)hipStreamSynchronize(c->stream); // its last replay may still be running
+                (void)hipGraphExecDestroy(c->loop_graphs[lru].exec);
+            }
             c->loop_graphs.erase(c->loop_graphs.begin() + (long)lru);
         }
         gat_ctx::LoopGraph g;

@@ -301,9 +301,8 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
             // Parameters this kernel cannot evaluate exactly poison the output with NaN (fail loudly):
             // prn outside the table, or a code-phase span beyond the int32 / float-reciprocal modulo range
             // (the host entry point rejects these up front; device-resident parameters are checked here).
-            const double span = __builtin_fabs(tau) + __builtin_fabs(ratio) * (double)(N + a.max_abs_shift) + 1.0;
-            const bool bad = P.prn < 0 || P.prn >= a.num_prns || !(span < 1073741824.0) ||
-                             !(span < 2097152.0 * (double)Lc) || !(ratio >= 0.0) || !(step == step) || !(phi == phi) ||
+            const bool bad = P.prn < 0 || P.prn >= a.num_prns || code_span_bad(ratio, tau, (double)(N + a.max_abs_shift), Lc) ||
+                             !(step == step) || !(phi == phi) ||
                              !(__builtin_fabs(step) < 1.0e15) || !(__builtin_fabs(phi) < 1.0e15);
             if (bad) ratio = 0.0, tau = 0.0, step = 0.0, phi = 0.0; // tame values; the output is poisoned below
             if (valid) valid_mask |= 1u << kk;

@@ -11,6 +11,7 @@ namespace gat {
 constexpr int kThreads = 256;       // 4 wave64 per workgroup
 constexpr int kMaxTapsPerLaunch = 8; // taps handled by one launch (register accumulators)
 constexpr int kMaxAntTile = 4;       // antennas handled by one workgroup
+constexpr int kFinalizeFewSplits = 32; // second stage: up to this many splits are summed by one thread per output element
 constexpr int kMaxReplicaSpan = 512;  // largest tap span served from the LDS replica segment of one launch (wider tap
                                       // lists are cut into several launches)
 

@@ -28,6 +28,35 @@ finalize_kernel(const float *__restrict__ partial, float *__restrict__ out_re,
     }
 }
 
+// Few splits (what the fused kernels leave behind: 2-16 per group): one THREAD per output element, its splits summed
+// in a fixed order (four interleaved chains, then ((0+1)+(2+3)): deterministic).  Consecutive threads read consecutive
+// floats of one split row, so every load instruction of a wave is one 256-byte line -- the wave-per-element kernel
+// above keeps splits of its 64 lanes busy (4 of 64 at the 16-antenna shard of BASELINE configs[3]: 196 608 waves for
+// 3 MB of partials, 40 us of a 0.72 ms step).
+__global__ void __launch_bounds__(kThreads)
+finalize_few_kernel(const float *__restrict__ partial, float *__restrict__ out_re,
+                    float *__restrict__ out_im, int splits, int elems, long long total)
+{
+    const long long o = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (o >= total) return;
+    const long long g = o / elems;
+    const int e = (int)(o - g * elems);
+    const float *p = partial + (size_t)g * splits * elems + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = 0;
+    for (; i + 4 <= splits; i += 4) {
+        s0 += p[(size_t)(i + 0) * elems];
+        s1 += p[(size_t)(i + 1) * elems];
+        s2 += p[(size_t)(i + 2) * elems];
+        s3 += p[(size_t)(i + 3) * elems];
+    }
+    if (i < splits) s0 += p[(size_t)i * elems];
+    if (i + 1 < splits) s1 += p[(size_t)(i + 1) * elems];
+    if (i + 2 < splits) s2 += p[(size_t)(i + 2) * elems];
+    float *out = (e & 1) ? out_im : out_re;
+    out[(size_t)g * (elems / 2) + (e >> 1)] = (s0 + s1) + (s2 + s3);
+}
+
 // ------------------------------------------------------------------------------------------
 // stand-alone operators
 // ------------------------------------------------------------------------------------------
@@ -72,9 +101,10 @@ code_replica_multi_kernel(float *__restrict__ rep, long long count, long long ro
     const int k = blockIdx.y;
     if (k >= K) return;
     const gat_channel_params P = params[k];
-    const bool bad = P.prn < 0 || P.prn >= num_prns;
-    const int8_t *code = codes + (size_t)(bad ? 0 : P.prn) * code_row_stride;
     const double ratio = P.code_freq_hz / fs;
+    const double reach = (double)count + (double)(first_shift < 0 ? -first_shift : first_shift);
+    const bool bad = P.prn < 0 || P.prn >= num_prns || code_span_bad(ratio, P.code_phase_chips, reach, Lc);
+    const int8_t *code = codes + (size_t)(P.prn < 0 || P.prn >= num_prns ? 0 : P.prn) * code_row_stride;
     const float inv_lc = 1.0f / (float)Lc;
     float *row = rep + (size_t)k * row_stride;
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < count; i += (long long)gridDim.x * kThreads)
@@ -96,6 +126,11 @@ accumulate_debug_kernel(const float *__restrict__ sig_re, const float *__restric
 {
     const double ratio = P.code_freq_hz / fs, step = P.carrier_freq_hz / fs;
     const float inv_lc = 1.0f / (float)Lc;
+    // the host validated the code-phase span (gat_downconvert_and_accumulate); a caller that bypasses it gets NaN
+    // products instead of a chip index outside the table
+    int max_shift = 0;
+    for (int l = 0; l < L; ++l) max_shift = max(max_shift, abs(shifts[l]));
+    const bool bad = code_span_bad(ratio, P.code_phase_chips, (double)N + (double)max_shift, Lc);
     for (long long n = (long long)blockIdx.x * kThreads + threadIdx.x; n < N; n += (long long)gridDim.x * kThreads) {
         float cr, ci;
         const double th = __builtin_fma((double)n, step, P.carrier_phase_cycles);
@@ -108,7 +143,8 @@ accumulate_debug_kernel(const float *__restrict__ sig_re, const float *__restric
             if (dw_re) dw_re[(size_t)m * N + n] = dr;
             if (dw_im) dw_im[(size_t)m * N + n] = di;
             for (int l = 0; l < L; ++l) {
-                const float chip = (float)code[chip_index(ratio, P.code_phase_chips, (int)n + shifts[l], Lc, inv_lc)];
+                const float chip = bad ? __builtin_nanf("")
+                                       : (float)code[chip_index(ratio, P.code_phase_chips, (int)n + shifts[l], Lc, inv_lc)];
                 if (acc_re) acc_re[((size_t)l * M + m) * N + n] = chip * dr;
                 if (acc_im) acc_im[((size_t)l * M + m) * N + n] = chip * di;
             }
@@ -303,6 +339,11 @@ hipError_t launch_finalize(const float *partial, float *out_re, float *out_im, i
                            long long groups, hipStream_t s)
 {
     const long long waves = groups * elems;
+    if (splits <= kFinalizeFewSplits) { // one thread per output element
+        hipLaunchKernelGGL(finalize_few_kernel, dim3((unsigned)((waves + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
+                           partial, out_re, out_im, splits, elems, waves);
+        return hipGetLastError();
+    }
     const unsigned grid = (unsigned)((waves + kThreads / 64 - 1) / (kThreads / 64));
     hipLaunchKernelGGL(finalize_kernel, dim3(grid), dim3(kThreads), 0, s, partial, out_re, out_im,
                        splits, elems, groups);

@@ -45,6 +45,15 @@ __device__ __forceinline__ int floormod_fast(int ip, int Lc, float inv_lc)
     return r;
 }
 
+// Parameters floormod_fast / chip_index cannot evaluate exactly: `reach` = the largest |sample + shift| of the call.  The
+// correlator kernels, the stand-alone replica and the materialising debug kernel all use this ONE predicate (they write
+// NaN instead of indexing outside the chip table); the host entry points with host-resident parameters reject the same set.
+__device__ __forceinline__ bool code_span_bad(double ratio, double tau, double reach, int Lc)
+{
+    const double span = __builtin_fabs(tau) + __builtin_fabs(ratio) * reach + 1.0;
+    return !(span < 1073741824.0) || !(span < 2097152.0 * (double)Lc) || !(ratio >= 0.0);
+}
+
 // The reference's code phase of sample x = n + shift, src/algorithms.jl:179: one double multiply and one double
 // add, NOT fused (bit-identical to the CPU oracle).
 __device__ __forceinline__ double code_phase(double ratio, double tau, int x)

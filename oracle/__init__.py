@@ -99,6 +99,8 @@ def _bind(l):
                                                    C.c_int64, C.c_int, C.c_int, C.c_int, i8p,
                                                    C.c_int, pp, C.c_double, C.c_int, i32p, dp, dp]
     l.gat_oracle_reduce_cplx_multi.argtypes = [fp, fp, C.c_int64, C.c_int, dp, dp]
+    l.gat_oracle_dc_f32_profile.argtypes = [fp, fp, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, i8p,
+                                            C.c_int, pp, C.c_double, C.c_int, i32p, fp, fp, dp]
     return l
 
 
@@ -218,6 +220,33 @@ def dc_f32(re, im, codes_tbl, params, fs, shifts, N=None, blk_stride=None, threa
         _p(o_re, C.c_float), _p(o_im, C.c_float))
     assert rc == 0
     return o_re + 1j * o_im
+
+
+def dc_f32_profile(re, im, codes_tbl, params, fs, shifts, N=None, blk_stride=None, native=False):
+    """The 4-pass CPU baseline on ONE thread with the wall time of each pass accumulated over all (block, channel)
+    calls.  Returns (complex64 [B, K, L, M], seconds [4]: code replica, carrier replica, downconvert, correlate)."""
+    l = lib(native=native)
+    re = np.ascontiguousarray(re, dtype=np.float32)
+    im = np.ascontiguousarray(im, dtype=np.float32)
+    ct = np.ascontiguousarray(codes_tbl, dtype=np.int8)
+    params = np.ascontiguousarray(params)
+    B, K = params.shape
+    M, ld = re.shape
+    if N is None:
+        N = ld // B
+    if blk_stride is None:
+        blk_stride = N
+    sh = np.ascontiguousarray(shifts, dtype=np.int32)
+    L = sh.size
+    o_re = np.empty((B, K, L, M), dtype=np.float32)
+    o_im = np.empty_like(o_re)
+    secs = np.zeros(4, dtype=np.float64)
+    rc = l.gat_oracle_dc_f32_profile(
+        _p(re, C.c_float), _p(im, C.c_float), ld, blk_stride, N, M, B, K, _p(ct, C.c_int8), ct.shape[1],
+        params.ctypes.data_as(C.POINTER(Params)), fs, L, _p(sh, C.c_int32), _p(o_re, C.c_float), _p(o_im, C.c_float),
+        _p(secs, C.c_double))
+    assert rc == 0
+    return o_re + 1j * o_im, secs
 
 
 def reduce_cplx_multi(in_re, in_im):

@@ -27,6 +27,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #define GAT_ORACLE_API __attribute__((visibility("default")))
 
@@ -215,104 +216,225 @@ GAT_ORACLE_API int gat_oracle_correlate_f64(const float *re, const float *im, in
  *   pass 2 carrier replica    -> carrier_re/im[N]          (float32)
  *   pass 3 downconvert!       -> dw_re/im[N x M]           (float32)
  *   pass 4 correlate          -> a[m,l] += dw[i,m] * code[i + shift_l - shift_0]
- * Single thread, float32 accumulation, auto-vectorised (the reference uses one Julia thread
- * with LoopVectorization @avx).  scratch must hold (N+nshift) + 2N + 2NM + Lc floats; N < 2^31.  This is the
+ * Single thread, float32 accumulation, EVERY pass auto-vectorised (the reference uses one Julia
+ * thread with LoopVectorization @avx; gcc -O3 -fopt-info-vec reports the loops below, the report
+ * of the build is kept under profiles/).  Passes 1-2 run on integer NCOs, as Tracking.jl 0.14's CPU
+ * path does (recollection, the fork's source is not available):
+ *   pass 1: 32.32 fixed-point code phase, re-anchored with the reference's double expression every
+ *           GAT_ORACLE_BATCH samples, table lookup as a vector gather from a table extended past
+ *           the code length (no modulo in the loop).  A batch that holds a sample whose fixed-point
+ *           fraction is too close to a chip edge to PROVE the same floor as the double expression
+ *           is redone with that expression: the replica is bit-identical to gen_code_replica above.
+ *   pass 2: 64-bit carrier NCO (one cycle = 2^64), float32 polynomial sincos on the quadrant-
+ *           reduced top 32 bits (|err| < 2e-7).
+ * scratch must hold (N+nshift) + 2N + 2NM + 2Lc + 4*GAT_ORACLE_BATCH floats; N < 2^30.  This is the
  * "port" timed by bench.py's cpu_baseline leg; it is itself checked against correlate_f64.
  * ---------------------------------------------------------------------------------------- */
-GAT_ORACLE_API int gat_oracle_dc_f32_4pass(const float *re, const float *im, int64_t ld, int64_t N,
-                                           int M, const int8_t *codes, int Lc, int prn0, double fc,
-                                           double fs, double f, double tau, double phi_cycles,
-                                           int L, const int32_t *shifts, float *scratch,
-                                           float *out_re, float *out_im)
+#define GAT_ORACLE_BATCH 1024
+
+static inline double now_s(void)
 {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* pass 1 */
+static void pass_code_replica(const int8_t *c, int Lc, double ratio, double tau, int64_t first, int64_t cnt,
+                              float *restrict code, float *restrict ctab /* [2 Lc] */,
+                              int32_t *restrict idxbuf /* [BATCH] */)
+{
+    for (int i = 0; i < Lc; ++i) ctab[i] = ctab[i + Lc] = (float)c[i];
+    /* the walk is provable only while a batch advances less than one code period and the margin
+     * stays far below one chip (GNSS magnitudes always do); otherwise every sample is exact */
+    const double span = fabs(tau) + fabs(ratio) * ((double)cnt + fabs((double)first)) + 1.0;
+    const double m = span * 0x1p-18 + (double)(GAT_ORACLE_BATCH + 2); /* 2^-32 chips, as gat_phase.h */
+    const int walk_ok = ratio >= 0.0 && ratio * (double)(GAT_ORACLE_BATCH + 1) + 2.0 < (double)Lc && m < 1.0e9 &&
+                        span < 2147483648.0;
+    const uint64_t rate = walk_ok ? (uint64_t)(ratio * 4294967296.0) : 0u; /* truncated */
+    const uint32_t margin = walk_ok ? (uint32_t)m + 1u : 0u;
+    for (int64_t i0 = 0; i0 < cnt; i0 += GAT_ORACLE_BATCH) {
+        const int len = (int)((cnt - i0) < GAT_ORACLE_BATCH ? (cnt - i0) : GAT_ORACLE_BATCH);
+        int exact = !walk_ok;
+        if (walk_ok) {
+            /* anchor: the reference's expression (src/algorithms.jl:179-182), exact */
+            const double p0 = ratio * (double)(i0 + first) + tau;
+            const double fl0 = floor(p0);
+            const uint64_t q0 = (uint64_t)((p0 - fl0) * 4294967296.0); /* p - floor(p) is exact */
+            const uint32_t idx0 = (uint32_t)floormod64((int64_t)fl0, Lc);
+            uint32_t amb = 0;
+            for (int i = 0; i < len; ++i) { /* 64-bit lanes */
+                const uint64_t q = q0 + (uint64_t)i * rate;
+                const uint32_t fr = (uint32_t)q;
+                idxbuf[i] = (int32_t)(idx0 + (uint32_t)(q >> 32)); /* < 2 Lc */
+                amb |= (uint32_t)((fr - margin) > (0xffffffffu - 2u * margin));
+            }
+            exact = amb != 0;
+            if (!exact)
+                for (int i = 0; i < len; ++i) code[i0 + i] = ctab[idxbuf[i]]; /* gather */
+        }
+        if (exact)
+            for (int i = 0; i < len; ++i) code[i0 + i] = (float)c[code_index(ratio, i0 + i + first, tau, Lc)];
+    }
+}
+
+/* pass 2 */
+static void pass_carrier_replica(double f, double fs, double phi_cycles, int64_t N, float *restrict car_re,
+                                 float *restrict car_im, uint32_t *restrict ubuf /* [BATCH] */)
+{
+    const double step = f / fs; /* cycles per sample */
+    const double sfrac = step - floor(step), pfrac = phi_cycles - floor(phi_cycles);
+    const uint64_t step64 = (uint64_t)ldexp(sfrac, 64), phi64 = (uint64_t)ldexp(pfrac, 64);
+    for (int64_t n0 = 0; n0 < N; n0 += GAT_ORACLE_BATCH) {
+        const int len = (int)((N - n0) < GAT_ORACLE_BATCH ? (N - n0) : GAT_ORACLE_BATCH);
+        const uint64_t base = phi64 + (uint64_t)n0 * step64; /* wraps with the cycle */
+        for (int i = 0; i < len; ++i) ubuf[i] = (uint32_t)((base + (uint64_t)i * step64) >> 32); /* 64-bit lanes */
+        for (int i = 0; i < len; ++i) { /* 32-bit lanes */
+            const uint32_t u = ubuf[i];                  /* phase, 2^32 = one cycle */
+            const uint32_t qd = (u + 0x20000000u) >> 30; /* nearest quadrant, 0..4 */
+            const int32_t r = (int32_t)(u - (qd << 30)); /* |r| <= 2^29: +-1/8 cycle */
+            const float a = (float)r * 1.4629180792671596e-9f; /* 2 pi / 2^32 */
+            const float a2 = a * a;
+            const float sp = a * (1.0f + a2 * (-1.6666667e-1f + a2 * (8.3333333e-3f + a2 * (-1.9841270e-4f + a2 * 2.7557319e-6f))));
+            const float cp = 1.0f + a2 * (-0.5f + a2 * (4.1666667e-2f + a2 * (-1.3888889e-3f + a2 * 2.4801587e-5f)));
+            const uint32_t qi = qd & 3u;
+            const float cs = (qi & 1u) ? sp : cp; /* |cos| source */
+            const float sn = (qi & 1u) ? cp : sp; /* |sin| source */
+            car_re[n0 + i] = (qi == 1u || qi == 2u) ? -cs : cs;
+            car_im[n0 + i] = (qi >= 2u) ? -sn : sn;
+        }
+    }
+}
+
+/* pass 4 for one antenna: the reference's loop nest (paper/paper.tex:286-292) -- samples outer, taps
+ * inner, so the downconverted sample is loaded once for all taps.  16 independent float partial sums
+ * per tap (what a SIMD loop with vector accumulators does), flushed into a double every 1024 samples:
+ * a single running float sum of ~N near-constant terms drifts by > 1e-4 relative at N = 20000. */
+#define GAT_ORACLE_CORRELATE(LL)                                                                     \
+    static void correlate_taps_##LL(const float *restrict dr, const float *restrict di,             \
+                                    const float *restrict code, const int32_t *off, int64_t N,      \
+                                    double *restrict tr, double *restrict ti)                        \
+    {                                                                                                \
+        for (int l = 0; l < LL; ++l) tr[l] = ti[l] = 0.0;                                            \
+        for (int64_t n0 = 0; n0 < N; n0 += 1024) {                                                   \
+            const int len = (int)((N - n0) < 1024 ? (N - n0) : 1024);                                \
+            float pr[LL][16], pi[LL][16];                                                            \
+            for (int l = 0; l < LL; ++l)                                                             \
+                for (int j = 0; j < 16; ++j) pr[l][j] = pi[l][j] = 0.f;                              \
+            int n = 0;                                                                               \
+            for (; n + 16 <= len; n += 16)                                                           \
+                for (int l = 0; l < LL; ++l) {                                                       \
+                    const float *cl = code + n0 + n + off[l];                                        \
+                    for (int j = 0; j < 16; ++j) {                                                   \
+                        pr[l][j] += dr[n0 + n + j] * cl[j];                                          \
+                        pi[l][j] += di[n0 + n + j] * cl[j];                                          \
+                    }                                                                                \
+                }                                                                                    \
+            for (; n < len; ++n)                                                                     \
+                for (int l = 0; l < LL; ++l) {                                                       \
+                    pr[l][0] += dr[n0 + n] * code[n0 + n + off[l]];                                  \
+                    pi[l][0] += di[n0 + n] * code[n0 + n + off[l]];                                  \
+                }                                                                                    \
+            for (int l = 0; l < LL; ++l) {                                                           \
+                float sr = 0.f, si = 0.f;                                                            \
+                for (int j = 0; j < 16; ++j) { sr += pr[l][j]; si += pi[l][j]; }                     \
+                tr[l] += sr;                                                                         \
+                ti[l] += si;                                                                         \
+            }                                                                                        \
+        }                                                                                            \
+    }
+GAT_ORACLE_CORRELATE(1)
+GAT_ORACLE_CORRELATE(2)
+GAT_ORACLE_CORRELATE(3)
+GAT_ORACLE_CORRELATE(4)
+GAT_ORACLE_CORRELATE(5)
+GAT_ORACLE_CORRELATE(6)
+GAT_ORACLE_CORRELATE(7)
+GAT_ORACLE_CORRELATE(8)
+
+static void correlate_taps(int L, const float *dr, const float *di, const float *code, const int32_t *off,
+                           int64_t N, double *tr, double *ti)
+{
+    switch (L) {
+    case 1: correlate_taps_1(dr, di, code, off, N, tr, ti); break;
+    case 2: correlate_taps_2(dr, di, code, off, N, tr, ti); break;
+    case 3: correlate_taps_3(dr, di, code, off, N, tr, ti); break;
+    case 4: correlate_taps_4(dr, di, code, off, N, tr, ti); break;
+    case 5: correlate_taps_5(dr, di, code, off, N, tr, ti); break;
+    case 6: correlate_taps_6(dr, di, code, off, N, tr, ti); break;
+    case 7: correlate_taps_7(dr, di, code, off, N, tr, ti); break;
+    case 8: correlate_taps_8(dr, di, code, off, N, tr, ti); break;
+    default: /* wider tap lists: eight at a time */
+        for (int l0 = 0; l0 < L; l0 += 8) {
+            const int ll = L - l0 < 8 ? L - l0 : 8;
+            correlate_taps(ll, dr, di, code, off + l0, N, tr + l0, ti + l0);
+        }
+    }
+}
+
+#define GAT_ORACLE_MAX_TAPS 64
+
+static int dc_f32_4pass_impl(const float *re, const float *im, int64_t ld, int64_t N, int M, const int8_t *codes,
+                             int Lc, int prn0, double fc, double fs, double f, double tau, double phi_cycles,
+                             int L, const int32_t *shifts, float *scratch, float *out_re, float *out_im,
+                             double *pass_seconds /* [4] accumulated, or NULL */)
+{
+    if (L < 1 || L > GAT_ORACLE_MAX_TAPS) return 1;
     const int64_t nshift = (int64_t)shifts[L - 1] - shifts[0];
     float *code = scratch;
     float *car_re = code + (N + nshift);
     float *car_im = car_re + N;
     float *dw_re = car_im + N;
     float *dw_im = dw_re + (size_t)N * M;
+    float *ctab = dw_im + (size_t)N * M;                         /* 2 Lc floats */
+    uint32_t *ibuf = (uint32_t *)(ctab + 2 * (size_t)Lc);        /* GAT_ORACLE_BATCH words */
     const double ratio = fc / fs;
     const int8_t *c = codes + (size_t)prn0 * (size_t)Lc;
+    double t0 = pass_seconds ? now_s() : 0.0, t1;
 
-    /* pass 1: code replica.  floor/mod done in double so the loop vectorises; all quantities
-     * are integers < 2^53, so fp - q*Lc is exact and the result equals floormod64().  The chip
-     * table is widened to float once so the lookup is a vector gather. */
-    {
-        const double inv_lc = 1.0 / (double)Lc, dlc = (double)Lc, s0 = (double)shifts[0];
-        float *ctab = dw_im + (size_t)N * M; /* Lc floats at the end of scratch */
-        for (int i = 0; i < Lc; ++i) ctab[i] = (float)c[i];
-        const int cnt = (int)(N + nshift);
-        for (int i = 0; i < cnt; ++i) {
-            const double p = ratio * ((double)i + s0) + tau;
-            const double fp = floor(p);
-            double r = fp - floor(fp * inv_lc) * dlc;
-            r = r < 0.0 ? r + dlc : r;
-            r = r >= dlc ? r - dlc : r;
-            code[i] = ctab[(int)r];
-        }
-    }
-    /* pass 2: carrier replica; phase reduced to [0,1) cycles in double, then a float32
-     * quadrant-reduced polynomial sincos (|err| < 2e-7) so that the loop vectorises, as the
-     * reference's @avx sincos does. */
-    {
-        const double step = f / fs;
-        const int cnt = (int)N;
-        for (int n = 0; n < cnt; ++n) {
-            double th = (double)n * step + phi_cycles;
-            th -= floor(th);
-            const float t = (float)th;
-            const float q = rintf(t * 4.0f);
-            const float a = (t - q * 0.25f) * 6.283185307179586f;
-            const float a2 = a * a;
-            const float sp = a * (1.0f + a2 * (-1.6666667e-1f + a2 * (8.3333333e-3f + a2 * (-1.9841270e-4f + a2 * 2.7557319e-6f))));
-            const float cp = 1.0f + a2 * (-0.5f + a2 * (4.1666667e-2f + a2 * (-1.3888889e-3f + a2 * 2.4801587e-5f)));
-            const int qi = (int)q & 3;
-            const float cs = (qi & 1) ? sp : cp;   /* |cos| source */
-            const float sn = (qi & 1) ? cp : sp;   /* |sin| source */
-            car_re[n] = (qi == 1 || qi == 2) ? -cs : cs;
-            car_im[n] = (qi >= 2) ? -sn : sn;
-        }
-    }
+    pass_code_replica(c, Lc, ratio, tau, shifts[0], N + nshift, code, ctab, (int32_t *)ibuf);
+    if (pass_seconds) { t1 = now_s(); pass_seconds[0] += t1 - t0; t0 = t1; }
+    pass_carrier_replica(f, fs, phi_cycles, N, car_re, car_im, ibuf);
+    if (pass_seconds) { t1 = now_s(); pass_seconds[1] += t1 - t0; t0 = t1; }
     /* pass 3: downconvert (conjugate carrier) */
     for (int m = 0; m < M; ++m) {
-        const float *xr = re + (size_t)m * (size_t)ld, *xi = im + (size_t)m * (size_t)ld;
-        float *dr = dw_re + (size_t)m * N, *di = dw_im + (size_t)m * N;
+        const float *restrict xr = re + (size_t)m * (size_t)ld, *restrict xi = im + (size_t)m * (size_t)ld;
+        float *restrict dr = dw_re + (size_t)m * N, *restrict di = dw_im + (size_t)m * N;
+        const float *restrict cr = car_re, *restrict ci = car_im;
         for (int64_t n = 0; n < N; ++n) {
-            dr[n] = xr[n] * car_re[n] + xi[n] * car_im[n];
-            di[n] = xi[n] * car_re[n] - xr[n] * car_im[n];
+            dr[n] = xr[n] * cr[n] + xi[n] * ci[n];
+            di[n] = xi[n] * cr[n] - xr[n] * ci[n];
         }
     }
-    /* pass 4: correlate.  16 independent float partial sums per (antenna, tap) (what a SIMD
-     * loop with vector accumulators does), flushed into a double every 1024 samples: a single
-     * running float sum of ~N near-constant terms drifts by >1e-4 relative at N = 20000. */
-    for (int l = 0; l < L; ++l) {
-        const float *cl = code + (shifts[l] - shifts[0]);
-        for (int m = 0; m < M; ++m) {
-            const float *dr = dw_re + (size_t)m * N, *di = dw_im + (size_t)m * N;
-            double tr = 0.0, ti = 0.0;
-            for (int64_t n0 = 0; n0 < N; n0 += 1024) {
-                const int len = (int)((N - n0) < 1024 ? (N - n0) : 1024);
-                float pr[16] = {0}, pi[16] = {0};
-                int n = 0;
-                for (; n + 16 <= len; n += 16)
-                    for (int j = 0; j < 16; ++j) {
-                        pr[j] += dr[n0 + n + j] * cl[n0 + n + j];
-                        pi[j] += di[n0 + n + j] * cl[n0 + n + j];
-                    }
-                for (; n < len; ++n) {
-                    pr[0] += dr[n0 + n] * cl[n0 + n];
-                    pi[0] += di[n0 + n] * cl[n0 + n];
-                }
-                float sr = 0.f, si = 0.f;
-                for (int j = 0; j < 16; ++j) { sr += pr[j]; si += pi[j]; }
-                tr += sr;
-                ti += si;
-            }
-            out_re[m + l * M] = (float)tr;
-            out_im[m + l * M] = (float)ti;
+    if (pass_seconds) { t1 = now_s(); pass_seconds[2] += t1 - t0; t0 = t1; }
+    /* pass 4: correlate */
+    int32_t off[GAT_ORACLE_MAX_TAPS];
+    double tr[GAT_ORACLE_MAX_TAPS], ti[GAT_ORACLE_MAX_TAPS];
+    for (int l = 0; l < L; ++l) off[l] = shifts[l] - shifts[0];
+    for (int m = 0; m < M; ++m) {
+        correlate_taps(L, dw_re + (size_t)m * N, dw_im + (size_t)m * N, code, off, N, tr, ti);
+        for (int l = 0; l < L; ++l) {
+            out_re[m + l * M] = (float)tr[l];
+            out_im[m + l * M] = (float)ti[l];
         }
     }
+    if (pass_seconds) { t1 = now_s(); pass_seconds[3] += t1 - t0; }
     return 0;
+}
+
+GAT_ORACLE_API size_t gat_oracle_dc_f32_scratch_floats(int64_t N, int M, int Lc, int64_t nshift)
+{
+    return (size_t)(N + nshift) + 2 * (size_t)N + 2 * (size_t)N * M + 2 * (size_t)Lc + GAT_ORACLE_BATCH;
+}
+
+GAT_ORACLE_API int gat_oracle_dc_f32_4pass(const float *re, const float *im, int64_t ld, int64_t N,
+                                           int M, const int8_t *codes, int Lc, int prn0, double fc,
+                                           double fs, double f, double tau, double phi_cycles,
+                                           int L, const int32_t *shifts, float *scratch,
+                                           float *out_re, float *out_im)
+{
+    return dc_f32_4pass_impl(re, im, ld, N, M, codes, Lc, prn0, fc, fs, f, tau, phi_cycles, L, shifts, scratch, out_re,
+                             out_im, NULL);
 }
 
 /* Batched CPU baseline over B consecutive blocks and K channels; params arrays are [K x B]
@@ -332,7 +454,7 @@ GAT_ORACLE_API int gat_oracle_dc_f32_batched(const float *re, const float *im, i
                                              float *out_im)
 {
     const int64_t nshift = (int64_t)shifts[L - 1] - shifts[0];
-    const size_t scratch_n = (size_t)(N + nshift) + 2 * (size_t)N + 2 * (size_t)N * M + (size_t)Lc;
+    const size_t scratch_n = gat_oracle_dc_f32_scratch_floats(N, M, Lc, nshift);
     int rc = 0;
 #ifdef _OPENMP
 #pragma omp parallel num_threads(threads > 0 ? threads : 1)
@@ -355,6 +477,31 @@ GAT_ORACLE_API int gat_oracle_dc_f32_batched(const float *re, const float *im, i
         free(scratch);
     }
     (void)threads;
+    return rc;
+}
+
+/* One thread, B x K calls as above, with the wall time of each pass accumulated into pass_seconds[4]
+ * (code replica, carrier replica, downconvert, correlate): what bench.py reports as per_pass_us. */
+GAT_ORACLE_API int gat_oracle_dc_f32_profile(const float *re, const float *im, int64_t ant_stride,
+                                             int64_t blk_stride, int64_t N, int M, int B, int K,
+                                             const int8_t *codes, int Lc, const gat_oracle_params *prm,
+                                             double fs, int L, const int32_t *shifts, float *out_re,
+                                             float *out_im, double *pass_seconds)
+{
+    const int64_t nshift = (int64_t)shifts[L - 1] - shifts[0];
+    float *scratch = (float *)malloc(gat_oracle_dc_f32_scratch_floats(N, M, Lc, nshift) * sizeof(float));
+    if (!scratch) return 2;
+    for (int i = 0; i < 4; ++i) pass_seconds[i] = 0.0;
+    int rc = 0;
+    for (int b = 0; b < B && !rc; ++b)
+        for (int k = 0; k < K && !rc; ++k) {
+            const gat_oracle_params *p = &prm[k + (size_t)b * K];
+            const size_t o = ((size_t)k + (size_t)b * K) * (size_t)(M * L);
+            rc = dc_f32_4pass_impl(re + (size_t)b * blk_stride, im + (size_t)b * blk_stride, ant_stride, N, M, codes,
+                                   Lc, p->prn0, p->code_freq_hz, fs, p->carrier_freq_hz, p->code_phase_chips,
+                                   p->carrier_phase_cycles, L, shifts, scratch, out_re + o, out_im + o, pass_seconds);
+        }
+    free(scratch);
     return rc;
 }
 
