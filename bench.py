@@ -160,12 +160,13 @@ def cpu_baseline(args, host_re, host_im, prm, shifts, fs, system):
 
     def run(nblk, threads, budget):
         """Repeat passes over the first nblk blocks until `budget` seconds are used."""
-        oracle.dc_f32(host_re[:, :min(4, nblk) * N], host_im[:, :min(4, nblk) * N], codes, oprm[:min(4, nblk)],
-                      fs, shifts, N=N, threads=threads, native=True)  # warm-up: page faults, OpenMP pool
+        # the whole (contiguous) host arrays go in and the parameter slice says how many blocks are processed: a column
+        # slice of the [M, B*N] arrays would be copied by the binding on every call (round 2 timed that copy with the
+        # one-thread figure)
+        oracle.dc_f32(host_re, host_im, codes, oprm[:min(4, nblk)], fs, shifts, N=N, threads=threads, native=True)  # warm-up
         done, t0 = 0, time.perf_counter()
         while True:
-            oracle.dc_f32(host_re[:, :nblk * N], host_im[:, :nblk * N], codes, oprm[:nblk], fs, shifts, N=N,
-                          threads=threads, native=True)
+            oracle.dc_f32(host_re, host_im, codes, oprm[:nblk], fs, shifts, N=N, threads=threads, native=True)
             done += nblk
             dt = time.perf_counter() - t0
             if dt >= budget:
@@ -181,9 +182,8 @@ def cpu_baseline(args, host_re, host_im, prm, shifts, fs, system):
     # one thread, per pass (code replica / carrier replica / downconvert / correlate): where the 4-pass structure spends
     # its time on this host, in microseconds per (block, channel)
     nprof = min(64, max_blk)
-    oracle.dc_f32_profile(host_re[:, :nprof * N], host_im[:, :nprof * N], codes, oprm[:nprof], fs, shifts, N=N, native=True)
-    _, secs = oracle.dc_f32_profile(host_re[:, :nprof * N], host_im[:, :nprof * N], codes, oprm[:nprof], fs, shifts, N=N,
-                                    native=True)
+    oracle.dc_f32_profile(host_re, host_im, codes, oprm[:nprof], fs, shifts, N=N, native=True)
+    _, secs = oracle.dc_f32_profile(host_re, host_im, codes, oprm[:nprof], fs, shifts, N=N, native=True)
     per_pass = {k: round(float(v) / (nprof * args.channels) * 1e6, 3)
                 for k, v in zip(("code_replica", "carrier_replica", "downconvert", "correlate"), secs)}
     return {
@@ -213,15 +213,12 @@ def cpu_sweep(out_path: str, seconds: float = 0.25):
             fs = n / 1e-3
             for m in ms:
                 re, im = oracle.gen_signal(codes, 0, fc, fs, 1500.0, 0.0, 0.0, n, m)
-                prm = oracle.make_params(0, fc, 1500.0, 0.0, 0.0, shape=(1, 1))
                 for l in ls:
                     sh = oracle.sample_shifts(l, fs, fc)
-                    oracle.dc_f32(re, im, codes, prm, fs, sh, N=n, threads=1, native=True)
-                    times, t_end = [], time.perf_counter() + seconds
-                    while time.perf_counter() < t_end or len(times) < 5:
-                        t0 = time.perf_counter_ns()
-                        oracle.dc_f32(re, im, codes, prm, fs, sh, N=n, threads=1, native=True)
-                        times.append(time.perf_counter_ns() - t0)
+                    # timed inside C, call by call (a ctypes round trip per sample would add ~10 us of Python to a 5 us block)
+                    per = oracle.dc_f32_time(re, im, codes, 0, fc, fs, 1500.0, 0.0, 0.0, sh, 20)[0].min() * 1e-9
+                    reps = int(min(10000, max(20, seconds / max(per, 1e-7))))
+                    times = oracle.dc_f32_time(re, im, codes, 0, fc, fs, 1500.0, 0.0, 0.0, sh, reps)[0]
                     t = np.asarray(times, dtype=np.float64)
                     rows.append({"processor": "CPU", "GNSS": gnss, "num_samples": n, "num_ants": m, "num_correlators": l,
                                  "algorithm": "cpu_port_1_thread", "Minimum": float(t.min()), "Median": float(np.median(t)),

@@ -32,6 +32,10 @@ EXPORTS = [
     "gat_gen_signal", "gat_reduce_cplx_multi", "gat_tracking_update", "gat_malloc", "gat_free", "gat_memcpy_h2d",
     "gat_memcpy_d2h", "gat_memset", "gat_timer_start", "gat_timer_stop", "gat_last_launch_info", "gat_set_matrix_core", "gat_tracking_run", "gat_set_vector_tiling", "gat_gen_code_replica_multi",
     "gat_downconvert_and_accumulate",
+    # several devices from one host thread (channel sharding, no collective)
+    "gat_device_count", "gat_memcpy_peer", "gat_group_create", "gat_group_destroy", "gat_group_size", "gat_group_ctx",
+    "gat_group_last_error", "gat_group_shard", "gat_group_set_codes", "gat_group_replicate", "gat_group_correlate",
+    "gat_group_gather", "gat_group_sync",
 ]
 
 
@@ -141,11 +145,24 @@ def load(build_if_missing: bool = True):
         "gat_memset": (i32, [vp, vp, i32, C.c_size_t]),
         "gat_timer_start": (i32, [vp]),
         "gat_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
-        "gat_last_launch_info": (i32, [vp, C.POINTER(LaunchInfo)]),
+        "gat_last_launch_info": (i32, [vp, C.POINTER(LaunchInfo), C.c_size_t]),
         "gat_set_matrix_core": (i32, [vp, i32]),
         "gat_set_vector_tiling": (i32, [vp, i32, i32, i32]),
         "gat_gen_code_replica_multi": (i32, [vp, vp, i64, i64, i32, vp, dbl, i64]),
         "gat_downconvert_and_accumulate": (i32, [vp, sp, pp, i32, i32p, dbl, vp, vp, vp, vp, vp, vp]),
+        "gat_device_count": (i32, [i32p]),
+        "gat_memcpy_peer": (i32, [vp, vp, vp, vp, C.c_size_t]),
+        "gat_group_create": (i32, [i32, i32p, C.POINTER(vp)]),
+        "gat_group_destroy": (i32, [vp]),
+        "gat_group_size": (i32, [vp, i32p]),
+        "gat_group_ctx": (i32, [vp, i32, C.POINTER(vp)]),
+        "gat_group_last_error": (C.c_char_p, [vp]),
+        "gat_group_shard": (i32, [vp, i32, i32, i32p, i32p]),
+        "gat_group_set_codes": (i32, [vp, C.POINTER(C.c_int8), i32, i32]),
+        "gat_group_replicate": (i32, [vp, i32, C.POINTER(vp), C.c_size_t]),
+        "gat_group_correlate": (i32, [vp, sp, pp, i32, i32, i32, i32p, dbl, C.POINTER(vp), C.POINTER(vp), u32]),
+        "gat_group_gather": (i32, [vp, C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, vp, vp]),
+        "gat_group_sync": (i32, [vp]),
     }
     assert sorted(sigs) == sorted(EXPORTS)
     for name, (res, args) in sigs.items():

@@ -91,15 +91,23 @@ def build_libgat(force: bool = False, verbose: bool = False, extra_flags: tuple[
     return out
 
 
-def build_c_example(force: bool = False) -> str:
-    """gcc build of examples/gat_known_answer.c against libgat.so (plain C host of the C ABI)."""
-    src = os.path.join(ROOT, "examples", "gat_known_answer.c")
-    out = os.path.join(ROOT, "build", "gat_known_answer")
+C_EXAMPLES = ("gat_known_answer", "gat_multi_gpu", "gat_latency")
+
+
+def build_c_example(force: bool = False, name: str = "gat_known_answer") -> str:
+    """gcc build of examples/<name>.c against libgat.so (plain C hosts of the C ABI: the reference's known answer,
+    channels sharded over every GPU of the node, single-block latency from native code)."""
+    src = os.path.join(ROOT, "examples", name + ".c")
+    out = os.path.join(ROOT, "build", name)
     os.makedirs(os.path.dirname(out), exist_ok=True)
     if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(LIB)):
         subprocess.run(["gcc", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-o", out, "-L" + HERE,
                         "-lgat", "-Wl,-rpath," + HERE, "-lm"], check=True)
     return out
+
+
+def build_c_examples(force: bool = False) -> list[str]:
+    return [build_c_example(force, n) for n in C_EXAMPLES if os.path.exists(os.path.join(ROOT, "examples", n + ".c"))]
 
 
 if __name__ == "__main__":

@@ -37,6 +37,7 @@ class Context:
             raise GatError(rc, "gat_create")
         self._codes_key = None
         self._codes_obj = None
+        self._codes_fp = None
 
     # -- plumbing -----------------------------------------------------------------------
     def check(self, rc: int, where: str):
@@ -66,7 +67,7 @@ class Context:
 
     def last_launch_info(self) -> dict:
         info = _lib.LaunchInfo()
-        self.check(self.lib.gat_last_launch_info(self._h, C.byref(info)), "gat_last_launch_info")
+        self.check(self.lib.gat_last_launch_info(self._h, C.byref(info), C.sizeof(info)), "gat_last_launch_info")
         return {n: getattr(info, n) for n, _ in info._fields_}
 
     def set_matrix_core(self, mode):
@@ -96,7 +97,9 @@ class Context:
         serves every operator on a (device, stream): each operator therefore re-binds its own table before every launch
         (a dual-frequency receiver alternates L1 and L5 on one context).  Cheap: the table bound last is remembered by
         identity; only a different array object is hashed, and only different contents are uploaded."""
-        if codes is self._codes_obj:
+        # identity + a fingerprint of the first chips of every row: a caller that patches a PRN row of system.codes in
+        # place is noticed (the full table is hashed only when the object or the fingerprint changed)
+        if codes is self._codes_obj and self._codes_fp == hash(np.asarray(codes)[:, :64].tobytes()):
             return
         arr = np.ascontiguousarray(codes, dtype=np.int8)
         key = (arr.shape, hash(arr.tobytes()))
@@ -104,6 +107,7 @@ class Context:
             p, lc = arr.shape
             self.check(self.lib.gat_set_codes(self._h, arr.ctypes.data_as(C.POINTER(C.c_int8)), lc, p), "gat_set_codes")
             self._codes_key = key
+        self._codes_fp = hash(np.asarray(codes)[:, :64].tobytes())
         self._codes_obj = codes  # keeps the array alive, so the identity test above cannot be fooled by a recycled id
 
     # -- operators ----------------------------------------------------------------------

@@ -1087,10 +1087,229 @@ GAT_API int32_t gat_set_vector_tiling(gat_ctx *c, int32_t max_antenna_tiles, int
     return GAT_OK;
 }
 
-GAT_API int32_t gat_last_launch_info(const gat_ctx *c, gat_launch_info *out)
+GAT_API int32_t gat_last_launch_info(const gat_ctx *c, gat_launch_info *out, size_t struct_size)
 {
-    if (!c || !out) return GAT_ERR_ARG;
-    *out = c->last;
+    if (!c || !out || struct_size == 0) return GAT_ERR_ARG;
+    // the struct grows at its end: a caller built against an older header gets the fields it knows
+    std::memcpy(out, &c->last, std::min(struct_size, sizeof(gat_launch_info)));
+    return GAT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Device groups: satellite channels sharded over several devices from ONE host thread.
+// Every member is an ordinary context with its own stream; nothing below synchronises unless it says so, so the
+// per-device launches of one gat_group_correlate overlap.  No collective: the signal is replicated with peer copies
+// (xGMI between the GPUs of one node), outputs are disjoint per channel.
+// ---------------------------------------------------------------------------------------------------------------------
+struct gat_group {
+    std::vector<gat_ctx *> ctx;
+    std::vector<gat_channel_params> staging; // host copy of one shard's parameters ([K_r x B]); reused per rank
+    hipEvent_t ready = nullptr;              // "source buffer is complete" marker of gat_group_replicate
+    int ready_device = -1;
+    std::string err;
+};
+
+namespace {
+int32_t gfail(gat_group *g, int32_t code, const char *msg)
+{
+    if (g) g->err = msg;
+    return code;
+}
+void shard_bounds(int total, int n, int r, int *lo, int *cnt)
+{
+    const int base = total / n, extra = total % n;
+    *lo = r * base + std::min(r, extra);
+    *cnt = base + (r < extra ? 1 : 0);
+}
+} // namespace
+
+GAT_API int32_t gat_device_count(int32_t *count)
+{
+    if (!count) return GAT_ERR_ARG;
+    int n = 0;
+    const hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return -(int32_t)e;
+    *count = n;
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_memcpy_peer(gat_ctx *dst_ctx, void *dst_dev, gat_ctx *src_ctx, const void *src_dev, size_t bytes)
+{
+    if (!dst_ctx || !src_ctx || !dst_dev || !src_dev) return fail(dst_ctx, GAT_ERR_ARG, "null argument");
+    if (bytes == 0) return GAT_OK;
+    // order: everything enqueued so far on the SOURCE stream (the upload / generator that fills src) completes before
+    // the copy, which runs on the DESTINATION stream (its correlator launches follow in stream order)
+    hipEvent_t ev = nullptr;
+    GAT_HIP(dst_ctx, hipSetDevice(src_ctx->device));
+    GAT_HIP(dst_ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, src_ctx->stream);
+    if (e == hipSuccess) e = hipSetDevice(dst_ctx->device);
+    if (e == hipSuccess) e = hipStreamWaitEvent(dst_ctx->stream, ev, 0);
+    if (e == hipSuccess) {
+        if (dst_ctx->device == src_ctx->device)
+            e = hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, dst_ctx->stream);
+        else
+            e = hipMemcpyPeerAsync(dst_dev, dst_ctx->device, src_dev, src_ctx->device, bytes, dst_ctx->stream);
+    }
+    (void)hipEventDestroy(ev); // released once the recorded work has completed
+    if (e != hipSuccess) return hipfail(dst_ctx, e, "gat_memcpy_peer");
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_group_create(int32_t num_members, const int32_t *devices, gat_group **out)
+{
+    if (!out || num_members < 1 || num_members > 64) return GAT_ERR_ARG;
+    *out = nullptr;
+    gat_group *g = new (std::nothrow) gat_group();
+    if (!g) return GAT_ERR_NOMEM;
+    for (int r = 0; r < num_members; ++r) {
+        gat_ctx *c = nullptr;
+        const int32_t rc = gat_create(devices ? devices[r] : r, GAT_OWN_STREAM, &c);
+        if (rc != GAT_OK) {
+            for (gat_ctx *x : g->ctx) (void)gat_destroy(x);
+            delete g;
+            return rc;
+        }
+        g->ctx.push_back(c);
+    }
+    // direct peer access between distinct member devices where the platform offers it (xGMI); without it
+    // hipMemcpyPeerAsync still works, staged by the runtime
+    for (gat_ctx *a : g->ctx)
+        for (gat_ctx *b : g->ctx) {
+            if (a->device == b->device) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, a->device, b->device) == hipSuccess && can) {
+                (void)hipSetDevice(a->device);
+                const hipError_t e = hipDeviceEnablePeerAccess(b->device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            }
+        }
+    (void)hipGetLastError();
+    *out = g;
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_group_destroy(gat_group *g)
+{
+    if (!g) return GAT_ERR_ARG;
+    for (gat_ctx *c : g->ctx) (void)gat_destroy(c);
+    delete g;
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_group_size(const gat_group *g, int32_t *num_members)
+{
+    if (!g || !num_members) return GAT_ERR_ARG;
+    *num_members = (int32_t)g->ctx.size();
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_group_ctx(gat_group *g, int32_t rank, gat_ctx **ctx)
+{
+    if (!g || !ctx || rank < 0 || rank >= (int32_t)g->ctx.size()) return gfail(g, GAT_ERR_ARG, "rank outside the group");
+    *ctx = g->ctx[(size_t)rank];
+    return GAT_OK;
+}
+
+GAT_API const char *gat_group_last_error(const gat_group *g)
+{
+    if (!g) return "null group";
+    if (!g->err.empty()) return g->err.c_str();
+    for (const gat_ctx *c : g->ctx)
+        if (!c->err.empty()) return c->err.c_str();
+    return "";
+}
+
+GAT_API int32_t gat_group_shard(const gat_group *g, int32_t num_channels, int32_t rank, int32_t *first, int32_t *count)
+{
+    if (!g || !first || !count || num_channels < 0 || rank < 0 || rank >= (int32_t)g->ctx.size()) return GAT_ERR_ARG;
+    int lo, cnt;
+    shard_bounds(num_channels, (int)g->ctx.size(), rank, &lo, &cnt);
+    *first = lo;
+    *count = cnt;
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_group_set_codes(gat_group *g, const int8_t *codes_host, int32_t code_length, int32_t num_prns)
+{
+    if (!g) return GAT_ERR_ARG;
+    for (gat_ctx *c : g->ctx) {
+        const int32_t rc = gat_set_codes(c, codes_host, code_length, num_prns);
+        if (rc != GAT_OK) return rc;
+    }
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_group_replicate(gat_group *g, int32_t src_rank, void *const *bufs_dev, size_t bytes)
+{
+    if (!g || !bufs_dev || src_rank < 0 || src_rank >= (int32_t)g->ctx.size()) return gfail(g, GAT_ERR_ARG, "bad argument");
+    for (size_t r = 0; r < g->ctx.size(); ++r) {
+        if (!bufs_dev[r]) return gfail(g, GAT_ERR_ARG, "null buffer");
+        if ((int32_t)r == src_rank || bufs_dev[r] == bufs_dev[src_rank]) continue;
+        const int32_t rc = gat_memcpy_peer(g->ctx[r], bufs_dev[r], g->ctx[(size_t)src_rank], bufs_dev[src_rank], bytes);
+        if (rc != GAT_OK) return rc;
+    }
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_group_correlate(gat_group *g, const gat_signal_desc *signals, const gat_channel_params *params_host,
+                                    int32_t B, int32_t K, int32_t L, const int32_t *shifts, double fs,
+                                    float *const *out_re_dev, float *const *out_im_dev, uint32_t flags)
+{
+    if (!g || !signals || !params_host || !shifts || !out_re_dev || !out_im_dev) return gfail(g, GAT_ERR_ARG, "null argument");
+    if (B < 1 || K < 1) return gfail(g, GAT_ERR_ARG, "sizes must be positive");
+    const int n = (int)g->ctx.size();
+    for (int r = 0; r < n; ++r) {
+        int lo, cnt;
+        shard_bounds(K, n, r, &lo, &cnt);
+        if (cnt == 0) continue; // fewer channels than members: this one idles
+        if (!out_re_dev[r] || !out_im_dev[r]) return gfail(g, GAT_ERR_ARG, "null output buffer");
+        // this member's channels of every block, channel fastest: [cnt x B]
+        g->staging.resize((size_t)cnt * B);
+        for (int b = 0; b < B; ++b)
+            std::memcpy(&g->staging[(size_t)b * cnt], &params_host[(size_t)b * K + lo], (size_t)cnt * sizeof(gat_channel_params));
+        gat_ctx *c = g->ctx[(size_t)r];
+        // the parameter upload is asynchronous from pageable host memory: the runtime copies it out before returning,
+        // so the staging vector may be reused for the next member
+        const int32_t rc = gat_downconvert_and_correlate(c, &signals[r], g->staging.data(), B, cnt, L, shifts, fs,
+                                                         out_re_dev[r], out_im_dev[r], flags);
+        if (rc != GAT_OK) return rc;
+    }
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_group_gather(gat_group *g, float *const *out_re_dev, float *const *out_im_dev, int32_t B, int32_t K,
+                                 int32_t L, int32_t M, float *host_re, float *host_im)
+{
+    if (!g || !out_re_dev || !out_im_dev || !host_re || !host_im) return gfail(g, GAT_ERR_ARG, "null argument");
+    if (B < 1 || K < 1 || L < 1 || M < 1) return gfail(g, GAT_ERR_ARG, "sizes must be positive");
+    const int n = (int)g->ctx.size();
+    const size_t lm = (size_t)L * M;
+    std::vector<float> tmp;
+    for (int r = 0; r < n; ++r) {
+        int lo, cnt;
+        shard_bounds(K, n, r, &lo, &cnt);
+        if (cnt == 0) continue;
+        tmp.resize((size_t)B * cnt * lm);
+        for (int comp = 0; comp < 2; ++comp) {
+            const float *src = comp ? out_im_dev[r] : out_re_dev[r];
+            float *dst = comp ? host_im : host_re;
+            const int32_t rc = gat_memcpy_d2h(g->ctx[(size_t)r], tmp.data(), src, tmp.size() * sizeof(float)); // synchronises
+            if (rc != GAT_OK) return rc;
+            for (int b = 0; b < B; ++b)
+                std::memcpy(dst + ((size_t)b * K + lo) * lm, tmp.data() + (size_t)b * cnt * lm, (size_t)cnt * lm * sizeof(float));
+        }
+    }
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_group_sync(gat_group *g)
+{
+    if (!g) return GAT_ERR_ARG;
+    for (gat_ctx *c : g->ctx) {
+        const int32_t rc = gat_sync(c);
+        if (rc != GAT_OK) return rc;
+    }
     return GAT_OK;
 }
 

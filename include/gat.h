@@ -318,7 +318,49 @@ typedef struct gat_launch_info {
     int32_t blocks_per_wg;   /* consecutive integration blocks one workgroup loops over                       */
     int32_t prefetch_depth;  /* vector kernel: register sets of samples per wave (steps in flight); else 0      */
 } gat_launch_info;
-GAT_API int32_t gat_last_launch_info(const gat_ctx *ctx, gat_launch_info *out);
+/* struct_size = sizeof(gat_launch_info) of the CALLER's header: the struct grows at its end between versions and the
+ * library copies no more than the caller has room for. */
+GAT_API int32_t gat_last_launch_info(const gat_ctx *ctx, gat_launch_info *out, size_t struct_size);
+
+/* ---- several devices from one host thread --------------------------------------------------
+ * The reference is single-device (its only device call is CUDA.CuDevice(0) for the GPU's name, src/benchmarks.jl:24;
+ * "parallelization over multiple channels can be easily extended", paper/paper.tex:114).  Satellite channels are
+ * independent given the antenna signal, so they shard with NO collective: every device holds the full signal
+ * (replicated by peer copies -- xGMI between the GPUs of one node; 6.4 MB per ms at 16 antennas x 50 MHz is 4 % of one
+ * link) and correlates a contiguous slice of the channels; outputs are disjoint.  A group is a set of ordinary
+ * contexts (one per member, each with its own stream: the members' launches of one call overlap); a member's context
+ * is available for every single-device function above (allocation, gat_gen_signal, timers ...).  The same device
+ * may appear several times (two members on device 0 rehearse the whole path on a one-GPU box). */
+typedef struct gat_group gat_group;
+GAT_API int32_t gat_device_count(int32_t *count);
+/* devices: num_members device ordinals, or NULL for 0 .. num_members-1 */
+GAT_API int32_t gat_group_create(int32_t num_members, const int32_t *devices, gat_group **out_group);
+GAT_API int32_t gat_group_destroy(gat_group *group);
+GAT_API int32_t gat_group_size(const gat_group *group, int32_t *num_members);
+GAT_API int32_t gat_group_ctx(gat_group *group, int32_t rank, gat_ctx **ctx); /* borrowed: destroyed with the group */
+GAT_API const char *gat_group_last_error(const gat_group *group);
+/* the contiguous channel slice of member `rank`: channels [first, first + count) of num_channels (count may be 0) */
+GAT_API int32_t gat_group_shard(const gat_group *group, int32_t num_channels, int32_t rank, int32_t *first,
+                                int32_t *count);
+GAT_API int32_t gat_group_set_codes(gat_group *group, const int8_t *codes_host, int32_t code_length,
+                                    int32_t num_prns);
+/* dst (on dst_ctx's device) <- src (on src_ctx's device), asynchronous: the copy runs on dst_ctx's stream after
+ * everything enqueued so far on src_ctx's stream (hipMemcpyPeerAsync; a plain device copy when both are one device). */
+GAT_API int32_t gat_memcpy_peer(gat_ctx *dst_ctx, void *dst_dev, gat_ctx *src_ctx, const void *src_dev, size_t bytes);
+/* bufs_dev[r] (r != src_rank) <- bufs_dev[src_rank], `bytes` each: the ingest device's signal to its peers */
+GAT_API int32_t gat_group_replicate(gat_group *group, int32_t src_rank, void *const *bufs_dev, size_t bytes);
+/* gat_downconvert_and_correlate over the group: params_host [num_channels x num_blocks] (channel fastest) for ALL
+ * channels; member r correlates its slice on signals[r] (its own copy of the signal) into out_*_dev[r], a device
+ * buffer [M x L x count_r x B] on ITS device.  Asynchronous on every member's stream. */
+GAT_API int32_t gat_group_correlate(gat_group *group, const gat_signal_desc *signals,
+                                    const gat_channel_params *params_host, int32_t num_blocks, int32_t num_channels,
+                                    int32_t num_taps, const int32_t *shifts_host, double sampling_freq_hz,
+                                    float *const *out_re_dev, float *const *out_im_dev, uint32_t flags);
+/* the members' outputs concatenated along the channel axis into host arrays [M x L x K x B]; synchronises */
+GAT_API int32_t gat_group_gather(gat_group *group, float *const *out_re_dev, float *const *out_im_dev,
+                                 int32_t num_blocks, int32_t num_channels, int32_t num_taps, int32_t num_ants,
+                                 float *out_re_host, float *out_im_host);
+GAT_API int32_t gat_group_sync(gat_group *group);
 
 #ifdef __cplusplus
 }

@@ -99,6 +99,8 @@ def _bind(l):
                                                    C.c_int64, C.c_int, C.c_int, C.c_int, i8p,
                                                    C.c_int, pp, C.c_double, C.c_int, i32p, dp, dp]
     l.gat_oracle_reduce_cplx_multi.argtypes = [fp, fp, C.c_int64, C.c_int, dp, dp]
+    l.gat_oracle_dc_f32_time.argtypes = [fp, fp, C.c_int64, C.c_int64, C.c_int, i8p, C.c_int, C.c_int, C.c_double,
+                                         C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, i32p, C.c_int, dp, fp, fp]
     l.gat_oracle_dc_f32_profile.argtypes = [fp, fp, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, i8p,
                                             C.c_int, pp, C.c_double, C.c_int, i32p, fp, fp, dp]
     return l
@@ -247,6 +249,26 @@ def dc_f32_profile(re, im, codes_tbl, params, fs, shifts, N=None, blk_stride=Non
         _p(secs, C.c_double))
     assert rc == 0
     return o_re + 1j * o_im, secs
+
+
+def dc_f32_time(re, im, codes_tbl, prn0, fc, fs, f, tau, phi_cycles, shifts, reps, native=True):
+    """``reps`` single-block calls of the 4-pass CPU baseline on ONE thread, each timed inside C (the reference's
+    ``@benchmark Tracking.downconvert_and_correlate!(...)``, src/benchmarks.jl:63-79).  re/im float32 [M, N].
+    Returns (times_ns float64 [reps], complex64 [L, M])."""
+    l = lib(native=native)
+    re = np.ascontiguousarray(re, dtype=np.float32)
+    im = np.ascontiguousarray(im, dtype=np.float32)
+    ct = np.ascontiguousarray(codes_tbl, dtype=np.int8)
+    M, N = re.shape
+    sh = np.ascontiguousarray(shifts, dtype=np.int32)
+    times = np.zeros(reps, dtype=np.float64)
+    o_re = np.empty((sh.size, M), dtype=np.float32)
+    o_im = np.empty_like(o_re)
+    rc = l.gat_oracle_dc_f32_time(_p(re, C.c_float), _p(im, C.c_float), N, N, M, _p(ct, C.c_int8), ct.shape[1], prn0, fc,
+                                  fs, f, tau, phi_cycles, sh.size, _p(sh, C.c_int32), reps, _p(times, C.c_double),
+                                  _p(o_re, C.c_float), _p(o_im, C.c_float))
+    assert rc == 0
+    return times, o_re + 1j * o_im
 
 
 def reduce_cplx_multi(in_re, in_im):

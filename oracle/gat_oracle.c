@@ -505,6 +505,29 @@ GAT_ORACLE_API int gat_oracle_dc_f32_profile(const float *re, const float *im, i
     return rc;
 }
 
+/* The reference's CPU benchmark (src/benchmarks.jl:63-79: @benchmark Tracking.downconvert_and_correlate!(...), one
+ * block, one thread, buffers allocated once outside the timed call) timed from C: `reps` calls on the same buffers,
+ * the wall time of each in times_ns (BenchmarkTools' samples).  A ctypes call per sample would add ~10 us of Python
+ * to blocks that take 5 us. */
+GAT_ORACLE_API int gat_oracle_dc_f32_time(const float *re, const float *im, int64_t ld, int64_t N, int M,
+                                          const int8_t *codes, int Lc, int prn0, double fc, double fs, double f,
+                                          double tau, double phi_cycles, int L, const int32_t *shifts, int reps,
+                                          double *times_ns, float *out_re, float *out_im)
+{
+    const int64_t nshift = (int64_t)shifts[L - 1] - shifts[0];
+    float *scratch = (float *)malloc(gat_oracle_dc_f32_scratch_floats(N, M, Lc, nshift) * sizeof(float));
+    if (!scratch) return 2;
+    int rc = 0;
+    for (int r = 0; r < reps && !rc; ++r) {
+        const double t0 = now_s();
+        rc = dc_f32_4pass_impl(re, im, ld, N, M, codes, Lc, prn0, fc, fs, f, tau, phi_cycles, L, shifts, scratch, out_re,
+                               out_im, NULL);
+        times_ns[r] = (now_s() - t0) * 1e9;
+    }
+    free(scratch);
+    return rc;
+}
+
 /* Same batching for the FP64 oracle (used by parity tests at moderate sizes). */
 GAT_ORACLE_API int gat_oracle_correlate_f64_batched(const float *re, const float *im,
                                                     int64_t ant_stride, int64_t blk_stride,

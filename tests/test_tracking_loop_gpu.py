@@ -212,6 +212,45 @@ def test_graph_replay_survives_scratch_growth_and_code_rebinding(g):
         both("replay after another system's table")
 
 
+def test_graph_in_flight_survives_knob_changes_and_scratch_growth_without_sync(g):
+    """gat_tracking_run(GAT_FLAG_GRAPH) is asynchronous; a knob change (set_vector_tiling /
+    set_matrix_core) or a scratch growth right behind it destroys the recorded graphs -- the library must drain the
+    stream first.  No ctx.sync() between the graph run and what invalidates it; results stay bit-identical to eager."""
+    import torch
+    system = g.GPSL1()
+    N, M, fs, nblk = 4000, 2, 4e6, 64
+    prns = np.array([5, 17])
+    dop = np.array([-600.0, 1900.0])
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        prm_sig = g.make_params(prns - 1, 1.023e6, dop, [[77.0, 640.5]], 0.0, shape=(nblk, 2))
+        re, im = g.gen_signal_stream(system, prm_sig, fs, N, M)
+        shifts = g.get_correlator_sample_shifts(system, g.EarlyPromptLateCorrelator(M, 3), fs, 0.5)
+
+        def make():
+            return g.TrackingLoop(system, prns, N, M, fs, shifts, init_carrier_doppler=dop + 3.0,
+                                  init_code_phase=np.array([77.1, 640.4]), dll_bandwidth_hz=4.0)
+        eager, graph = make(), make()
+        ctx = graph.ctx
+        out = (torch.empty((nblk, 2, 3, M), device=ctx.device), torch.empty((nblk, 2, 3, M), device=ctx.device))
+        big_n = 2_000_000
+        big = g.StreamCorrelator(system, big_n, 4, 1, 2, shifts, fs, ctx=ctx)
+        big.set_params(g.make_params(np.arange(2), 1.023e6, 1500.0, 0.0, 0.0, shape=(1, 2)))
+        zeros = torch.zeros((4, big_n), device=ctx.device)
+        ctx.sync()
+        invalidators = [lambda: ctx.set_vector_tiling(4, 4, 16), lambda: ctx.set_matrix_core(g.GAT_MC_AUTO),
+                        lambda: big(zeros, zeros)]  # the last one grows the split-partials buffer (first time only)
+        for i, inval in enumerate(invalidators * 2):
+            graph.run(re, im, nblk, graph=True, out=out)   # record (or re-record)
+            graph.run(re, im, nblk, graph=True, out=out)   # replay: 2 * nblk launches in flight ...
+            inval()                                        # ... when the recorded graphs are dropped
+            e_re, e_im = eager.run(re, im, nblk)
+            e_re, e_im = eager.run(re, im, nblk)
+            ctx.sync()
+            assert torch.equal(e_re, out[0]) and torch.equal(e_im, out[1]), i
+            assert eager.params().tobytes() == graph.params().tobytes(), i
+
+
 def test_two_systems_share_one_context(g):
     """the code table is per-context state; operators of two systems created on the same context
     must each correlate against THEIR table, whatever the creation order (the reference passes `system` per call)."""
