@@ -8,14 +8,16 @@
  * Parity status: PINNED for the operator's mathematical result by the reference's own
  * known-answer literals (test/algorithms.jl:85, :191, :300, :1374, :1513 -> [1476 2500 1476];
  * test/reduction.jl:51-52 -> [N N N]), see tests/test_oracle_golden.py; the C/A code tables by the
- * IS-GPS-200 first-10-chip octals (PRN 1-32); the GPS L5 I5 code tables by the IS-GPS-705 initial XB
- * code states (PRN 1-16: the first 13 chips of each code, and -- through the register recurrence --
- * the XB advances, tests/golden/golden.json "l5i_xb_initial_state").  ([1024 2048 1024] for the
- * N = 2048 shape is this build's own derivation, not a reference literal: the reference asserts
- * 1476 there, test/algorithms.jl:1310, a defect.)
+ * IS-GPS-200 first-10-chip octals (PRN 1-32); the GPS L5 I5 code tables, every chip of PRN 1-37, by
+ * IS-GPS-705 data alone: the initial XB code states of all 37 PRNs (consistent with the XB advances
+ * through an independent register, 37 x 13 bits) and the XA short-cycle decode state 1111111111101
+ * (reached by an independent register with the ICD's XA polynomial exactly at chip 8190) -- an
+ * independent XA xor XB built from those reproduces the whole table (tests/golden/golden.json
+ * "l5i_xb_initial_state", "l5_xa_decode_state").  ([1024 2048 1024] for the N = 2048 shape is this
+ * build's own derivation, not a reference literal: the reference asserts 1476 there,
+ * test/algorithms.jl:1310, a defect.)
  * UNPINNED for: the Tracking.jl CPU call itself (Julia, un-vendored fork, Manifest.toml:1392-1398
- * -- cannot run here), tap spacing for L > 3, L5 PRN 17-37 and the XA half of the L5 code beyond
- * its all-ones start (no external vector at hand: the reference holds no L5 test).
+ * -- cannot run here) and tap spacing for L > 3 (no fixture exists in the reference).
  *
  * All paths below are relative to /root/reference.  Indices are 0-based here; the reference
  * is 1-based (sample_idx - 1 at src/algorithms.jl:172, :179).
@@ -64,7 +66,8 @@ GAT_ORACLE_API int gat_oracle_code_gpsl1(int prn, int8_t *out /* [1023] */)
 
 /* GPS L5 I5: IS-GPS-705.  XA = 1+x^9+x^10+x^12+x^13 short-cycled to 8190 chips,
  * XB = 1+x+x^3+x^4+x^6+x^7+x^8+x^12+x^13 (period 8191), XB advanced per PRN (Table 3-Ia, I5
- * column).  10230 chips.  Pinned for PRN 1-16 by the ICD's initial XB code states (see the header). */
+ * column).  10230 chips.  Pinned for PRN 1-37 by the ICD's initial XB code states and the XA decode
+ * state (see the header). */
 static const unsigned short l5i_advance[37] = {
     266,  365,  804,  1138, 1509, 1559, 1756, 2084, 2170, 2303, 2527, 2687, 2930,
     3471, 3940, 4132, 4332, 4924, 5343, 5443, 5641, 5816, 5898, 5918, 5955, 6243,

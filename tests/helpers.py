@@ -22,7 +22,7 @@ def make_case(seed, system="GPSL1", N=2500, M=1, L=3, K=1, B=1, fs=None, if_hz=0
     codes, fc, lc = system_tables(system)
     if fs is None:
         fs = N / 1e-3
-    prns = rng.permutation(32)[:K]
+    prns = rng.permutation(32)[:K]  # every row of both tables is pinned to its ICD (tests/test_oracle_golden.py)
     f = if_hz + rng.uniform(-5e3, 5e3, size=(B, K))
     fcode = fc * (1.0 + (f - if_hz) / 1575.42e6)
     tau = rng.uniform(0, lc, size=(B, K))

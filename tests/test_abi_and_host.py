@@ -74,7 +74,7 @@ def test_host_code_generators_match_oracle(g, system):
 
 
 def test_host_l5_generator_against_icd_initial_states(g):
-    """libgat's own GPS L5 I5 generator against IS-GPS-705's initial XB code states (tests/golden, PRN 1-16): the
+    """libgat's own GPS L5 I5 generator against IS-GPS-705's initial XB code states (tests/golden, PRN 1-37): the
     first 13 code chips are the complement of the state read from stage 13 down (XA = all ones); and its C/A
     generator against IS-GPS-200's first-10-chip octals -- the product's tables are pinned to the ICDs directly, not
     only through the oracle."""

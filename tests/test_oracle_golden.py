@@ -66,7 +66,8 @@ def _xb_register_states(count):
 
 def test_l5_icd_columns_are_consistent():
     """IS-GPS-705 Table 3-Ia gives, per PRN, the XB code advance AND the initial XB code state: clocking the register
-    `advance` times from all ones must give the state.  16 x 13 bits agree -> neither column was mistyped."""
+    `advance` times from all ones must give the state.  37 x 13 bits agree -> neither column was mistyped."""
+    assert len(GOLD["l5i_xb_advance"]) == len(GOLD["l5i_xb_initial_state"]) == 37
     states = _xb_register_states(max(GOLD["l5i_xb_advance"]) + 1)
     for prn, (adv, want) in enumerate(zip(GOLD["l5i_xb_advance"], GOLD["l5i_xb_initial_state"]), 1):
         assert states[adv] == want, f"PRN {prn}"
@@ -75,12 +76,58 @@ def test_l5_icd_columns_are_consistent():
 def test_l5_first_chips_from_icd_initial_states():
     """The external pin of the GPS L5 I5 code CONTENT (the reference holds no L5 vector): the first 13 XB output chips
     of a PRN are its ICD initial state read from stage 13 down to stage 1; XA starts at all ones, so the first 13 code
-    chips are their complement (logic 0 -> +1, logic 1 -> -1).  Covers PRN 1-16, i.e. every PRN of BASELINE configs[2]."""
-    codes = oracle.codes("GPSL5", 32)
+    chips are their complement (logic 0 -> +1, logic 1 -> -1).  PRN 1-37: every row of the table."""
+    codes = oracle.codes("GPSL5", 37)
     for prn, state in enumerate(GOLD["l5i_xb_initial_state"], 1):
         xb = [int(c) for c in reversed(state)]          # output order: stage 13 first
         want = [1 - 2 * (1 ^ b) for b in xb]            # XA = 1 for the first 13 chips
         assert codes[prn - 1, :13].tolist() == want, f"PRN {prn}"
+
+
+def _xa_register_outputs(count):
+    """Output (stage 13) and state sequence of the L5 XA register (IS-GPS-705: 1 + x^9 + x^10 + x^12 + x^13, all ones at
+    the start), WITHOUT the short cycle -- independent of both generators."""
+    taps = (9, 10, 12, 13)
+    reg = [1] * 13
+    outs, states = [], []
+    for _ in range(count):
+        states.append("".join(map(str, reg)))
+        outs.append(reg[12])
+        fb = 0
+        for t in taps:
+            fb ^= reg[t - 1]
+        reg = [fb] + reg[:-1]
+    return outs, states
+
+
+def test_l5_xa_short_cycle_decode_state():
+    """The XA half: the ICD names the state whose decode resets the XA coder (short cycle to 8190 chips).  An independent
+    register with the ICD's polynomial holds exactly that state while it outputs chip number 8190 (one clock before its
+    natural all-ones): polynomial and cycle length agree with the ICD."""
+    outs, states = _xa_register_outputs(8192)
+    period = GOLD["l5_xa_period"]
+    assert states[period - 1] == GOLD["l5_xa_decode_state"]
+    assert states[8191] == "1" * 13 and states.index(GOLD["l5_xa_decode_state"]) == period - 1  # natural period 8191; unique
+
+
+def test_l5_full_code_content_from_icd_data():
+    """Every chip of every GPS L5 I5 code of the oracle = XA (independent register, reset to all ones after the ICD's
+    decode state, i.e. every 8190 chips) xor XB (independent register started from the ICD's initial state of that PRN,
+    free-running over the 10230 chips of 1 ms).  With the two tests above nothing of the L5 table is unpinned."""
+    xa1, _ = _xa_register_outputs(GOLD["l5_xa_period"])
+    xa = np.array((xa1 + xa1)[:10230])
+    codes = oracle.codes("GPSL5", 37)
+    taps = (1, 3, 4, 6, 7, 8, 12, 13)
+    for prn, state in enumerate(GOLD["l5i_xb_initial_state"], 1):
+        reg = [int(c) for c in state]
+        xb = np.empty(10230, dtype=np.int64)
+        for i in range(10230):
+            xb[i] = reg[12]
+            fb = 0
+            for t in taps:
+                fb ^= reg[t - 1]
+            reg = [fb] + reg[:-1]
+        assert np.array_equal(codes[prn - 1], 1 - 2 * (xa ^ xb)), f"PRN {prn}"
 
 
 def test_code_tables_properties_and_digest():
@@ -88,6 +135,7 @@ def test_code_tables_properties_and_digest():
         c = oracle.codes(system, 32)
         assert c.shape == (32, lc) and set(np.unique(c)) == {-1, 1}
         assert hashlib.sha256(c.tobytes()).hexdigest() == GOLD["code_sha256"][system]
+    assert hashlib.sha256(oracle.codes("GPSL5", 37).tobytes()).hexdigest() == GOLD["code_sha256"]["GPSL5_37"]
     ca = oracle.codes("GPSL1", 32).astype(np.int64)
     # Gold-code properties: balance -1 (one more logic-1), 3-valued autocorrelation {-1, -65, 63}
     assert (ca.sum(axis=1) == -1).all()
