@@ -159,9 +159,16 @@ struct SampleIO {
             xr = (float)(short)(w & 0xffff);
             xi = (float)(w >> 16);
         } else {
-            const int w = raw[0][j >> 1] >> ((j & 1) * 16); // two complex int8 samples per dword
-            xr = (float)(signed char)(w & 0xff);
-            xi = (float)(signed char)((w >> 8) & 0xff);
+            // two complex int8 samples per dword; one sign-extending byte convert per component (v_cvt_f32_i32 with an
+            // SDWA byte select).  The compiler finds bytes 0, 1 and 3 by itself but shifts the dword first for byte 2.
+            const int w = raw[0][j >> 1];
+            if (j & 1) {
+                asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(xr) : "v"(w));
+                xi = (float)(w >> 24);
+            } else {
+                xr = (float)(signed char)(w & 0xff);
+                xi = (float)(signed char)((w >> 8) & 0xff);
+            }
         }
     }
     // one sample with scalar loads
@@ -188,10 +195,16 @@ struct SampleIO {
 // per SIMD (<= 168) costs them nothing, while the four-antenna five-tap instance otherwise lands ONE register over
 // that step.  No bound for the larger instances, and never a tighter one: the allocator then spills into the step loop
 // (measured in both rounds: 1.2-3x slower).
-constexpr int dc_min_waves(int mt, int l, int kt) { return 2 * mt * l * kt <= 40 ? 3 : 1; }
+#ifndef GAT_DC_SB_EXPR
+#define GAT_DC_SB_EXPR (S > 4 ? 4 : S)
+#endif
+#ifndef GAT_DC_MINW
+#define GAT_DC_MINW 3
+#endif
+constexpr int dc_min_waves(int mt, int l, int kt, int d = 1) { return 2 * mt * l * kt <= 40 ? (d == 1 && 2 * mt * l * kt >= 40 ? GAT_DC_MINW : 3) : 1; }
 
 template <int MT, int L, int VEC, int FMT, int AW, int KT, bool KEEP, int NW, int D>
-__global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(const DcArgs a)
+__global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel(const DcArgs a)
 {
     // NW = 4 waves per workgroup, or 1: short blocks in a long stream (a few steps per block) spend their time in the
     // per-block set-up, which all four waves of a workgroup repeat, and at its three barriers; a one-wave workgroup
@@ -252,7 +265,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
 
     // replica producer role of this thread: channel slot gk (wave-uniform), entries gr, gr + RPC, gr + 2 RPC, ... of
     // every segment (consecutive lanes store consecutive floats); entry i <-> sample (segment start) + shift0 + i
-    const int gk = uni(tid / RPC);
+    const int gk = KT == 1 ? 0 : uni(tid / RPC);
     const int gr = tid % RPC;
 
     const int c_begin = split * a.chunks_per_split;
@@ -390,9 +403,12 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
         // chips of the S samples of one group (first sample at segment-relative position rel, a multiple of S) for the
         // L taps: one 8-byte-aligned vector read per tap and 4 samples -- tap_off[l] is the tap's distance from the first
         // when that is even, else (distance - 1) into the copy stored one entry further (host: gat_api.cpp).
-        auto get_chips_group = [&](float (&chip)[S][L], int rel, const float *rep) {
+        // SB = samples handled at once: the whole group, or half of the eight-sample groups of int8 pairs (see the step)
+        constexpr int SB = GAT_DC_SB_EXPR;
+        constexpr int NH = S / SB;
+        auto get_chips_sub = [&](float (&chip)[SB][L], int rel, const float *rep) {
 #if defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 2)
-            for (int j = 0; j < S; ++j) for (int l = 0; l < L; ++l) chip[j][l] = __int_as_float(0x3f800000 + ((rel + j + l) & 1));
+            for (int j = 0; j < SB; ++j) for (int l = 0; l < L; ++l) chip[j][l] = __int_as_float(0x3f800000 + ((rel + j + l) & 1));
             return;
 #endif
             typedef float f32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
@@ -400,21 +416,29 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
 #pragma unroll
             for (int l = 0; l < L; ++l) {
                 const float *p = rep + rel + a.tap_off[l];
-                if constexpr (S % 4 == 0) {
+                if constexpr (SB == 4) {
+                    const f32x4a8 v = *reinterpret_cast<const f32x4a8 *>(p);
 #pragma unroll
-                    for (int q = 0; q < S / 4; ++q) {
-                        const f32x4a8 v = *reinterpret_cast<const f32x4a8 *>(p + 4 * q);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) chip[4 * q + j][l] = v[j];
-                    }
-                } else if constexpr (S == 2) {
+                    for (int j = 0; j < 4; ++j) chip[j][l] = v[j];
+                } else if constexpr (SB == 2) {
                     const f32x2a8 v = *reinterpret_cast<const f32x2a8 *>(p);
                     chip[0][l] = v[0];
                     chip[1][l] = v[1];
                 } else {
 #pragma unroll
-                    for (int j = 0; j < S; ++j) chip[j][l] = rep[rel + j + (a.shifts[l] - shift0)];
+                    for (int j = 0; j < SB; ++j) chip[j][l] = rep[rel + j + (a.shifts[l] - shift0)];
                 }
+            }
+        };
+        auto get_chips_group = [&](float (&chip)[S][L], int rel, const float *rep) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                float c[SB][L];
+                get_chips_sub(c, rel + h * SB, rep);
+#pragma unroll
+                for (int j = 0; j < SB; ++j)
+#pragma unroll
+                    for (int l = 0; l < L; ++l) chip[h * SB + j][l] = c[j][l];
             }
         };
         // one sample of one antenna: conj(carrier) wipe-off (src/algorithms.jl:175-176), L taps.  Plain scalar FMAs:
@@ -433,22 +457,22 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
         // multiply-adds -- every instruction then has its operands ready when it issues (written sample by sample the
         // compiler forms the products right in front of their first use; configs[2] 1.36 -> 1.30 ms).  Not for the
         // channel-looping instances: six more live registers there (configs[3] shard 0.70 -> 0.725 ms).
-        auto accumulate_group = [&](f32x2 (&ac)[L], const i32x4 (&rw)[IO::NV], const float (&pr)[S], const float (&pi)[S],
-                                    const float (&chip)[S][L]) {
-            float xr[S], xi[S], tr[S], ti[S], dr[S], di[S];
+        auto accumulate_sub = [&](f32x2 (&ac)[L], const i32x4 (&rw)[IO::NV], int j0, const float (&pr)[SB], const float (&pi)[SB],
+                                  const float (&chip)[SB][L]) {
+            float xr[SB], xi[SB], tr[SB], ti[SB], dr[SB], di[SB];
 #pragma unroll
-            for (int j = 0; j < S; ++j) {
-                IO::get(rw, j, xr[j], xi[j]);
+            for (int j = 0; j < SB; ++j) {
+                IO::get(rw, j0 + j, xr[j], xi[j]);
                 tr[j] = xi[j] * pi[j];
                 ti[j] = -(xr[j] * pi[j]);
             }
 #pragma unroll
-            for (int j = 0; j < S; ++j) {
+            for (int j = 0; j < SB; ++j) {
                 dr[j] = __builtin_fmaf(xr[j], pr[j], tr[j]);
                 di[j] = __builtin_fmaf(xi[j], pr[j], ti[j]);
             }
 #pragma unroll
-            for (int j = 0; j < S; ++j)
+            for (int j = 0; j < SB; ++j)
 #pragma unroll
                 for (int l = 0; l < L; ++l) {
                     ac[l][0] = __builtin_fmaf(chip[j][l], dr[j], ac[l][0]);
@@ -496,13 +520,11 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
         // entries gr, gr + RPC, ...: ONE exact double-precision anchor, then the 32.32 walk (gat_phase.h) RPC samples
         // at a time in batches of 4, branch-free; a batch with an unproven entry is redone with the reference's
         // expression.  Every thread takes the same number of steps (the overshoot lands in the copy's spare room).
-        auto fill_segment = [&](int c0, int seg_cnt) {
-#if defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 4)
-            return;
-#endif
-            if (!g_valid) return;
+        // (TWO: taps at odd distances -> the copy shifted by one entry is stored as well; the store addresses of a batch are
+        // one base register + immediate offsets, and only the last, partial batch of a run checks its bound)
+        auto fill_impl = [&](auto two_c, int c0, int seg_cnt) {
+            constexpr bool TWO = decltype(two_c)::value;
             float *rep = s_rep + gk * RCH + gr;
-            const bool two = a.rep_copy_stride != 0;              // wave-uniform
             float *rep1 = rep + a.rep_copy_stride - 1;            // copy[i] = entry i + 1
             const int8_t *tab = s_code + (size_t)gk * a.code_row_stride;
             const int run = (seg_cnt + RPC - 1) / RPC;            // entries per producer thread (wave-uniform)
@@ -516,9 +538,12 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
             {
                 const float v = (float)tab[idx];
                 rep[0] = v;
-                if (two && gr > 0) rep1[0] = v;
+                if (TWO && gr > 0) rep1[0] = v;
             }
-            for (int j0 = 1; j0 < run; j0 += 4) {
+            // one batch of four walked entries j0 .. j0 + 3 (stored at w[0], w[RPC], ...)
+            auto batch = [&](auto partial_c, int j0) {
+                constexpr bool PARTIAL = decltype(partial_c)::value;
+                float *const w = rep + j0 * RPC;
                 unsigned id[4];
                 bool amb = w_exact;
 #pragma unroll
@@ -535,14 +560,30 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
 #pragma unroll 1
                     for (int u = 0; u < 4; ++u) id[u] = (unsigned)chip_index(ratio, tau, x0 + RPC * (j0 + u), Lc, inv_lc);
                 }
+                // all four table reads first: the table is int8 (a character type may alias anything), so a read written
+                // after a replica store would have to wait for it -- four serial LDS round trips per batch
+                int8_t t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = tab[id[u]];
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (j0 + u < run) { // wave-uniform bound
-                        const float v = (float)tab[id[u]];
-                        rep[(j0 + u) * RPC] = v;
-                        if (two) rep1[(j0 + u) * RPC] = v;
+                    if (!PARTIAL || j0 + u < run) { // wave-uniform bound
+                        const float v = (float)t[u];
+                        w[u * RPC] = v;
+                        if constexpr (TWO) w[a.rep_copy_stride - 1 + u * RPC] = v;
                     }
-            }
+            };
+            int j0 = 1;
+            for (; j0 + 4 <= run; j0 += 4) batch(std::false_type{}, j0);
+            if (j0 < run) batch(std::true_type{}, j0);
+        };
+        auto fill_segment = [&](int c0, int seg_cnt) {
+#if defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 4)
+            return;
+#endif
+            if (!g_valid) return;
+            if (a.rep_copy_stride != 0) fill_impl(std::true_type{}, c0, seg_cnt); // wave-uniform
+            else fill_impl(std::false_type{}, c0, seg_cnt);
         };
 
         if (c_begin < c_full && !preloaded) {
@@ -608,20 +649,39 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT)) dc_kernel(co
 #pragma unroll
                     for (int g = 0; g < G; ++g) {
                         const int rel = srel + rel0 + g * GSTRIDE;
-                        float pr[S], pi[S], chip[S][L];
-                        group_phasors(pr, pi, 0, g);
-                        get_chips_group(chip, rel, s_rep);
+                        // SB samples at a time (NH = 2 passes over the eight-sample groups of int8 pairs: chips, phasors and
+                        // wipe-off products of four samples live at once instead of eight -- 153 -> fewer registers, a
+                        // fourth wave per SIMD); an antenna's registers are refilled when its last samples are consumed
+                        float run_r = car_r[0][g], run_i = car_i[0][g];
 #pragma unroll
-                        for (int m = 0; m < MT; ++m) {
-                            accumulate_group(acc[0][m], raw[DI][g][m], pr, pi, chip);
+                        for (int h = 0; h < NH; ++h) {
+                            float pr[SB], pi[SB], chip[SB][L];
+                            pr[0] = run_r;
+                            pi[0] = run_i;
+#pragma unroll
+                            for (int j = 1; j < SB; ++j) {
+                                pr[j] = __builtin_fmaf(pr[j - 1], wr_k[0], -(pi[j - 1] * wi_k[0]));
+                                pi[j] = __builtin_fmaf(pr[j - 1], wi_k[0], pi[j - 1] * wr_k[0]);
+                            }
+                            if (h + 1 < NH) { // the next batch's first phasor
+                                run_r = __builtin_fmaf(pr[SB - 1], wr_k[0], -(pi[SB - 1] * wi_k[0]));
+                                run_i = __builtin_fmaf(pr[SB - 1], wi_k[0], pi[SB - 1] * wr_k[0]);
+                            }
+                            get_chips_sub(chip, rel + h * SB, s_rep);
+#pragma unroll
+                            for (int m = 0; m < MT; ++m) {
+                                accumulate_sub(acc[0][m], raw[DI][g][m], h * SB, pr, pi, chip);
+                                if (h + 1 == NH) {
 #if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 16))
-                            load_ant(raw[DI][g][m], m, n_rr, n_ri, n_off[g]);
+                                    load_ant(raw[DI][g][m], m, n_rr, n_ri, n_off[g]);
 #endif
-                            // antenna by antenna: left alone the scheduler wipes off all antennas first (their
-                            // products and the refilled sample registers are then live together: + 30 registers)
+                                }
+                                // antenna by antenna: left alone the scheduler wipes off all antennas first (their
+                                // products and the refilled sample registers are then live together: + 30 registers)
 #if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 32))
-                            __builtin_amdgcn_sched_barrier(0);
+                                __builtin_amdgcn_sched_barrier(0);
 #endif
+                            }
                         }
                         // carry the group's phasor to the next step
                         const float t = __builtin_fmaf(car_r[0][g], cwr_k[0], -(car_i[0][g] * cwi_k[0]));
