@@ -560,6 +560,65 @@ void key_put(std::vector<unsigned char> &k, const T &v)
     k.insert(k.end(), p, p + sizeof(T));
 }
 
+// GAT_FLAG_GRAPH: replay the launch sequence of `enqueue` as one instantiated hipGraph when the same call repeats.
+// Every argument that shapes the sequence is part of the key (make_key), together with the library-owned pointers and
+// sizes the recorded launches bake in; a call with a known key replays its graph.  The first call with a key runs
+// eagerly (this also sizes the library's scratch buffers, which must not be reallocated inside a capture -- a
+// reallocation drops every recorded graph), then the same sequence is recorded for the following calls under the key of
+// the buffers the capture really uses.  Up to kMaxLoopGraphs graphs are kept (least recently used goes).
+template <class MakeKey, class Enqueue>
+int32_t graph_replay_or_record(gat_ctx *c, MakeKey make_key, Enqueue enqueue)
+{
+    {
+        const std::vector<unsigned char> key = make_key();
+        for (auto &g : c->loop_graphs)
+            if (g.exec && g.key == key) {
+                g.last_use = ++c->loop_graph_clock;
+                GAT_HIP(c, hipGraphLaunch(g.exec, c->stream));
+                return GAT_OK;
+            }
+    }
+    int32_t rc = enqueue();
+    if (rc != GAT_OK) return rc;
+    const std::vector<unsigned char> key = make_key();
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        return GAT_OK; // no graph (e.g. the legacy default stream): stay eager
+    }
+    rc = enqueue();
+    const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
+    hipGraphExec_t exec = nullptr;
+    if (rc == GAT_OK && ce == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+        if (c->loop_graphs.size() >= kMaxLoopGraphs) { // evict the least recently used
+            size_t lru = 0;
+            for (size_t i = 1; i < c->loop_graphs.size(); ++i)
+                if (c->loop_graphs[i].last_use < c->loop_graphs[lru].last_use) lru = i;
+            if (c->loop_graphs[lru].exec) {
+                (void)hipStreamSynchronize(c->stream); // its last replay may still be running
+                (void)hipGraphExecDestroy(c->loop_graphs[lru].exec);
+            }
+            c->loop_graphs.erase(c->loop_graphs.begin() + (long)lru);
+        }
+        gat_ctx::LoopGraph g;
+        g.key = key;
+        g.exec = exec;
+        g.last_use = ++c->loop_graph_clock;
+        c->loop_graphs.push_back(std::move(g));
+    }
+    if (graph) (void)hipGraphDestroy(graph);
+    return GAT_OK;
+}
+
+// the part of a graph key every recorded launch sequence shares: kernel-selection knobs and library-owned buffers
+void key_put_ctx(std::vector<unsigned char> &key, const gat_ctx *c)
+{
+    key_put(key, c->mc_mode); key_put(key, c->max_aw); key_put(key, c->max_kt); key_put(key, c->max_bpw);
+    key_put(key, c->wgs_per_cu); key_put(key, c->max_depth); key_put(key, c->one_wave);
+    key_put(key, c->d_codes); key_put(key, c->d_code_bits); key_put(key, c->Lc); key_put(key, c->P);
+    key_put(key, c->d_partial); key_put(key, c->partial_bytes);
+}
+
 } // namespace
 
 extern "C" {
@@ -735,7 +794,23 @@ GAT_API int32_t gat_downconvert_and_correlate_dev(gat_ctx *c, const gat_signal_d
 {
     if (!c) return GAT_ERR_ARG;
     GAT_HIP(c, hipSetDevice(c->device));
-    return correlate_impl(c, sig, params_dev, B, K, L, shifts, fs, out_re, out_im, flags);
+    if (!(flags & GAT_FLAG_GRAPH)) return correlate_impl(c, sig, params_dev, B, K, L, shifts, fs, out_re, out_im, flags);
+    // a receiver that calls the operator block after block on the same buffers: the one to three launches of a call
+    // (tap groups, second stage) replayed as one instantiated graph
+    if (!sig || !shifts || L < 1 || L > GAT_MAX_TAPS) return fail(c, GAT_ERR_ARG, "bad argument");
+    const uint32_t kflags = flags & ~GAT_FLAG_GRAPH;
+    auto make_key = [&]() {
+        std::vector<unsigned char> key;
+        key_put(key, (int)2 /* sequence: one correlate call */);
+        key_put(key, sig->re); key_put(key, sig->im); key_put(key, sig->layout); key_put(key, sig->num_ants);
+        key_put(key, sig->num_samples); key_put(key, sig->ant_stride); key_put(key, sig->block_stride);
+        key_put(key, sig->chan_stride); key_put(key, params_dev); key_put(key, B); key_put(key, K); key_put(key, L);
+        key_put(key, fs); key_put(key, out_re); key_put(key, out_im); key_put(key, kflags);
+        for (int l = 0; l < L; ++l) key_put(key, shifts[l]);
+        key_put_ctx(key, c);
+        return key;
+    };
+    return graph_replay_or_record(c, make_key, [&]() { return correlate_impl(c, sig, params_dev, B, K, L, shifts, fs, out_re, out_im, kflags); });
 }
 
 GAT_API int32_t gat_downconvert_and_correlate(gat_ctx *c, const gat_signal_desc *sig,
@@ -944,54 +1019,16 @@ GAT_API int32_t gat_tracking_run(gat_ctx *c, const gat_signal_desc *sig, int32_t
         key_put(key, cfg->early_late_spacing_chips); key_put(key, cfg->code_length); key_put(key, cfg->num_taps);
         key_put(key, cfg->early_index); key_put(key, cfg->prompt_index); key_put(key, cfg->late_index);
         key_put(key, state); key_put(key, params_a); key_put(key, params_b); key_put(key, acc_re); key_put(key, acc_im);
-        key_put(key, acc_block_stride); key_put(key, kflags); key_put(key, c->mc_mode); key_put(key, c->max_aw);
-        key_put(key, c->max_kt); key_put(key, c->max_bpw); key_put(key, c->d_codes); key_put(key, c->d_code_bits);
-        key_put(key, c->Lc); key_put(key, c->P); key_put(key, c->d_partial); key_put(key, c->partial_bytes);
+        key_put(key, acc_block_stride); key_put(key, kflags); key_put(key, (int)1 /* sequence: tracking run */);
+        key_put_ctx(key, c);
         for (int l = 0; l < L; ++l) key_put(key, shifts[l]);
         return key;
     };
     if (current_is_b) *current_is_b = (num_blocks & 1) ? 1 : 0; // the buffers swap once per block
-    {
-        const std::vector<unsigned char> key = make_key();
-        for (auto &g : c->loop_graphs)
-            if (g.exec && g.key == key) {
-                g.last_use = ++c->loop_graph_clock;
-                GAT_HIP(c, hipGraphLaunch(g.exec, c->stream));
-                return GAT_OK;
-            }
-    }
-    // first call with these arguments: run it eagerly (this also sizes the library's scratch buffers, which must
-    // not be reallocated inside a capture -- a reallocation drops every recorded graph), then record the same
-    // sequence for the following calls under the key of the buffers the capture really uses
-    int32_t rc = tracking_run_enqueue(c, sig, num_blocks, K, L, shifts, fs, cfg, state, params_a, params_b, acc_re, acc_im,
-                                      acc_block_stride, kflags, nullptr);
-    if (rc != GAT_OK) return rc;
-    const std::vector<unsigned char> key = make_key();
-    hipGraph_t graph = nullptr;
-    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return GAT_OK; // no graph: stay eager
-    rc = tracking_run_enqueue(c, sig, num_blocks, K, L, shifts, fs, cfg, state, params_a, params_b, acc_re, acc_im,
-                              acc_block_stride, kflags, nullptr);
-    const hipError_t ce = hipStreamEndCapture(c->stream, &graph);
-    hipGraphExec_t exec = nullptr;
-    if (rc == GAT_OK && ce == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-        if (c->loop_graphs.size() >= kMaxLoopGraphs) { // evict the least recently used
-            size_t lru = 0;
-            for (size_t i = 1; i < c->loop_graphs.size(); ++i)
-                if (c->loop_graphs[i].last_use < c->loop_graphs[lru].last_use) lru = i;
-            if (c->loop_graphs[lru].exec) {
-                (void)hipStreamSynchronize(c->stream); // its last replay may still be running
-                (void)hipGraphExecDestroy(c->loop_graphs[lru].exec);
-            }
-            c->loop_graphs.erase(c->loop_graphs.begin() + (long)lru);
-        }
-        gat_ctx::LoopGraph g;
-        g.key = key;
-        g.exec = exec;
-        g.last_use = ++c->loop_graph_clock;
-        c->loop_graphs.push_back(std::move(g));
-    }
-    if (graph) (void)hipGraphDestroy(graph);
-    return GAT_OK;
+    return graph_replay_or_record(c, make_key, [&]() {
+        return tracking_run_enqueue(c, sig, num_blocks, K, L, shifts, fs, cfg, state, params_a, params_b, acc_re, acc_im,
+                                    acc_block_stride, kflags, nullptr);
+    });
 }
 
 GAT_API int32_t gat_malloc(gat_ctx *c, size_t bytes, void **out)

@@ -241,7 +241,7 @@ __device__ __forceinline__ void mfma_step(f32x16 (&acc)[RT == 1 ? 2 : RT], unsig
 
 struct ChanInfoB { // per channel slot of the workgroup, in LDS
     double ratio, tau, step, phi;
-    float wr, wi;   // e^{j 2 pi step}: one-sample carrier rotation
+    float wr, wi;   // e^{j 2 pi OS step}: carrier rotation between the two samples of a producer item (OS samples apart)
     float wTr, wTi; // e^{j 2 pi T step}: one-step carrier rotation
     int prn, valid, bad;
     int inc_ok;     // fewer than Lc chips per step: the code index can be advanced by floor differences
@@ -272,6 +272,12 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     constexpr bool X1 = FMT == GAT_LAYOUT_INTERLEAVED_I8; // samples exact in one bf16 term: 4 samples per MFMA
     constexpr int SPS = X1 ? 4 : 2; // samples per k-slice
     constexpr int NM = SW / SPS;   // MFMA k-slices per consumer wave and step (two sample streams)
+    // A producer item = one channel slot x TWO samples OS apart.  3-term path: samples q and q + T/2, so that the 64 lanes
+    // of a wave (consecutive q) store CONSECUTIVE 16-byte W entries and consecutive replica words (round 2 owned the
+    // adjacent samples 2q, 2q + 1: every W store 32 bytes from its neighbour's -- every other bank group, 2-way conflicts,
+    // SQ_LDS_BANK_CONFLICT 24.6 % of SQ_LDS_IDX_ACTIVE at configs[4]; 18.3 % now, profiles/r03).  1-term path (int8): the
+    // consumers read adjacent sample pairs as one 16-byte entry, the item keeps 2q, 2q + 1.
+    constexpr int OS = X1 ? 1 : T / 2;
     // LDS row strides in entries.  3-term: X 8 B / W 16 B per sample, odd (32 planes x one sample = 32 distinct
     // bank pairs).  1-term: X 8 B / W 8 B per sample, read in 16-byte pairs: even, rows 4 banks apart.
     constexpr int XS = X1 ? T + 2 : T + 1;
@@ -335,7 +341,8 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
                      !(ci.ratio >= 0.0) || !(ci.ratio * 32.0 < (double)Lc) || !(ci.step == ci.step) || !(ci.phi == ci.phi);
             ci.prn = (P.prn < 0 || P.prn >= a.num_prns) ? 0 : P.prn;
             if (ci.bad) { ci.ratio = 0.0; ci.tau = 0.0; ci.step = 0.0; ci.phi = 0.0; }
-            sincos_cycles(ci.step - __builtin_rint(ci.step), ci.wr, ci.wi);
+            const double st_O = ci.step * (double)OS;
+            sincos_cycles(st_O - __builtin_rint(st_O), ci.wr, ci.wi);
             const double st_T = ci.step * (double)T;
             sincos_cycles(st_T - __builtin_rint(st_T), ci.wTr, ci.wTi);
             ci.inc_ok = ci.ratio * (double)(T + 2) < (double)Lc;
@@ -457,12 +464,12 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     // Every entry is the reference's FP64 expression, unfused (src/algorithms.jl:179).  Table index: the
     // full floored modulo only when `anchor`; otherwise it follows from the exact floor differences
     // (chips advance monotonically): ip - ip_prev chips on from the index of T samples ago
-    // (c.inc_ok: fewer than Lc chips per step), and the pair's second entry at most one wrap on.
-    auto gen_rep2 = [&](const ChanInfoB &c, const unsigned *tab, unsigned *row, int nb, int e0, int e_end, bool anchor,
+    // (c.inc_ok: fewer than Lc chips per step), and the pair's second entry (dist samples on) at most two wraps on.
+    auto gen_rep2 = [&](const ChanInfoB &c, const unsigned *tab, unsigned *row, int nb, int e0, int dist, int e_end, bool anchor,
                         int &ip_state, int &t_state) {
         const int x0 = nb + a.shifts[0] + e0;
         const double p0 = code_phase(c.ratio, c.tau, x0);
-        const double p1 = code_phase(c.ratio, c.tau, x0 + 1);
+        const double p1 = code_phase(c.ratio, c.tau, x0 + dist);
         const int ip0 = (int)__builtin_floor(p0);
         const int ip1 = (int)__builtin_floor(p1);
         int t0;
@@ -476,12 +483,13 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         t_state = t0;
         int t1 = t0 + (ip1 - ip0);
         t1 -= (t1 >= Lc) ? Lc : 0;
+        if (dist > 1) t1 -= (t1 >= Lc) ? Lc : 0; // up to T/2 = 64 samples on: fewer than 2 Lc chips (ratio * 32 < Lc)
         // both table words first, then both masks: two LDS round trips in flight together, not one after the other
         const unsigned w0 = tab[t0 >> 5], w1 = tab[t1 >> 5];
         const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe(w0, t0 & 31, 1) & 0x80008000u; // bit set: chip -1
         const unsigned m1 = (unsigned)__builtin_amdgcn_sbfe(w1, t1 & 31, 1) & 0x80008000u;
         row[e0] = m0;
-        if (e0 + 1 < e_end) row[e0 + 1] = m1;
+        if (e0 + dist < e_end) row[e0 + dist] = m1;
     };
     // one item = (slot, 2 consecutive samples): carrier fragments + the 2 new replica entries.  A producer
     // thread owns the same item in every step (at most one: the planner keeps nslots * T / 2 <= PT) and
@@ -490,6 +498,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     float car_r = 0.f, car_i = 0.f;
     int rep_ip = 0, rep_t = 0;
     const int item_slot = ptid / (T / 2), item_q = ptid % (T / 2);
+    const int item_s0 = X1 ? 2 * item_q : item_q; // the item's first sample (step-relative); its second one is OS further
     const bool have_item = producer && item_slot < nslots;
     auto produce = [&](int st, int buf, bool first) { // everything of step st except the samples
         const int nb = st * T;
@@ -504,7 +513,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
                 const ChanInfoB cs = s_chan[slot];
                 if (!cs.valid) continue;
                 int ip_unused, t_unused;
-                gen_rep2(cs, s_code + slot * a.code_bits_stride, rb + slot * RS, nb, 2 * g, span, true, ip_unused, t_unused);
+                gen_rep2(cs, s_code + slot * a.code_bits_stride, rb + slot * RS, nb, 2 * g, 1, span, true, ip_unused, t_unused);
             }
         } else { // the overlap with the previous step is already known
             const int pw = wave - NCW;
@@ -517,14 +526,14 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
 #if defined(GAT_ABLATE) && (GAT_ABLATE & 1) // diagnostic builds (scripts/ablate_mfma_bf16.sh; results wrong on purpose): no replica
         if (first)
 #endif
-        gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, nb, span + 2 * item_q, span + T,
+        gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, nb, span + item_s0, OS, span + T,
                  anchor || !c.inc_ok, rep_ip, rep_t);
 #if defined(GAT_ABLATE) && (GAT_ABLATE & 2) // diagnostic: carrier fragments only in the first step
         if (!first) return;
 #endif
         float cr, ci;
         if (anchor) {
-            const double th = __builtin_fma((double)(nb + 2 * item_q), c.step, c.phi);
+            const double th = __builtin_fma((double)(nb + item_s0), c.step, c.phi);
             sincos_cycles(th - __builtin_rint(th), cr, ci);
         } else { // T samples on from the previous step's first sample
             cr = __builtin_fmaf(car_r, c.wTr, -(car_i * c.wTi));
@@ -532,21 +541,21 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         }
         car_r = cr;
         car_i = ci;
-        u32x2 *w_re = wb + ((2 * item_slot) * WS + 2 * item_q) * WE;
+        u32x2 *w_re = wb + ((2 * item_slot) * WS + item_s0) * WE;
         u32x2 *w_im = w_re + WS * WE;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const Split3 sc = split3(cr), ss = split3(-ci); // w_re = chip * cos, w_im = -chip * sin (conjugate)
             if constexpr (X1) { // {hi|mid, lo|0}
-                w_re[u] = u32x2{GAT_PERM(sc.r, sc.v, 0x07060302u), sc.r2 >> 16};
+                w_re[u] = u32x2{GAT_PERM(sc.r, sc.v, 0x07060302u), sc.r2 >> 16}; // OS == 1
                 w_im[u] = u32x2{GAT_PERM(ss.r, ss.v, 0x07060302u), ss.r2 >> 16};
             } else { // {hh, mm, ll, hm}
                 const unsigned c_hh = GAT_PERM(sc.v, sc.v, 0x03020302u), c_mm = GAT_PERM(sc.r, sc.r, 0x03020302u),
                                c_ll = GAT_PERM(sc.r2, sc.r2, 0x03020302u), c_hm = GAT_PERM(sc.r, sc.v, 0x07060302u);
                 const unsigned s_hh = GAT_PERM(ss.v, ss.v, 0x03020302u), s_mm = GAT_PERM(ss.r, ss.r, 0x03020302u),
                                s_ll = GAT_PERM(ss.r2, ss.r2, 0x03020302u), s_hm = GAT_PERM(ss.r, ss.v, 0x07060302u);
-                *reinterpret_cast<u32x4 *>(w_re + 2 * u) = u32x4{c_hh, c_mm, c_ll, c_hm};
-                *reinterpret_cast<u32x4 *>(w_im + 2 * u) = u32x4{s_hh, s_mm, s_ll, s_hm};
+                *reinterpret_cast<u32x4 *>(w_re + 2 * OS * u) = u32x4{c_hh, c_mm, c_ll, c_hm};
+                *reinterpret_cast<u32x4 *>(w_im + 2 * OS * u) = u32x4{s_hh, s_mm, s_ll, s_hm};
             }
             if (u == 0) {
                 const float tr = __builtin_fmaf(cr, c.wr, -(ci * c.wi));

@@ -50,8 +50,9 @@ extern "C" {
 #define GAT_FLAG_ATOMIC 1u /* single-pass float atomics (reference alg. 4/5,                */
                            /* src/algorithms.jl:625-632); default = deterministic two-stage */
 
-#define GAT_FLAG_GRAPH 2u  /* gat_tracking_run only: replay the launch sequence as an instantiated hipGraph when the */
-                           /* call repeats with the same arguments (needs a non-default stream; else stays eager)    */
+#define GAT_FLAG_GRAPH 2u  /* gat_tracking_run and gat_downconvert_and_correlate_dev: replay the call's launch sequence */
+                           /* as an instantiated hipGraph when it repeats with the same arguments and buffers (needs a  */
+                           /* non-default stream; else stays eager).  Not for the host-parameter entry point.          */
 
 /* ---- signal layouts ---------------------------------------------------------------------- */
 #define GAT_LAYOUT_PLANAR 0          /* float32 re[] and im[] planes (reference StructArray)   */
