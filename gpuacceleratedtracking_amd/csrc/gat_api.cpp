@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <string>
 #include <vector>
@@ -43,6 +44,14 @@ struct gat_ctx {
     int Lc = 0, P = 0, code_row_stride = 0; // rows padded to a multiple of 16 bytes
     float *d_partial = nullptr;
     size_t partial_bytes = 0;
+    // completion flag (latency regime): small launches of the vector kernel end by storing a sequence number into pinned
+    // host memory; gat_sync spins on it instead of going through hipStreamSynchronize (~5 us sooner)
+    unsigned *h_flag = nullptr;      // pinned, host address
+    unsigned *d_flag = nullptr;      // the same word, device address
+    unsigned *d_done = nullptr;      // device: arrival counter of a launch's workgroups
+    unsigned flag_seq = 0;           // last sequence number handed to a launch
+    unsigned wait_seq = 0;           // != 0: the newest work on the stream is a flagged launch with this number
+    int flag_max_wgs = 1024;         // env GAT_SYNC_FLAG_WGS: largest launch that carries the flag (0: never)
     gat_channel_params *d_params = nullptr;
     size_t params_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -125,6 +134,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
                        int32_t B, int32_t K, int32_t L, const int32_t *shifts, double fs,
                        float *out_re, float *out_im, uint32_t flags)
 {
+    c->wait_seq = 0;
     if (!sig || !params_dev || !shifts || !out_re || !out_im) return fail(c, GAT_ERR_ARG, "null argument");
     if (!c->d_codes) return fail(c, GAT_ERR_STATE, "gat_set_codes has not been called");
     const int fmt = sig->layout;
@@ -422,6 +432,17 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     a.out_re = out_re;
     a.out_im = out_im;
     a.partial = c->d_partial;
+    a.total_wgs = (unsigned)(tiles * KG);
+    // completion flag: small launches outside a stream capture (a replayed graph would store a stale number)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(c->stream, &cap);
+    // (library-owned streams only: nobody else can have enqueued newer work on them behind the library's back)
+    const bool flagged = c->own_stream && c->d_flag && c->flag_max_wgs > 0 && tiles * KG <= c->flag_max_wgs && cap == hipStreamCaptureStatusNone;
+    (void)hipGetLastError();
+    auto next_seq = [&]() { // sequence numbers of flagged launches: never 0 (0 = "nothing to wait for")
+        if (++c->flag_seq == 0) ++c->flag_seq;
+        return c->flag_seq;
+    };
     a.N = N;
     a.ant_stride = sig->ant_stride;
     a.block_stride = sig->block_stride;
@@ -504,13 +525,22 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             const int d = a.shifts[l] - a.shifts[0];
             a.tap_off[l] = (d & 1) ? a.rep_copy_stride + d - 1 : d;
         }
+        // completion flag: carried by the call's last launch -- the last tap group's kernel, or the second stage behind it
+        const bool fin_follows = !atomic && splits > 1;
+        if (flagged && !fin_follows && t1 >= L) {
+            a.done_counter = c->d_done;
+            a.host_flag = c->d_flag;
+            a.flag_seq = next_seq();
+        }
         GAT_HIP(c, launch_dc(a, cfg, c->stream));
         t0 = t1;
     }
     const bool fin = !atomic && splits > 1;
-    if (fin)
-        GAT_HIP(c, launch_finalize(c->d_partial, out_re, out_im, (int)splits, L * M * 2, (long long)B * K,
-                                   c->stream));
+    if (fin) {
+        GAT_HIP(c, launch_finalize(c->d_partial, out_re, out_im, (int)splits, L * M * 2, (long long)B * K, c->stream,
+                                   flagged ? c->d_done : nullptr, c->d_flag, flagged ? next_seq() : 0u));
+    }
+    if (flagged) c->wait_seq = c->flag_seq;
 
     c->last.workgroups = (int32_t)cfg.grid;
     c->last.threads = 64 * nw;
@@ -573,6 +603,7 @@ int32_t graph_replay_or_record(gat_ctx *c, MakeKey make_key, Enqueue enqueue)
         const std::vector<unsigned char> key = make_key();
         for (auto &g : c->loop_graphs)
             if (g.exec && g.key == key) {
+                c->wait_seq = 0;
                 g.last_use = ++c->loop_graph_clock;
                 GAT_HIP(c, hipGraphLaunch(g.exec, c->stream));
                 return GAT_OK;
@@ -652,6 +683,14 @@ GAT_API int32_t gat_create(int32_t device, void *hip_stream, gat_ctx **out_ctx)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
     if (hipMalloc(&c->d_zeros, 64) == hipSuccess) (void)hipMemset(c->d_zeros, 0, 64);
+    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_flag), 64, hipHostMallocCoherent | hipHostMallocMapped) == hipSuccess) {
+        *c->h_flag = 0;
+        if (hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_flag), c->h_flag, 0) != hipSuccess) c->d_flag = nullptr;
+        if (c->d_flag && hipMalloc(reinterpret_cast<void **>(&c->d_done), 64) == hipSuccess) (void)hipMemset(c->d_done, 0, 64);
+        else c->d_flag = nullptr;
+    }
+    (void)hipGetLastError();
+    if (const char *e = std::getenv("GAT_SYNC_FLAG_WGS")) c->flag_max_wgs = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("GAT_NO_MFMA")) c->mc_mode = e[0] == '1' ? 0 : 1;
     if (const char *e = std::getenv("GAT_MAX_ANT_TILE")) c->max_ant_tile = std::min(kMaxAntTile, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("GAT_DC_AW")) c->max_aw = std::max(1, std::atoi(e));
@@ -681,6 +720,8 @@ GAT_API int32_t gat_destroy(gat_ctx *c)
     if (c->d_zeros) (void)hipFree(c->d_zeros);
     drop_loop_graphs(c);
     if (c->d_partial) (void)hipFree(c->d_partial);
+    if (c->d_done) (void)hipFree(c->d_done);
+    if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -693,6 +734,7 @@ GAT_API int32_t gat_set_stream(gat_ctx *c, void *hip_stream)
 {
     if (!c) return GAT_ERR_ARG;
     GAT_HIP(c, hipSetDevice(c->device));
+    c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
     GAT_HIP(c, hipStreamSynchronize(c->stream));
     drop_loop_graphs(c);
     if (c->own_stream) {
@@ -711,6 +753,23 @@ GAT_API int32_t gat_set_stream(gat_ctx *c, void *hip_stream)
 GAT_API int32_t gat_sync(gat_ctx *c)
 {
     if (!c) return GAT_ERR_ARG;
+    if (c->wait_seq && c->h_flag) {
+        // the newest work on the stream is a flagged correlator launch: its last workgroup stores wait_seq into pinned
+        // host memory after its results are out (system-scope release).  Launches of one stream finish in order, so
+        // the flag reaches wait_seq exactly when everything enqueued is done.  Bounded spin, then the ordinary wait.
+        const unsigned want = c->wait_seq;
+        c->wait_seq = 0;
+        timespec t0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (unsigned spins = 0;; ++spins) {
+            if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == want) return GAT_OK;
+            if ((spins & 255u) == 255u) {
+                timespec t1;
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 200000) break; // 200 us
+            }
+        }
+    }
     GAT_HIP(c, hipSetDevice(c->device));
     GAT_HIP(c, hipStreamSynchronize(c->stream));
     return GAT_OK;
@@ -868,6 +927,7 @@ static int32_t gen_code_replica_impl(gat_ctx *c, float *rep, int64_t count, int3
     if (!f32_coordinates && !code_span_ok(fc / fs, tau, (double)count + (double)std::llabs((long long)first_shift), c->Lc))
         return fail(c, GAT_ERR_RANGE, "code phase span too large");
     GAT_HIP(c, hipSetDevice(c->device));
+    c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
     GAT_HIP(c, launch_gen_code_replica(rep, count, c->d_codes + (size_t)prn * c->code_row_stride, c->Lc, fc, fs, tau,
                                        first_shift, f32_coordinates, c->stream));
     return GAT_OK;
@@ -893,6 +953,7 @@ GAT_API int32_t gat_gen_code_replica_multi(gat_ctx *c, float *rep, int64_t count
     if (count < 1 || K < 1 || K > 65535 || row_stride < count) return fail(c, GAT_ERR_ARG, "bad sizes");
     if (!(fs > 0.0) || count + std::llabs((long long)first_shift) >= (1ll << 30)) return fail(c, GAT_ERR_RANGE, "replica too long");
     GAT_HIP(c, hipSetDevice(c->device));
+    c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
     GAT_HIP(c, launch_gen_code_replica_multi(rep, count, row_stride, K, params_dev, c->d_codes, c->code_row_stride, c->Lc,
                                              c->P, fs, first_shift, c->stream));
     return GAT_OK;
@@ -917,6 +978,7 @@ GAT_API int32_t gat_downconvert_and_accumulate(gat_ctx *c, const gat_signal_desc
     if (!code_span_ok(p->code_freq_hz / fs, p->code_phase_chips, (double)(sig->num_samples + max_shift), c->Lc))
         return fail(c, GAT_ERR_RANGE, "code phase span too large");
     GAT_HIP(c, hipSetDevice(c->device));
+    c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
     // the tap list goes through the library's parameter scratch (device memory the kernel can read)
     const size_t need = ((size_t)L * sizeof(int32_t) + sizeof(gat_channel_params) - 1) / sizeof(gat_channel_params);
     if (need > c->params_cap) {
@@ -949,6 +1011,7 @@ GAT_API int32_t gat_gen_signal(gat_ctx *c, void *re, void *im, int32_t layout, i
     if (N < 1 || N >= (1ll << 30) || M < 1 || B < 1 || B > 65535 || K < 1) return fail(c, GAT_ERR_RANGE, "size out of range");
     if (!(fs > 0.0) || !std::isfinite(amplitude)) return fail(c, GAT_ERR_ARG, "bad sampling frequency / amplitude");
     GAT_HIP(c, hipSetDevice(c->device));
+    c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
     GAT_HIP(c, launch_gen_signal(re, im, layout, N, M, ant_stride, block_stride, B, K, params_dev, c->d_codes,
                                  c->code_row_stride, c->Lc, c->P, fs, (float)amplitude, c->stream));
     return GAT_OK;
@@ -960,6 +1023,7 @@ GAT_API int32_t gat_reduce_cplx_multi(gat_ctx *c, const float *in_re, const floa
     if (!c || !in_re || !in_im || !out_re || !out_im) return fail(c, GAT_ERR_ARG, "null argument");
     if (n < 1 || cols < 1 || cols > 65535) return fail(c, GAT_ERR_ARG, "sizes must be positive");
     GAT_HIP(c, hipSetDevice(c->device));
+    c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
     long long chunks = (n + 4 * kThreads - 1) / (4 * kThreads);
     const long long want = std::max<long long>(1, (4ll * c->num_cus + cols - 1) / cols);
     chunks = std::max<long long>(1, std::min(chunks, want));
@@ -985,6 +1049,7 @@ GAT_API int32_t gat_tracking_update(gat_ctx *c, const float *acc_re, const float
         !(cfg->early_late_spacing_chips > 0.0 && cfg->early_late_spacing_chips < 2.0))
         return fail(c, GAT_ERR_ARG, "bad loop configuration");
     GAT_HIP(c, hipSetDevice(c->device));
+    c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
     GAT_HIP(c, launch_tracking_update(acc_re, acc_im, K, M, *cfg, state, cur, next, c->stream));
     return GAT_OK;
 }
@@ -1051,6 +1116,7 @@ GAT_API int32_t gat_memcpy_h2d(gat_ctx *c, void *dst, const void *src, size_t by
 {
     if (!c || !dst || !src) return fail(c, GAT_ERR_ARG, "null argument");
     GAT_HIP(c, hipSetDevice(c->device));
+    c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
     GAT_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     GAT_HIP(c, hipStreamSynchronize(c->stream));
     return GAT_OK;
@@ -1060,6 +1126,7 @@ GAT_API int32_t gat_memcpy_d2h(gat_ctx *c, void *dst, const void *src, size_t by
 {
     if (!c || !dst || !src) return fail(c, GAT_ERR_ARG, "null argument");
     GAT_HIP(c, hipSetDevice(c->device));
+    c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
     GAT_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     GAT_HIP(c, hipStreamSynchronize(c->stream));
     return GAT_OK;
@@ -1069,6 +1136,7 @@ GAT_API int32_t gat_memset(gat_ctx *c, void *dst, int32_t value, size_t bytes)
 {
     if (!c || !dst) return fail(c, GAT_ERR_ARG, "null argument");
     GAT_HIP(c, hipSetDevice(c->device));
+    c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
     GAT_HIP(c, hipMemsetAsync(dst, value, bytes, c->stream));
     return GAT_OK;
 }
@@ -1077,6 +1145,7 @@ GAT_API int32_t gat_timer_start(gat_ctx *c)
 {
     if (!c) return GAT_ERR_ARG;
     GAT_HIP(c, hipSetDevice(c->device));
+    c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
     GAT_HIP(c, hipEventRecord(c->ev0, c->stream));
     c->timer_running = true;
     return GAT_OK;
@@ -1087,6 +1156,7 @@ GAT_API int32_t gat_timer_stop(gat_ctx *c, float *ms)
     if (!c || !ms) return fail(c, GAT_ERR_ARG, "null argument");
     if (!c->timer_running) return fail(c, GAT_ERR_STATE, "timer not started");
     GAT_HIP(c, hipSetDevice(c->device));
+    c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
     GAT_HIP(c, hipEventRecord(c->ev1, c->stream));
     GAT_HIP(c, hipEventSynchronize(c->ev1));
     GAT_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
@@ -1174,6 +1244,7 @@ GAT_API int32_t gat_memcpy_peer(gat_ctx *dst_ctx, void *dst_dev, gat_ctx *src_ct
 {
     if (!dst_ctx || !src_ctx || !dst_dev || !src_dev) return fail(dst_ctx, GAT_ERR_ARG, "null argument");
     if (bytes == 0) return GAT_OK;
+    dst_ctx->wait_seq = 0;
     // order: everything enqueued so far on the SOURCE stream (the upload / generator that fills src) completes before
     // the copy, which runs on the DESTINATION stream (its correlator launches follow in stream order)
     hipEvent_t ev = nullptr;

@@ -191,6 +191,26 @@ struct SampleIO {
 };
 
 
+// Completion flag (latency regime): the last workgroup of a launch to get here stores the call's sequence number into
+// pinned host memory, where gat_sync spins on it -- a kernel's end reaches the host ~5 us sooner that way than through
+// hipStreamSynchronize (scripts/sync_probe.hip: 7.0 vs 11.7 us for an empty kernel).  Called by every thread of every
+// workgroup that did work, after its result stores.
+__device__ __forceinline__ void completion_flag(unsigned *done_counter, unsigned *host_flag, unsigned seq, unsigned total_wgs)
+{
+    if (!done_counter) return; // launch-uniform
+    __syncthreads(); // every thread of this workgroup has issued its result stores
+    if (threadIdx.x == 0) {
+        // this XCD's L2 holds the workgroup's results: written back before it counts as arrived (the host may hand the
+        // buffers to a copy engine or another stream as soon as it sees the flag)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned arrived = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == total_wgs - 1u) {
+            __hip_atomic_store(done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // Occupancy hint: instances with up to 40 accumulator registers come out at 125-165 registers; asking for three waves
 // per SIMD (<= 168) costs them nothing, while the four-antenna five-tap instance otherwise lands ONE register over
 // that step.  No bound for the larger instances, and never a tighter one: the allocator then spills into the step loop
@@ -799,6 +819,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
         // the next block's s_const / table writes come after this barrier-separated reduction: the threads that still
         // read s_part above do not touch s_const, s_rep or s_code
     }
+    completion_flag(a.done_counter, a.host_flag, a.flag_seq, a.total_wgs);
 }
 
 // ------------------------------------------------------------------------------------------------------------

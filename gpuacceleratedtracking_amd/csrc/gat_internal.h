@@ -42,6 +42,9 @@ struct DcArgs {
     float *out_re;                    // dev, [B][K][Ltot][M]
     float *out_im;
     float *partial;                   // dev, [B*K][splits][Ltot*M*2] (splits > 1 only)
+    unsigned *done_counter;           // dev, arrival counter of the launch's workgroups, or null: no completion flag
+    unsigned *host_flag;              // pinned host memory (device address): the last workgroup stores flag_seq there
+    unsigned flag_seq, total_wgs;     // total_wgs: workgroups that do work (num_tiles * KG)
     long long N, ant_stride, block_stride, chan_stride;
     double fs;
     int M, K, B, Lc, num_prns, code_row_stride;
@@ -164,8 +167,10 @@ int mfma_bf16_producer_threads(int rt, int nct);
 hipError_t launch_dc(const DcArgs &a, const DcLaunch &cfg, hipStream_t s);
 // one translation unit per sample format (gat_dc_f*.hip), so that the instances compile in parallel
 template <int FMT> hipError_t launch_dc_fmt(const DcArgs &a, const DcLaunch &cfg, hipStream_t s);
+// done_counter != null: the launch ends by storing flag_seq into host_flag (completion flag, see gat_dc.h)
 hipError_t launch_finalize(const float *partial, float *out_re, float *out_im, int splits, int elems,
-                           long long groups, hipStream_t s);
+                           long long groups, hipStream_t s, unsigned *done_counter = nullptr, unsigned *host_flag = nullptr,
+                           unsigned flag_seq = 0);
 hipError_t launch_gen_code_replica(float *rep, long long count, const int8_t *code_row, int Lc,
                                    double fc, double fs, double tau, long long first_shift,
                                    bool f32_coordinates, hipStream_t s);

@@ -11,21 +11,24 @@ namespace gat {
 // partial [groups][splits][elems], elems = cols*2 with re/im interleaved innermost.
 __global__ void __launch_bounds__(kThreads)
 finalize_kernel(const float *__restrict__ partial, float *__restrict__ out_re,
-                float *__restrict__ out_im, int splits, int elems, long long groups)
+                float *__restrict__ out_im, int splits, int elems, long long groups, unsigned *done_counter,
+                unsigned *host_flag, unsigned flag_seq)
 {
     const long long wave_id = (long long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-    if (wave_id >= groups * elems) return;
-    const int lane = threadIdx.x & 63;
-    const long long g = wave_id / elems;
-    const int e = (int)(wave_id - g * elems);
-    const float *p = partial + (size_t)g * splits * elems + e;
-    float s = 0.f;
-    for (int i = lane; i < splits; i += 64) s += p[(size_t)i * elems];
-    s = wave_sum(s);
-    if (lane == 0) {
-        float *o = (e & 1) ? out_im : out_re;
-        o[(size_t)g * (elems / 2) + (e >> 1)] = s;
+    if (wave_id < groups * elems) {
+        const int lane = threadIdx.x & 63;
+        const long long g = wave_id / elems;
+        const int e = (int)(wave_id - g * elems);
+        const float *p = partial + (size_t)g * splits * elems + e;
+        float s = 0.f;
+        for (int i = lane; i < splits; i += 64) s += p[(size_t)i * elems];
+        s = wave_sum(s);
+        if (lane == 0) {
+            float *o = (e & 1) ? out_im : out_re;
+            o[(size_t)g * (elems / 2) + (e >> 1)] = s;
+        }
     }
+    completion_flag(done_counter, host_flag, flag_seq, gridDim.x);
 }
 
 // Few splits (what the fused kernels leave behind: 2-16 per group): one THREAD per output element, its splits summed
@@ -35,26 +38,29 @@ finalize_kernel(const float *__restrict__ partial, float *__restrict__ out_re,
 // 3 MB of partials, 40 us of a 0.72 ms step).
 __global__ void __launch_bounds__(kThreads)
 finalize_few_kernel(const float *__restrict__ partial, float *__restrict__ out_re,
-                    float *__restrict__ out_im, int splits, int elems, long long total)
+                    float *__restrict__ out_im, int splits, int elems, long long total, unsigned *done_counter,
+                    unsigned *host_flag, unsigned flag_seq)
 {
     const long long o = (long long)blockIdx.x * kThreads + threadIdx.x;
-    if (o >= total) return;
-    const long long g = o / elems;
-    const int e = (int)(o - g * elems);
-    const float *p = partial + (size_t)g * splits * elems + e;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int i = 0;
-    for (; i + 4 <= splits; i += 4) {
-        s0 += p[(size_t)(i + 0) * elems];
-        s1 += p[(size_t)(i + 1) * elems];
-        s2 += p[(size_t)(i + 2) * elems];
-        s3 += p[(size_t)(i + 3) * elems];
+    if (o < total) {
+        const long long g = o / elems;
+        const int e = (int)(o - g * elems);
+        const float *p = partial + (size_t)g * splits * elems + e;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int i = 0;
+        for (; i + 4 <= splits; i += 4) {
+            s0 += p[(size_t)(i + 0) * elems];
+            s1 += p[(size_t)(i + 1) * elems];
+            s2 += p[(size_t)(i + 2) * elems];
+            s3 += p[(size_t)(i + 3) * elems];
+        }
+        if (i < splits) s0 += p[(size_t)i * elems];
+        if (i + 1 < splits) s1 += p[(size_t)(i + 1) * elems];
+        if (i + 2 < splits) s2 += p[(size_t)(i + 2) * elems];
+        float *out = (e & 1) ? out_im : out_re;
+        out[(size_t)g * (elems / 2) + (e >> 1)] = (s0 + s1) + (s2 + s3);
     }
-    if (i < splits) s0 += p[(size_t)i * elems];
-    if (i + 1 < splits) s1 += p[(size_t)(i + 1) * elems];
-    if (i + 2 < splits) s2 += p[(size_t)(i + 2) * elems];
-    float *out = (e & 1) ? out_im : out_re;
-    out[(size_t)g * (elems / 2) + (e >> 1)] = (s0 + s1) + (s2 + s3);
+    completion_flag(done_counter, host_flag, flag_seq, gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -336,17 +342,17 @@ hipError_t launch_dc(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)
 }
 
 hipError_t launch_finalize(const float *partial, float *out_re, float *out_im, int splits, int elems,
-                           long long groups, hipStream_t s)
+                           long long groups, hipStream_t s, unsigned *done_counter, unsigned *host_flag, unsigned flag_seq)
 {
     const long long waves = groups * elems;
     if (splits <= kFinalizeFewSplits) { // one thread per output element
         hipLaunchKernelGGL(finalize_few_kernel, dim3((unsigned)((waves + kThreads - 1) / kThreads)), dim3(kThreads), 0, s,
-                           partial, out_re, out_im, splits, elems, waves);
+                           partial, out_re, out_im, splits, elems, waves, done_counter, host_flag, flag_seq);
         return hipGetLastError();
     }
     const unsigned grid = (unsigned)((waves + kThreads / 64 - 1) / (kThreads / 64));
     hipLaunchKernelGGL(finalize_kernel, dim3(grid), dim3(kThreads), 0, s, partial, out_re, out_im,
-                       splits, elems, groups);
+                       splits, elems, groups, done_counter, host_flag, flag_seq);
     return hipGetLastError();
 }
 

@@ -35,6 +35,7 @@ def run_hip(g, case, layout=0, flags=0, start_misalign=0):
     op.set_params(prm)
     if layout == 0:
         op(re, im)
+        op.last_signal = (re, im)  # kept for tests that launch again on the same buffers
     else:
         x = torch.stack([re, im], dim=-1).contiguous()
         op(x, None)
@@ -147,6 +148,27 @@ def test_split_and_finalize_path_deterministic(gat):
     check_close(got1, oracle_result(case), what="split")
     got2, _ = run_hip(gat, case)
     assert np.array_equal(got1.view(np.float32), got2.view(np.float32))
+
+
+@pytest.mark.parametrize("N,M,K,B,L", [(120000, 16, 4, 3, 3), (65536 + 4, 4, 3, 5, 5), (300000, 1, 1, 1, 3), (49996, 2, 7, 2, 7),
+                                       (30000, 16, 9, 2, 3)])
+def test_split_second_stage_soak(gat, N, M, K, B, L):
+    """Split blocks (two-stage sum, one thread per output element in the second stage): many groups, ragged last splits,
+    channel-looping and antenna-parallel tilings -- equal to the oracle, and forty repeated launches on the same buffers
+    bit-identical."""
+    import torch
+    g = gat
+    case = make_case(900 + M + K, N=N, M=M, K=K, B=B, L=L, fs=N / 1e-3)
+    got, op = run_hip(g, case)
+    info = op.ctx.last_launch_info()
+    assert info["matrix_core"] == 0 and info["splits"] > 1 and info["finalize_launched"] == 1, info
+    check_close(got, oracle_result(case), what="split second stage")
+    ref_re, ref_im = op.out_re.clone(), op.out_im.clone()
+    for i in range(40):
+        op.out_re.fill_(float("nan"))
+        op.out_im.fill_(float("nan"))
+        op(*op.last_signal)
+        assert torch.equal(op.out_re, ref_re) and torch.equal(op.out_im, ref_im), i
 
 
 def test_atomic_mode(gat):
