@@ -114,15 +114,34 @@ def self_launch(n: int) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # poll ALL children: the first one that fails takes the others down with it (they would otherwise sit in the
+    # rendezvous / barrier until the deadline), and so does the deadline.  Only the exact children started above.
     rc = 0
     deadline = time.time() + float(os.environ.get("GAT_BENCH_LAUNCH_TIMEOUT", "1500"))
-    for p in procs:
-        try:
-            code = p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()  # the exact child this process started
-            code = 124
-        rc = rc or code
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+        if live and (rc != 0 or time.time() > deadline):
+            if rc == 0:
+                rc = 124
+            for p in live:
+                p.terminate()
+            t_kill = time.time() + 5.0
+            for p in live:
+                try:
+                    p.wait(timeout=max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            live = []
+        elif live:
+            time.sleep(0.05)
     return rc
 
 
@@ -237,7 +256,7 @@ def algorithmic_flops(B, N, M, L, K) -> float:
     return float(B) * N * K * (30.0 + M * (8.0 + 4.0 * L))
 
 
-def roofline(shape, launch_s, matrix_core, traffic):
+def roofline(shape, launch_s, matrix_core, traffic_and_source):
     """max(bytes / HBM peak, flops / compute peak) vs the measured launch duration; names the winning term."""
     import gpuacceleratedtracking_amd as g
 
@@ -246,8 +265,9 @@ def roofline(shape, launch_s, matrix_core, traffic):
     flops = algorithmic_flops(B, N, M, L, K)
     t_hbm = alg_bytes / (HBM_PEAK_GBS * 1e9)
     t_f32 = flops / (F32_PEAK_TFLOPS * 1e12)
+    traffic, traffic_source = traffic_and_source
     out = {"algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": flops,
-           "kernel_ms_per_launch": round(launch_s * 1e3, 6), "traffic": traffic,
+           "kernel_ms_per_launch": round(launch_s * 1e3, 6), "traffic": traffic, "traffic_source": traffic_source,
            "terms_ms": {"hbm": round(t_hbm * 1e3, 6), "f32_flops": round(t_f32 * 1e3, 6)},
            "kernel": {0: "dc_kernel (vector)", 1: "mfma_kernel (f32 MFMA)", 2: "mfma_bf16_kernel (split-bf16 MFMA)"}.get(matrix_core, "?")}
     if t_hbm >= t_f32:
@@ -269,17 +289,19 @@ def roofline(shape, launch_s, matrix_core, traffic):
 
 def stored_traffic(key):
     """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the microarchitecture guide), keyed by workload."""
+    --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the microarchitecture guide), keyed by workload.  NOT a
+    counter of this run (a PMC pass needs the profiler around the process): returns (bytes, where they come from)."""
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(tpath) as f:
             tj = json.load(f)
         for e in tj.get("entries", [tj]):
             if e.get("workload_key") == key:
-                return e.get("hbm_bytes_per_launch")
+                return e.get("hbm_bytes_per_launch"), (f"stored: profiles/pmc_traffic.json <- {tj.get('source', '?')}, kernel "
+                                                       f"{e.get('kernel', '?')} (2 x FETCH_SIZE + WRITE_SIZE; not measured in this run)")
     except Exception:
         pass
-    return None
+    return None, "none: no stored PMC pass for this workload"
 
 
 def measure(args, g, torch, dist, world, rank, shape_kw, steps, warmup, settle, want_host_copy):
@@ -337,19 +359,23 @@ def parity_check(g, m):
     B, N, M, L, K, layout = m["shape"]
     sig, op, prm = m["sig"], m["op"], m["prm"]
     host_blocks = min(B, 512)
-    if layout == g.GAT_LAYOUT_PLANAR:
-        h_re = sig[0][:, :host_blocks * N].cpu().numpy()
-        h_im = sig[1][:, :host_blocks * N].cpu().numpy()
-    else:
-        h = sig[0][:, :host_blocks * N, :].cpu().numpy().astype(np.float32)  # ints convert exactly
-        h_re, h_im = np.ascontiguousarray(h[..., 0]), np.ascontiguousarray(h[..., 1])
+
+    def host_copy(b0, nb):
+        if layout == g.GAT_LAYOUT_PLANAR:
+            return sig[0][:, b0 * N:(b0 + nb) * N].cpu().numpy(), sig[1][:, b0 * N:(b0 + nb) * N].cpu().numpy()
+        h = sig[0][:, b0 * N:(b0 + nb) * N, :].cpu().numpy().astype(np.float32)  # ints convert exactly
+        return np.ascontiguousarray(h[..., 0]), np.ascontiguousarray(h[..., 1])
+
+    h_re, h_im = host_copy(0, host_blocks)
     got = op.result()
     oprm = oracle.make_params(prm["prn"], prm["code_freq_hz"], prm["carrier_freq_hz"],
                               prm["code_phase_chips"], prm["carrier_phase_cycles"])
     nchk = min(2, host_blocks)
-    ref = oracle.correlate_f64(h_re[:, :nchk * N], h_im[:, :nchk * N], op.system.codes, oprm[:nchk], m["fs"],
-                               op.shifts, N=N)
-    err = float(np.max(np.abs(got[:nchk] - ref) / np.abs(ref).max(axis=(2, 3), keepdims=True)))
+    err = 0.0
+    for b0 in sorted({0, max(0, B - nchk)}):  # the first and the last blocks of the launch
+        c_re, c_im = (h_re[:, :nchk * N], h_im[:, :nchk * N]) if b0 == 0 else host_copy(b0, nchk)
+        ref = oracle.correlate_f64(c_re, c_im, op.system.codes, oprm[b0:b0 + nchk], m["fs"], op.shifts, N=N)
+        err = max(err, float(np.max(np.abs(got[b0:b0 + nchk] - ref) / np.abs(ref).max(axis=(2, 3), keepdims=True))))
     return err, h_re, h_im
 
 
@@ -373,6 +399,9 @@ def main():
         sys.exit(2)
     if os.environ.get("GAT_BENCH_DRYRUN") == "1":
         # launcher rehearsal without a GPU (tests/test_bench_launcher.py): rendezvous, barrier, gather, one line
+        if os.environ.get("GAT_BENCH_DRYRUN_FAIL_RANK") == str(rank):  # rehearsal of a rank that dies before the rendezvous
+            print(f"bench.py: rank {rank} fails on request", file=sys.stderr)
+            sys.exit(3)
         import torch.distributed as dist
         dist.init_process_group(backend="gloo")
         t = torch.tensor([float(rank)], dtype=torch.float64)

@@ -36,7 +36,7 @@ def _flags(extra: tuple[str, ...] = ()) -> list[str]:
 def command(out: str = LIB) -> list[str]:
     """The one-line recipe (what INTEGRATION.md quotes); build_libgat() runs the same flags per source
     so that an edit to one kernel file does not recompile the others."""
-    return [hipcc_path(), *_flags(), "-fno-slp-vectorize", "-shared", *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
+    return [hipcc_path(), *_flags(), "-fno-slp-vectorize", "-shared", *[os.path.join(CSRC, s) for s in SOURCES], "-ldl", "-o", out]
 
 
 def is_stale(lib: str = LIB) -> bool:
@@ -87,7 +87,7 @@ def build_libgat(force: bool = False, verbose: bool = False, extra_flags: tuple[
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
         list(ex.map(run, jobs))
-    run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out])
+    run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", out])
     return out
 
 

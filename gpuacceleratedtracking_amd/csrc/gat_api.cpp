@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <dlfcn.h>
 #include <new>
 #include <string>
 #include <vector>
@@ -71,6 +72,40 @@ struct gat_ctx {
 };
 
 namespace {
+
+// Tracing ranges around the library's launch sequences (the reference wraps every launch of kernel_algorithm in
+// NVTX.@range, src/algorithms.jl:953, :973 ... :1526): roctxRangePush / Pop from librocprofiler-sdk-roctx, resolved at
+// the first use so that the library has no link-time dependency on the profiler SDK; no-ops when it is not installed.
+// Ranges show up in rocprofv3 --marker-trace.  GAT_ROCTX=0 disables the lookup.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char *e = std::getenv("GAT_ROCTX");
+        if (e && e[0] == '0') return;
+        void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_LAZY | RTLD_LOCAL);
+        if (!h) h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_LAZY | RTLD_LOCAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_LOCAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+struct TraceRange { // RAII: one range per launch sequence of an entry point
+    explicit TraceRange(const char *name)
+    {
+        static const Roctx r; // resolved once, thread-safe
+        rx = &r;
+        if (rx->push) (void)rx->push(name);
+    }
+    ~TraceRange()
+    {
+        if (rx->pop) (void)rx->pop();
+    }
+    const Roctx *rx;
+};
 
 constexpr size_t kMaxLoopGraphs = 4;
 
@@ -135,6 +170,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
                        float *out_re, float *out_im, uint32_t flags)
 {
     c->wait_seq = 0;
+    const TraceRange trace("gat_downconvert_and_correlate");
     if (!sig || !params_dev || !shifts || !out_re || !out_im) return fail(c, GAT_ERR_ARG, "null argument");
     if (!c->d_codes) return fail(c, GAT_ERR_STATE, "gat_set_codes has not been called");
     const int fmt = sig->layout;
@@ -928,6 +964,7 @@ static int32_t gen_code_replica_impl(gat_ctx *c, float *rep, int64_t count, int3
         return fail(c, GAT_ERR_RANGE, "code phase span too large");
     GAT_HIP(c, hipSetDevice(c->device));
     c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
+    const TraceRange trace("gat_gen_code_replica");
     GAT_HIP(c, launch_gen_code_replica(rep, count, c->d_codes + (size_t)prn * c->code_row_stride, c->Lc, fc, fs, tau,
                                        first_shift, f32_coordinates, c->stream));
     return GAT_OK;
@@ -954,6 +991,7 @@ GAT_API int32_t gat_gen_code_replica_multi(gat_ctx *c, float *rep, int64_t count
     if (!(fs > 0.0) || count + std::llabs((long long)first_shift) >= (1ll << 30)) return fail(c, GAT_ERR_RANGE, "replica too long");
     GAT_HIP(c, hipSetDevice(c->device));
     c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
+    const TraceRange trace("gat_gen_code_replica_multi");
     GAT_HIP(c, launch_gen_code_replica_multi(rep, count, row_stride, K, params_dev, c->d_codes, c->code_row_stride, c->Lc,
                                              c->P, fs, first_shift, c->stream));
     return GAT_OK;
@@ -979,6 +1017,7 @@ GAT_API int32_t gat_downconvert_and_accumulate(gat_ctx *c, const gat_signal_desc
         return fail(c, GAT_ERR_RANGE, "code phase span too large");
     GAT_HIP(c, hipSetDevice(c->device));
     c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
+    const TraceRange trace("gat_downconvert_and_accumulate");
     // the tap list goes through the library's parameter scratch (device memory the kernel can read)
     const size_t need = ((size_t)L * sizeof(int32_t) + sizeof(gat_channel_params) - 1) / sizeof(gat_channel_params);
     if (need > c->params_cap) {
@@ -1012,6 +1051,7 @@ GAT_API int32_t gat_gen_signal(gat_ctx *c, void *re, void *im, int32_t layout, i
     if (!(fs > 0.0) || !std::isfinite(amplitude)) return fail(c, GAT_ERR_ARG, "bad sampling frequency / amplitude");
     GAT_HIP(c, hipSetDevice(c->device));
     c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
+    const TraceRange trace("gat_gen_signal");
     GAT_HIP(c, launch_gen_signal(re, im, layout, N, M, ant_stride, block_stride, B, K, params_dev, c->d_codes,
                                  c->code_row_stride, c->Lc, c->P, fs, (float)amplitude, c->stream));
     return GAT_OK;
@@ -1024,6 +1064,7 @@ GAT_API int32_t gat_reduce_cplx_multi(gat_ctx *c, const float *in_re, const floa
     if (n < 1 || cols < 1 || cols > 65535) return fail(c, GAT_ERR_ARG, "sizes must be positive");
     GAT_HIP(c, hipSetDevice(c->device));
     c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
+    const TraceRange trace("gat_reduce_cplx_multi");
     long long chunks = (n + 4 * kThreads - 1) / (4 * kThreads);
     const long long want = std::max<long long>(1, (4ll * c->num_cus + cols - 1) / cols);
     chunks = std::max<long long>(1, std::min(chunks, want));
@@ -1050,6 +1091,7 @@ GAT_API int32_t gat_tracking_update(gat_ctx *c, const float *acc_re, const float
         return fail(c, GAT_ERR_ARG, "bad loop configuration");
     GAT_HIP(c, hipSetDevice(c->device));
     c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
+    const TraceRange trace("gat_tracking_update");
     GAT_HIP(c, launch_tracking_update(acc_re, acc_im, K, M, *cfg, state, cur, next, c->stream));
     return GAT_OK;
 }
@@ -1065,6 +1107,7 @@ GAT_API int32_t gat_tracking_run(gat_ctx *c, const gat_signal_desc *sig, int32_t
     if (cfg->num_taps != L || L < 1 || L > GAT_MAX_TAPS) return fail(c, GAT_ERR_ARG, "loop configuration and tap list disagree");
     if (flags & ~(GAT_FLAG_ATOMIC | GAT_FLAG_GRAPH)) return fail(c, GAT_ERR_ARG, "unknown flag bits");
     GAT_HIP(c, hipSetDevice(c->device));
+    const TraceRange trace("gat_tracking_run");
     const uint32_t kflags = flags & ~GAT_FLAG_GRAPH;
     if (!(flags & GAT_FLAG_GRAPH))
         return tracking_run_enqueue(c, sig, num_blocks, K, L, shifts, fs, cfg, state, params_a, params_b, acc_re, acc_im,

@@ -80,6 +80,12 @@ typedef struct gat_channel_params {
 /* Device-resident antenna signal; replaces signal.re / signal.im (CuArray{Float32,2} or ,3)
  * handed to kernel_algorithm (src/algorithms.jl:887-888) -- element (n, m, b, k) lives at
  *   n + m*ant_stride + b*block_stride + k*chan_stride          (in samples). */
+/* Fast path requirements (checked per call; a signal that misses them is still correlated, by the scalar-load kernel --
+ * one antenna per wave, a double-precision sincos per sample, typically 5-10x slower; gat_launch_info.vec tells which ran):
+ * plane base pointers 16-byte aligned, and ant_stride, block_stride, chan_stride AND num_samples multiples of the samples
+ * one 16-byte load holds -- 4 (planar float), 2 (ComplexF32 pairs), 4 (int16 pairs), 8 (int8 pairs).  A receiver whose
+ * block length is not such a multiple (e.g. N = 2046) pads its blocks: block_stride up to the next multiple, num_samples
+ * down to the previous one plus a short second call, or simply N + pad zeros. */
 typedef struct gat_signal_desc {
     const void *re;       /* dev; planar: float real plane. interleaved formats: base pointer */
     const void *im;       /* dev; planar: float imaginary plane. interleaved formats: NULL    */

@@ -1,52 +1,57 @@
 #!/usr/bin/env python3
-"""profiles/pmc_traffic.json from the summary of scripts/r02_profile_configs.sh (the `<tag>_fetch {...}` / `<tag>_write {...}`
-lines): HBM bytes per launch = 2 * FETCH_SIZE KB (gfx950 correction of MI355X_MICROARCH.md for 16-B/lane streaming reads)
-+ WRITE_SIZE KB, against bench.py's algorithmic bytes of the same workload.
-usage: scripts/make_pmc_traffic.py profiles/r02/r02r_final_rocprofv3_and_pmc_summary.txt"""
+"""profiles/pmc_traffic.json from the summary of scripts/r03_profile_configs.sh (lines `<tag> fetch <kernel> {...}` /
+`<tag> write <kernel> {...}` written by scripts/r03_pmc.sh): HBM bytes per launch = 2 * FETCH_SIZE KB (gfx950 correction of
+MI355X_MICROARCH.md for 16-B/lane streaming reads) + WRITE_SIZE KB, against bench.py's algorithmic bytes of the same
+workload.  The kernel label is the full instance name rocprofv3 reports (all template arguments).
+usage: scripts/make_pmc_traffic.py profiles/r03/r03p_summary.txt"""
 import ast
 import json
+import os
 import re
 import sys
-import os
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import gpuacceleratedtracking_amd.benchmarks as gb  # algorithmic_bytes (host arithmetic only)
 
-WORK = {  # tag -> (workload key of bench.py's stored_traffic, kernel)
-    "c2": (["GPSL1", 20000, 4, 3, 1, 4096, "planar"], "dc_kernel<4,3,4,0,1,1,nt,4 waves>"),
-    "c3": (["GPSL5", 50000, 4, 5, 12, 1024, "planar"], "dc_kernel<4,5,4,0,1,1,keep,4 waves>"),
-    "c4": (["GPSL1", 50000, 16, 3, 4, 512, "planar"], "dc_kernel<4,3,4,0,4,4,nt,4 waves> (+ finalize_kernel)"),
-    "c5": (["GPSL1", 2000000, 64, 3, 64, 1, "planar"], "mfma_bf16_kernel<4,4,0> (+ finalize_kernel)"),
-    "c1shape": (["GPSL1", 4000, 1, 3, 1, 16384, "planar"], "dc_kernel<1,3,4,0,1,1,nt,1 wave>"),
+WORK = {  # tag -> (workload key of bench.py's stored_traffic, bytes per complex sample)
+    "c2": (["GPSL1", 20000, 4, 3, 1, 4096, "planar"], 8),
+    "c3": (["GPSL5", 50000, 4, 5, 12, 1024, "planar"], 8),
+    "c4": (["GPSL1", 50000, 16, 3, 4, 512, "planar"], 8),
+    "c5": (["GPSL1", 2000000, 64, 3, 64, 1, "planar"], 8),
+    "c1shape": (["GPSL1", 4000, 1, 3, 1, 16384, "planar"], 8),
+    "c2_i16": (["GPSL1", 20000, 4, 3, 1, 4096, "i16"], 4),
+    "c2_i8": (["GPSL1", 20000, 4, 3, 1, 4096, "i8"], 2),
 }
 
 
 def main(path):
     vals = {}
     for line in open(path):
-        m = re.match(r"^(\w+)_(fetch|write) (\{.*\})\s*$", line)
+        m = re.match(r"^(\w+) (fetch|write) (.*?) (\{.*\})\s*$", line)
         if m:
-            vals.setdefault(m.group(1), {})[m.group(2)] = ast.literal_eval(m.group(3))
+            vals.setdefault(m.group(1), {})[m.group(2)] = (m.group(3), ast.literal_eval(m.group(4)))
     entries = []
-    for tag, (key, kernel) in WORK.items():
-        if tag not in vals:
+    for tag, (key, sample_bytes) in WORK.items():
+        if tag not in vals or "fetch" not in vals[tag] or "write" not in vals[tag]:
             continue
-        f = vals[tag]["fetch"]["FETCH_SIZE"]
-        w = vals[tag]["write"]["WRITE_SIZE"]
+        kernel, fd = vals[tag]["fetch"]
+        f = fd["FETCH_SIZE"]
+        w = vals[tag]["write"][1]["WRITE_SIZE"]
         _, N, M, L, K, B, _ = key
-        alg = gb.algorithmic_bytes(B, N, M, L, K)
+        alg = gb.algorithmic_bytes(B, N, M, L, K, sample_bytes)
         hbm = int(round((2 * f + w) * 1024))
-        entries.append({"workload_key": key, "kernel": kernel, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
+        entries.append({"workload_key": key, "kernel": kernel.strip(), "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
                         "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "ratio": round(hbm / alg, 4)})
-    out = {"how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python bench.py --steps 4 --warmup 1 "
-                  "--settle 2 [--baseline-config i]` (scripts/r02_profile_configs.sh -> " + os.path.basename(path) + "); per-dispatch "
-                  "counter values of the correlator kernel, mean of the last three dispatches; FETCH_SIZE (KB) doubled as "
-                  "MI355X_MICROARCH.md prescribes for gfx950 16-B/lane streaming reads, WRITE_SIZE (KB) as reported "
-                  "(scripts/make_pmc_traffic.py)",
+    out = {"how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python bench.py --steps 6 --warmup 40 "
+                  "--settle 64 [shape flags]` (scripts/r03_pmc.sh, driven by scripts/r03_profile_configs.sh -> "
+                  + os.path.basename(path) + "); per-dispatch counter values of the correlator kernel named in `kernel`, mean of the "
+                  "last four dispatches; FETCH_SIZE (KB) doubled as MI355X_MICROARCH.md prescribes for gfx950 16-B/lane streaming "
+                  "reads, WRITE_SIZE (KB) as reported (scripts/make_pmc_traffic.py)",
+           "source": "profiles/r03/" + os.path.basename(path),
            "entries": entries}
     json.dump(out, open(os.path.join(os.path.dirname(__file__), "..", "profiles", "pmc_traffic.json"), "w"), indent=1)
     for e in entries:
-        print(e["workload_key"], e["ratio"])
+        print(e["workload_key"], e["kernel"], e["ratio"])
 
 
 if __name__ == "__main__":

@@ -10,12 +10,13 @@ sets="fetch write sq1 sq2 clk"
 if [ "$1" != "--" ]; then sets=$1; shift; fi
 shift
 OUT=$REPO/gpurun_out/r03; mkdir -p $OUT
+RAW=$(mktemp -d /tmp/r03pmc.XXXXXX)  # raw counter csv: scratch, only the averaged lines are kept
 export TMPDIR=/tmp
 cd /tmp
 pmc() { # set counters args...
   s=$1; cnt=$2; shift; shift
-  timeout -k 10 240 rocprofv3 --pmc $cnt --kernel-trace --output-format csv -d $OUT/pmc_${tag}_$s -- python3 $REPO/bench.py --no-cpu-baseline --steps 6 --warmup 40 --settle 64 "$@" > $OUT/pmc_${tag}_$s.json 2> $OUT/pmc_${tag}_$s.log
-  python3 - $OUT/pmc_${tag}_$s $tag $s <<'PY' | tee -a $OUT/pmc_$tag.txt
+  timeout -k 10 240 rocprofv3 --pmc $cnt --kernel-trace --output-format csv -d $RAW/pmc_${tag}_$s -- python3 $REPO/bench.py --no-cpu-baseline --steps 6 --warmup 40 --settle 64 "$@" > $OUT/pmc_${tag}_$s.json 2> $OUT/pmc_${tag}_$s.log
+  python3 - $RAW/pmc_${tag}_$s $tag $s <<'PY' | tee -a $OUT/pmc_$tag.txt
 import csv, glob, os, sys
 acc={}; name=None
 for f in glob.glob(os.path.join(sys.argv[1],"**","*counter_collection.csv"),recursive=True):

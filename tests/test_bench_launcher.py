@@ -42,6 +42,18 @@ def test_external_launcher_two_ranks():
     assert rec["n_gpus"] == 2 and rec["ranks_seen"] == [0, 1]
 
 
+def test_self_launch_ends_soon_when_one_rank_dies():
+    """a rank that exits early (missing device, import error) must not leave its siblings in the rendezvous
+    until the launch deadline -- the launcher polls all children, terminates the survivors and returns the failure."""
+    import time
+    env = dict(_env(), GAT_BENCH_DRYRUN_FAIL_RANK="1", GAT_BENCH_LAUNCH_TIMEOUT="600")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 3, (p.returncode, p.stderr[-500:])
+    assert time.time() - t0 < 120  # not the 600 s deadline
+
+
 def test_world_size_mismatch_is_an_error():
     env = dict(_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)

@@ -298,3 +298,58 @@ def test_two_sample_sets_match_the_oracle_and_one_set(gat, shape, layout, monkey
             check_close(outs[0][sel], oracle_result(sub), what=f"{shape} layout {layout} blocks {sel}")
     else:
         check_close(outs[0], oracle_result(small), what=f"{shape} layout {layout}")
+
+
+@pytest.mark.parametrize("N,M,layout", [(4002, 4, "planar"), (2501, 2, "planar"), (4004, 1, "i8")])
+def test_ragged_block_length_takes_the_scalar_kernel_and_padding_restores_the_vector_kernel(gat, N, M, layout):
+    """the 16-byte vector path needs num_samples to be a multiple of the samples one load holds (include/gat.h,
+    gat_signal_desc).  A block length that is not (aligned strides otherwise) is served by the scalar-load kernel -- still
+    equal to the oracle, and launch_info.vec says so; the documented remedy, zero padding up to the next multiple, gives
+    the same result from the vector kernel (zeros add nothing) and is several times faster."""
+    import time
+
+    import torch
+    g = gat
+    case = make_case(321 + N, N=N, M=M, K=2, B=4, L=3)
+    sysobj = g.GNSSDICT[case["system"]](use_gpu=True)
+    dev = g.get_context().device
+    prm = g.make_params(case["prm"]["prn0"], case["prm"]["code_freq_hz"], case["prm"]["carrier_freq_hz"],
+                        case["prm"]["code_phase_chips"], case["prm"]["carrier_phase_cycles"])
+    B = case["B"]
+    spv = 8 if layout == "i8" else 4
+    Np = (N + spv - 1) // spv * spv
+    # blocks stored Np apart (aligned strides); the operator is told N (ragged) or Np (padded with zeros)
+    re = torch.zeros((M, B * Np), device=dev)
+    im = torch.zeros((M, B * Np), device=dev)
+    for b in range(B):
+        re[:, b * Np:b * Np + N] = torch.from_numpy(case["re"][:, b * N:(b + 1) * N]).to(dev)
+        im[:, b * Np:b * Np + N] = torch.from_numpy(case["im"][:, b * N:(b + 1) * N]).to(dev)
+    if layout == "i8":
+        scale = 20.0
+        x = torch.stack([torch.clamp(torch.round(re * scale), -128, 127), torch.clamp(torch.round(im * scale), -128, 127)],
+                        dim=-1).to(torch.int8).contiguous()
+        ref_case = dict(case)
+        ref_case["re"] = np.concatenate([x[:, b * Np:b * Np + N, 0].cpu().numpy().astype(np.float32) for b in range(B)], axis=1)
+        ref_case["im"] = np.concatenate([x[:, b * Np:b * Np + N, 1].cpu().numpy().astype(np.float32) for b in range(B)], axis=1)
+        ref = oracle_result(ref_case)
+    else:
+        ref = oracle_result(case)
+    out, vec, times = {}, {}, {}
+    for name, n in (("ragged", N), ("padded", Np)):
+        op = g.StreamCorrelator(sysobj, n, M, B, 2, case["shifts"], case["fs"])
+        op.set_params(prm)
+        desc = g._lib.SignalDesc(x.data_ptr() if layout == "i8" else re.data_ptr(), None if layout == "i8" else im.data_ptr(),
+                                 g.GAT_LAYOUT_INTERLEAVED_I8 if layout == "i8" else g.GAT_LAYOUT_PLANAR, M, n, B * Np, Np, 0)
+        op.launch(desc)
+        out[name] = op.result()
+        vec[name] = op.ctx.last_launch_info()["vec"]
+        op.ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            op.launch(desc)
+        op.ctx.sync()
+        times[name] = (time.perf_counter() - t0) / 20
+    assert vec == {"ragged": 1, "padded": 4}, vec
+    check_close(out["ragged"], ref, what="ragged N through the scalar kernel")
+    check_close(out["padded"], ref, what="zero-padded N through the vector kernel")
+    print(f"N={N} {layout}: scalar kernel {times['ragged'] * 1e6:.1f} us, padded vector kernel {times['padded'] * 1e6:.1f} us per launch")
