@@ -70,6 +70,54 @@ int main(void)
         }
     printf("taps %d %d %d -> antenna 0: [%.2f%+.2fj, %.2f%+.2fj, %.2f%+.2fj]  %s\n", shifts[0], shifts[1], shifts[2],
            h_re[0], h_im[0], h_re[M], h_im[M], h_re[2 * M], h_im[2 * M], bad ? "MISMATCH" : "OK (known answer 1476 2500 1476)");
+
+    /* ---- the stand-alone stage operators the reference's tests launch directly, in the order julia/GATHip.jl binds
+     * them: downconvert_and_accumulate! (test/algorithms.jl:1438-1514: prompt products == 1, column sums == the known
+     * answer), reduce_cplx_multi! (test/reduction.jl:13-52: the two-pass sum of those very products), and
+     * gen_code_replica_nsat! (test/algorithms.jl:1199: one replica row per satellite == the single-satellite operator) */
+    int bad2 = 0;
+    {
+        void *acc_re, *acc_im, *sum_re, *sum_im;
+        CHECK(gat_malloc(ctx, sizeof(float) * N * M * L, &acc_re));
+        CHECK(gat_malloc(ctx, sizeof(float) * N * M * L, &acc_im));
+        CHECK(gat_malloc(ctx, sizeof(float) * M * L, &sum_re));
+        CHECK(gat_malloc(ctx, sizeof(float) * M * L, &sum_im));
+        CHECK(gat_downconvert_and_accumulate(ctx, &sig, &p, L, shifts, fs, NULL, NULL, NULL, NULL, acc_re, acc_im));
+        float *prod = malloc(sizeof(float) * N * M * L);
+        CHECK(gat_memcpy_d2h(ctx, prod, acc_re, sizeof(float) * N * M * L));
+        for (int n = 0; n < N; ++n) /* prompt tap (l = 1), antenna 0: every product is 1 (test/algorithms.jl:1514) */
+            if (fabsf(prod[((size_t)1 * M + 0) * N + n] - 1.f) > 1e-5f) ++bad2;
+        /* columns = (tap, antenna) pairs, n = N rows each: exactly the layout the products were written in */
+        CHECK(gat_reduce_cplx_multi(ctx, acc_re, acc_im, N, M * L, sum_re, sum_im));
+        float s_re[M * L];
+        CHECK(gat_memcpy_d2h(ctx, s_re, sum_re, sizeof s_re));
+        for (int l = 0; l < L; ++l)
+            for (int m = 0; m < M; ++m)
+                if (fabsf(s_re[m + l * M] - want[l]) > 1e-5f * N) ++bad2;
+        /* replicas of two satellites in one launch against the single-satellite operator */
+        void *rep2, *rep1, *prm2_dev;
+        const int cnt = N + shifts[L - 1] - shifts[0];
+        const gat_channel_params p2[2] = {{0, 0, fc, f, 0.0, 0.0}, {6, 0, fc * 1.000002, f, 511.75, 0.0}};
+        CHECK(gat_malloc(ctx, sizeof(float) * cnt * 2, &rep2));
+        CHECK(gat_malloc(ctx, sizeof(float) * cnt, &rep1));
+        CHECK(gat_malloc(ctx, sizeof p2, &prm2_dev));
+        CHECK(gat_memcpy_h2d(ctx, prm2_dev, p2, sizeof p2));
+        CHECK(gat_gen_code_replica_multi(ctx, rep2, cnt, cnt, 2, prm2_dev, fs, shifts[0]));
+        float *r2 = malloc(sizeof(float) * cnt * 2), *r1 = malloc(sizeof(float) * cnt);
+        CHECK(gat_memcpy_d2h(ctx, r2, rep2, sizeof(float) * cnt * 2));
+        for (int k = 0; k < 2; ++k) {
+            CHECK(gat_gen_code_replica(ctx, rep1, cnt, p2[k].prn, p2[k].code_freq_hz, fs, p2[k].code_phase_chips, shifts[0]));
+            CHECK(gat_memcpy_d2h(ctx, r1, rep1, sizeof(float) * cnt));
+            for (int i = 0; i < cnt; ++i)
+                if (r1[i] != r2[(size_t)k * cnt + i]) ++bad2;
+        }
+        printf("stage operators: accumulate products, two-pass reduction [%.0f %.0f %.0f], two-satellite replica: %s\n", s_re[0],
+               s_re[M], s_re[2 * M], bad2 ? "MISMATCH" : "OK");
+        free(prod); free(r2); free(r1);
+        gat_free(ctx, acc_re); gat_free(ctx, acc_im); gat_free(ctx, sum_re); gat_free(ctx, sum_im);
+        gat_free(ctx, rep2); gat_free(ctx, rep1); gat_free(ctx, prm2_dev);
+    }
+    bad += bad2;
     gat_free(ctx, re); gat_free(ctx, im); gat_free(ctx, prm_dev); gat_free(ctx, out_re); gat_free(ctx, out_im);
     gat_destroy(ctx);
     free(codes);

@@ -23,6 +23,8 @@ const libgat = get(ENV, "LIBGAT", "libgat.so")
 
 const GAT_OK = Int32(0)
 const GAT_FLAG_ATOMIC = UInt32(1)
+const GAT_FLAG_GRAPH = UInt32(2)
+const GAT_OWN_STREAM = Ptr{Cvoid}(typemax(UInt))   # (void *)-1: the library creates and owns a non-blocking stream
 const GAT_LAYOUT_PLANAR = Int32(0)
 const GAT_LAYOUT_INTERLEAVED = Int32(1)
 const GAT_LAYOUT_INTERLEAVED_I16 = Int32(2)
@@ -66,11 +68,18 @@ mutable struct Context
     out_cap::Int
     host_re::Vector{Float32}
     host_im::Vector{Float32}
-    function Context(device::Integer = 0, stream::Ptr{Cvoid} = C_NULL)
+    # argument buffers of the single-channel call, written in place: the harness method times nothing but the ccall
+    prm1::Vector{ChannelParams}
+    shifts::Vector{Int32}
+    desc::Base.RefValue{SignalDesc}
+    # a library-owned stream by default: single-block calls then end with the completion flag gat_sync spins on
+    # (include/gat.h; ~4 us less per call + sync than hipStreamSynchronize on this platform)
+    function Context(device::Integer = 0, stream::Ptr{Cvoid} = GAT_OWN_STREAM)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:gat_create, libgat), Int32, (Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, stream, h)
         rc == GAT_OK || throw(GatError(rc, "gat_create"))
-        ctx = new(h[], C_NULL, C_NULL, 0, Float32[], Float32[])
+        ctx = new(h[], C_NULL, C_NULL, 0, Float32[], Float32[], [ChannelParams(0, 0, 0.0, 0.0, 0.0, 0.0)], Int32[],
+                  Ref(SignalDesc(C_NULL, C_NULL, GAT_LAYOUT_PLANAR, 0, 0, 0, 0, 0)))
         finalizer(ctx) do c
             c.out_re == C_NULL || ccall((:gat_free, libgat), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), c.handle, c.out_re)
             c.out_im == C_NULL || ccall((:gat_free, libgat), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), c.handle, c.out_im)
@@ -196,10 +205,11 @@ function Tracking.downconvert_and_correlate!(
 ) where {L}
     ctx = system.ctx
     M = signal.num_ants
-    prm = [ChannelParams(prn - 1, 0, ustrip(Hz, code_frequency), ustrip(Hz, carrier_frequency),
-                         Float64(code_phase), Float64(carrier_phase))]
-    correlate_async!(ctx, signal_desc(signal, signal_start_sample, num_samples), prm,
-                     Int32[correlator_sample_shifts...], Float64(ustrip(Hz, sampling_frequency)), M)
+    reserve_outputs!(ctx, M * L)                         # a no-op after the first call
+    correlate_single!(ctx, signal_desc(signal, signal_start_sample, num_samples), prn - 1,
+                      Float64(ustrip(Hz, code_frequency)), Float64(ustrip(Hz, carrier_frequency)), Float64(code_phase),
+                      Float64(carrier_phase), correlator_sample_shifts, Float64(ustrip(Hz, sampling_frequency)),
+                      ctx.out_re, ctx.out_im)
     re, im = fetch_result!(ctx, M * L)
     accumulators = SVector{L}(ntuple(l -> SVector{M}(ntuple(m -> complex(re[(l - 1) * M + m], im[(l - 1) * M + m]), M)), L))
     return EarlyPromptLateCorrelator(accumulators)       # functional update, as Tracking.jl does
@@ -221,6 +231,107 @@ function downconvert_and_correlate_channels!(
     re, im = fetch_result!(ctx, M * L * K)
     reshape(complex.(re, im), M, L, K)
 end
+
+# ---- the same call with every argument buffer cached in the context (no allocation at all per call): what
+#      kernel_algorithm(..., ::KernelAlgorithm{9000}) in GATHipHarness.jl runs
+function correlate_single!(ctx::Context, desc::SignalDesc, prn0::Integer,
+                           code_freq_hz::Float64, carrier_freq_hz::Float64, code_phase::Float64, carrier_phase::Float64,
+                           shifts, sampling_frequency_hz::Float64, out_re::Ptr{Cfloat}, out_im::Ptr{Cfloat})
+    L = length(shifts)
+    length(ctx.shifts) == L || resize!(ctx.shifts, L)          # first call / another tap count only
+    @inbounds for l in 1:L
+        ctx.shifts[l] = shifts[l]
+    end
+    @inbounds ctx.prm1[1] = ChannelParams(prn0, 0, code_freq_hz, carrier_freq_hz, code_phase, carrier_phase)
+    ctx.desc[] = desc
+    check(ctx, ccall((:gat_downconvert_and_correlate, libgat), Int32,
+                     (Ptr{Cvoid}, Ref{SignalDesc}, Ptr{ChannelParams}, Int32, Int32, Int32, Ptr{Int32}, Float64,
+                      Ptr{Cfloat}, Ptr{Cfloat}, UInt32),
+                     ctx.handle, ctx.desc, ctx.prm1, 1, 1, L, ctx.shifts, sampling_frequency_hz, out_re, out_im, UInt32(0)))
+end
+
+# ---- reduce_cplx_multi_3/4/5 two-pass column sums (src/reduction.jl:93, :331, :548; launch sequence
+#      src/algorithms.jl:914-922; test/reduction.jl:13-52): planar complex [n x cols] on the device -> [cols]
+function reduce_cplx_multi!(ctx::Context, out_re::Ptr{Cfloat}, out_im::Ptr{Cfloat}, in_re::Ptr{Cfloat}, in_im::Ptr{Cfloat},
+                            n::Integer, cols::Integer)
+    check(ctx, ccall((:gat_reduce_cplx_multi, libgat), Int32,
+                     (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, Int32, Ptr{Cfloat}, Ptr{Cfloat}),
+                     ctx.handle, in_re, in_im, n, cols, out_re, out_im))
+end
+
+# ---- gen_code_replica_texture_mem_strided_nsat_kernel! (src/algorithms.jl:78-98; test/algorithms.jl:1199): the
+#      replicas of K satellite channels in one launch, row k of `replica_dev` (row_stride floats apart) = channel k.
+#      params_dev: device array of K ChannelParams (prn, code_freq_hz, code_phase_chips used)
+function gen_code_replica_nsat!(ctx::Context, replica_dev::Ptr{Cfloat}, count::Integer, row_stride::Integer, K::Integer,
+                                params_dev::Ptr{Cvoid}, sampling_frequency_hz::Float64, first_shift::Integer)
+    check(ctx, ccall((:gat_gen_code_replica_multi, libgat), Int32,
+                     (Ptr{Cvoid}, Ptr{Cfloat}, Int64, Int64, Int32, Ptr{Cvoid}, Float64, Int64),
+                     ctx.handle, replica_dev, count, row_stride, K, params_dev, sampling_frequency_hz, first_shift))
+end
+
+# ---- downconvert_and_accumulate_strided_kernel! (src/algorithms.jl:828-866; test/algorithms.jl:1438-1514): the
+#      materialising middle stage of the reference's algorithm 2 as a debug export -- carrier [N], downconverted
+#      signal [N x M], per-sample products [N x M x L]; any output pointer may be C_NULL
+function downconvert_and_accumulate!(ctx::Context, signal::HipSignal, prm::ChannelParams, shifts::Vector{Int32},
+                                     sampling_frequency_hz::Float64; carrier_re = C_NULL, carrier_im = C_NULL, dw_re = C_NULL,
+                                     dw_im = C_NULL, accum_re = C_NULL, accum_im = C_NULL)
+    desc = signal_desc(signal, 1, signal.num_samples)
+    check(ctx, ccall((:gat_downconvert_and_accumulate, libgat), Int32,
+                     (Ptr{Cvoid}, Ref{SignalDesc}, Ref{ChannelParams}, Int32, Ptr{Int32}, Float64, Ptr{Cfloat}, Ptr{Cfloat},
+                      Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}),
+                     ctx.handle, Ref(desc), Ref(prm), length(shifts), shifts, sampling_frequency_hz, carrier_re, carrier_im,
+                     dw_re, dw_im, accum_re, accum_im))
+end
+
+# ---- several GPUs from one Julia task: one context per device, channels sharded contiguously, no collective
+#      (include/gat.h gat_group_*; the C form of this sequence is examples/gat_multi_gpu.c)
+mutable struct DeviceGroup
+    handle::Ptr{Cvoid}
+    n::Int
+    function DeviceGroup(devices::Vector{Int32})
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:gat_group_create, libgat), Int32, (Int32, Ptr{Int32}, Ref{Ptr{Cvoid}}), length(devices), devices, h)
+        rc == GAT_OK || throw(GatError(rc, "gat_group_create"))
+        g = new(h[], length(devices))
+        finalizer(x -> ccall((:gat_group_destroy, libgat), Int32, (Ptr{Cvoid},), x.handle), g)
+        g
+    end
+end
+function device_count()
+    n = Ref{Int32}(0)
+    ccall((:gat_device_count, libgat), Int32, (Ref{Int32},), n) == GAT_OK || throw(GatError(1, "gat_device_count"))
+    Int(n[])
+end
+DeviceGroup() = DeviceGroup(Int32.(0:device_count() - 1))
+function gcheck(g::DeviceGroup, rc::Int32)
+    rc == GAT_OK && return nothing
+    throw(GatError(rc, unsafe_string(ccall((:gat_group_last_error, libgat), Cstring, (Ptr{Cvoid},), g.handle))))
+end
+set_codes!(g::DeviceGroup, codes::Matrix{Int8}) = gcheck(g, ccall((:gat_group_set_codes, libgat), Int32,
+    (Ptr{Cvoid}, Ptr{Int8}, Int32, Int32), g.handle, codes, size(codes, 1), size(codes, 2)))
+function shard(g::DeviceGroup, K::Integer, rank::Integer)       # rank 0-based -> (first channel 0-based, count)
+    lo, cnt = Ref{Int32}(0), Ref{Int32}(0)
+    gcheck(g, ccall((:gat_group_shard, libgat), Int32, (Ptr{Cvoid}, Int32, Int32, Ref{Int32}, Ref{Int32}), g.handle, K, rank, lo, cnt))
+    Int(lo[]), Int(cnt[])
+end
+# bufs[r + 1] (r != src_rank) <- bufs[src_rank + 1]: the ingest device's signal to its peers (hipMemcpyPeerAsync)
+replicate!(g::DeviceGroup, src_rank::Integer, bufs::Vector{Ptr{Cvoid}}, bytes::Integer) = gcheck(g, ccall(
+    (:gat_group_replicate, libgat), Int32, (Ptr{Cvoid}, Int32, Ptr{Ptr{Cvoid}}, Csize_t), g.handle, src_rank, bufs, bytes))
+# member r correlates its channel slice of prm ([K x B], channel fastest) on descs[r + 1] into its own device outputs
+correlate!(g::DeviceGroup, descs::Vector{SignalDesc}, prm::Matrix{ChannelParams}, shifts::Vector{Int32}, fs_hz::Float64,
+           out_re::Vector{Ptr{Cfloat}}, out_im::Vector{Ptr{Cfloat}}, flags::UInt32 = UInt32(0)) = gcheck(g, ccall(
+    (:gat_group_correlate, libgat), Int32,
+    (Ptr{Cvoid}, Ptr{SignalDesc}, Ptr{ChannelParams}, Int32, Int32, Int32, Ptr{Int32}, Float64, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, UInt32),
+    g.handle, descs, prm, size(prm, 2), size(prm, 1), length(shifts), shifts, fs_hz, out_re, out_im, flags))
+# the members' outputs concatenated along the channel axis: ComplexF32 [M x L x K x B] (synchronises)
+function gather(g::DeviceGroup, out_re::Vector{Ptr{Cfloat}}, out_im::Vector{Ptr{Cfloat}}, B, K, L, M)
+    re, im = Array{Float32}(undef, M, L, K, B), Array{Float32}(undef, M, L, K, B)
+    gcheck(g, ccall((:gat_group_gather, libgat), Int32,
+        (Ptr{Cvoid}, Ptr{Ptr{Cfloat}}, Ptr{Ptr{Cfloat}}, Int32, Int32, Int32, Int32, Ptr{Cfloat}, Ptr{Cfloat}),
+        g.handle, out_re, out_im, B, K, L, M, re, im))
+    complex.(re, im)
+end
+sync(g::DeviceGroup) = gcheck(g, ccall((:gat_group_sync, libgat), Int32, (Ptr{Cvoid},), g.handle))
 
 # ---- Tracking.gen_code_replica! (scripts/code_replica_experiment.jl:70)
 function gen_code_replica!(ctx::Context, code_replica_dev::Ptr{Cfloat}, code_frequency, sampling_frequency,

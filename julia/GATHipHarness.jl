@@ -82,14 +82,10 @@ function kernel_algorithm(
     num_corrs,
     algorithm::KernelAlgorithm{9000}
 ) where {NANT, NCOR}
-    ctx = codes.ctx
-    desc = GATHip.SignalDesc(signal_re, signal_im, GATHip.GAT_LAYOUT_PLANAR, NANT, num_samples, num_samples, num_samples, 0)
-    prm = [GATHip.ChannelParams(prn - 1, 0, ustrip(Hz, code_frequency), ustrip(Hz, carrier_frequency),
-                                Float64(start_code_phase), Float64(carrier_phase))]
-    GATHip.check(ctx, ccall((:gat_downconvert_and_correlate, GATHip.libgat), Int32,
-        (Ptr{Cvoid}, Ref{GATHip.SignalDesc}, Ptr{GATHip.ChannelParams}, Int32, Int32, Int32, Ptr{Int32}, Float64,
-         Ptr{Cfloat}, Ptr{Cfloat}, UInt32),
-        ctx.handle, Ref(desc), prm, 1, 1, NCOR, Int32[correlator_sample_shifts...],
-        Float64(ustrip(Hz, sampling_frequency)), accum_re, accum_im, 0))
+    # no allocation here: parameters, tap list and signal descriptor live in the context and are written in place
+    desc = GATHip.SignalDesc(signal_re, signal_im, GATHip.GAT_LAYOUT_PLANAR, NANT, num_samples, num_samples, num_samples, 0) # isbits
+    GATHip.correlate_single!(codes.ctx, desc, prn - 1, Float64(ustrip(Hz, code_frequency)),
+                             Float64(ustrip(Hz, carrier_frequency)), Float64(start_code_phase), Float64(carrier_phase),
+                             correlator_sample_shifts, Float64(ustrip(Hz, sampling_frequency)), accum_re, accum_im)
     return nothing
 end

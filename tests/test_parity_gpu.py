@@ -446,3 +446,4 @@ def test_c_abi_from_plain_c(gat):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK (known answer 1476 2500 1476)" in r.stdout
+    assert "two-satellite replica: OK" in r.stdout  # the stage operators julia/GATHip.jl binds, same sequence in C
