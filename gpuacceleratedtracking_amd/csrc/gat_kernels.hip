@@ -6,36 +6,59 @@
 
 namespace gat {
 
-// second stage: sum of the per-split partials in a FIXED order (deterministic): one wave64 per
-// output element, lane i adds splits i, i+64, ... sequentially, then a fixed butterfly.
+// second stage: sum of the per-split partials in a FIXED order (deterministic).  Many splits (the matrix-core kernels
+// leave 256 per (block, channel) at configs[4]: 25 MB of partials): a workgroup = 32 consecutive output elements x 8
+// slices; thread (element, slice) adds splits slice, slice + 8, ... with four loads in flight -- consecutive threads read
+// consecutive floats of one split row --, then the 8 slices are added in slice order through LDS.  (Round 2 spent one
+// wave64 per output element, lane i adding splits i, i + 64, ...: every load instruction fetched 64 floats 1.5 KB apart,
+// 33 us at configs[4]; now 9.)
 // partial [groups][splits][elems], elems = cols*2 with re/im interleaved innermost.
+constexpr int kFinElems = 32, kFinSlices = kThreads / kFinElems;
 __global__ void __launch_bounds__(kThreads)
 finalize_kernel(const float *__restrict__ partial, float *__restrict__ out_re,
-                float *__restrict__ out_im, int splits, int elems, long long groups, unsigned *done_counter,
+                float *__restrict__ out_im, int splits, int elems, long long total, unsigned *done_counter,
                 unsigned *host_flag, unsigned flag_seq)
 {
-    const long long wave_id = (long long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-    if (wave_id < groups * elems) {
-        const int lane = threadIdx.x & 63;
-        const long long g = wave_id / elems;
-        const int e = (int)(wave_id - g * elems);
+    __shared__ float s_sum[kFinSlices][kFinElems];
+    const int el = threadIdx.x % kFinElems, slice = threadIdx.x / kFinElems;
+    const long long o = (long long)blockIdx.x * kFinElems + el;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (o < total) {
+        const long long g = o / elems;
+        const int e = (int)(o - g * elems);
         const float *p = partial + (size_t)g * splits * elems + e;
-        float s = 0.f;
-        for (int i = lane; i < splits; i += 64) s += p[(size_t)i * elems];
-        s = wave_sum(s);
-        if (lane == 0) {
-            float *o = (e & 1) ? out_im : out_re;
-            o[(size_t)g * (elems / 2) + (e >> 1)] = s;
+        int i = slice;
+        for (; i + 3 * kFinSlices < splits; i += 4 * kFinSlices) {
+            const float v0 = p[(size_t)i * elems], v1 = p[(size_t)(i + kFinSlices) * elems];
+            const float v2 = p[(size_t)(i + 2 * kFinSlices) * elems], v3 = p[(size_t)(i + 3 * kFinSlices) * elems];
+            s0 += v0;
+            s1 += v1;
+            s2 += v2;
+            s3 += v3;
         }
+        if (i < splits) s0 += p[(size_t)i * elems];
+        if (i + kFinSlices < splits) s1 += p[(size_t)(i + kFinSlices) * elems];
+        if (i + 2 * kFinSlices < splits) s2 += p[(size_t)(i + 2 * kFinSlices) * elems];
+    }
+    s_sum[slice][el] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slice == 0 && o < total) {
+        float tot = s_sum[0][el];
+#pragma unroll
+        for (int j = 1; j < kFinSlices; ++j) tot += s_sum[j][el];
+        const long long g = o / elems;
+        const int e = (int)(o - g * elems);
+        float *out = (e & 1) ? out_im : out_re;
+        out[(size_t)g * (elems / 2) + (e >> 1)] = tot;
     }
     completion_flag(done_counter, host_flag, flag_seq, gridDim.x);
 }
 
-// Few splits (what the fused kernels leave behind: 2-16 per group): one THREAD per output element, its splits summed
+// Few splits (what the vector kernel leaves behind: 2-32 per group): one THREAD per output element, its splits summed
 // in a fixed order (four interleaved chains, then ((0+1)+(2+3)): deterministic).  Consecutive threads read consecutive
-// floats of one split row, so every load instruction of a wave is one 256-byte line -- the wave-per-element kernel
-// above keeps splits of its 64 lanes busy (4 of 64 at the 16-antenna shard of BASELINE configs[3]: 196 608 waves for
-// 3 MB of partials, 40 us of a 0.72 ms step).
+// floats of one split row, so every load instruction of a wave is one 256-byte line (round 2's wave-per-element kernel
+// kept 4 of its 64 lanes busy at the 16-antenna shard of BASELINE configs[3]: 196 608 waves for 3 MB of partials,
+// 40 us of a 0.72 ms step).
 __global__ void __launch_bounds__(kThreads)
 finalize_few_kernel(const float *__restrict__ partial, float *__restrict__ out_re,
                     float *__restrict__ out_im, int splits, int elems, long long total, unsigned *done_counter,
@@ -350,9 +373,9 @@ hipError_t launch_finalize(const float *partial, float *out_re, float *out_im, i
                            partial, out_re, out_im, splits, elems, waves, done_counter, host_flag, flag_seq);
         return hipGetLastError();
     }
-    const unsigned grid = (unsigned)((waves + kThreads / 64 - 1) / (kThreads / 64));
+    const unsigned grid = (unsigned)((waves + kFinElems - 1) / kFinElems);
     hipLaunchKernelGGL(finalize_kernel, dim3(grid), dim3(kThreads), 0, s, partial, out_re, out_im,
-                       splits, elems, groups, done_counter, host_flag, flag_seq);
+                       splits, elems, waves, done_counter, host_flag, flag_seq);
     return hipGetLastError();
 }
 
