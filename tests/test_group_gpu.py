@@ -138,3 +138,65 @@ def test_group_argument_errors(gat):
     with pytest.raises(g.GatError):
         grp.shard(7, 1)
     grp.close()
+
+
+def test_native_latency_example_and_completion_flag(gat):
+    """examples/gat_latency.c: the harness's timed body from plain C on a library-owned stream -- every grid point runs the
+    host-parameter call, the device-parameter call (completion flag: gat_sync spins on the sequence number the launch's
+    last workgroup stores into pinned host memory) and the hipGraph replay; each point prints the prompt correlation, which
+    must be N (noise-free signal, zero phases): a flag that fired before the results were out would show here."""
+    import re
+    from gpuacceleratedtracking_amd import build
+    exe = build.build_c_example(name="gat_latency")
+    r = subprocess.run([exe, "60"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    rows = [ln for ln in r.stdout.splitlines() if ln.strip() and not ln.startswith("#")]
+    assert len(rows) == 8 * 2 * 2, r.stdout
+    for ln in rows:
+        n = int(ln.split()[0])
+        m = re.search(r"\(prompt (\d+)\)", ln)
+        assert m and int(m.group(1)) == n, ln
+        dev_min = float(ln.split("|")[2].split("/")[0])
+        assert 3.0 < dev_min < 200.0, ln  # microseconds: a call + sync is neither free nor a stall
+
+
+def test_sync_after_flagged_launch_sees_results_and_later_work_falls_back(gat):
+    """gat_sync on a library-owned stream: after a flagged correlate the results are visible to a device-to-host copy; work
+    enqueued after the flagged launch (a memset of the outputs) makes the next gat_sync wait for the stream instead of the flag."""
+    import ctypes as C
+    g = gat
+    lib = g.load_library()
+    h = C.c_void_p()
+    assert lib.gat_create(0, C.c_void_p(-1), C.byref(h)) == 0  # GAT_OWN_STREAM
+    system = g.GPSL1(use_gpu=True)
+    codes = np.ascontiguousarray(system.codes, dtype=np.int8)
+    assert lib.gat_set_codes(h, codes.ctypes.data_as(C.POINTER(C.c_int8)), codes.shape[1], codes.shape[0]) == 0
+    N, M, L = 2500, 4, 3
+    fs = N / 1e-3
+    bufs = {}
+    for name, nbytes in (("re", 4 * N * M), ("im", 4 * N * M), ("prm", 40), ("o_re", 4 * M * L), ("o_im", 4 * M * L)):
+        p = C.c_void_p()
+        assert lib.gat_malloc(h, nbytes, C.byref(p)) == 0
+        bufs[name] = p
+    prm = g.make_params(np.zeros((1, 1), dtype=np.int32), 1.023e6, 1500.0, 0.0, 0.0)
+    prm = np.ascontiguousarray(prm)
+    assert lib.gat_memcpy_h2d(h, bufs["prm"], prm.ctypes.data_as(C.c_void_p), 40) == 0
+    assert lib.gat_gen_signal(h, bufs["re"], bufs["im"], 0, N, M, N, N, 1, 1, bufs["prm"], fs, 1.0) == 0
+    desc = g._lib.SignalDesc(bufs["re"].value, bufs["im"].value, 0, M, N, N, N, 0)
+    shifts = (C.c_int32 * L)(-1, 0, 1)
+    out = np.zeros(M * L, dtype=np.float32)
+    for rep in range(50):
+        assert lib.gat_memset(h, bufs["o_re"], 0xFF, 4 * M * L) == 0     # NaN pattern
+        assert lib.gat_downconvert_and_correlate_dev(h, C.byref(desc), bufs["prm"], 1, 1, L, shifts, fs, bufs["o_re"], bufs["o_im"], 0) == 0
+        assert lib.gat_sync(h) == 0                                        # flag path
+        assert lib.gat_memcpy_d2h(h, out.ctypes.data_as(C.c_void_p), bufs["o_re"], 4 * M * L) == 0
+        assert np.allclose(out.reshape(L, M)[:, 0], [1476, 2500, 1476], rtol=1e-5), (rep, out)
+    # newer work behind a flagged launch: gat_sync must not return on the (already reached) flag
+    assert lib.gat_downconvert_and_correlate_dev(h, C.byref(desc), bufs["prm"], 1, 1, L, shifts, fs, bufs["o_re"], bufs["o_im"], 0) == 0
+    assert lib.gat_memset(h, bufs["o_re"], 0, 4 * M * L) == 0
+    assert lib.gat_sync(h) == 0
+    assert lib.gat_memcpy_d2h(h, out.ctypes.data_as(C.c_void_p), bufs["o_re"], 4 * M * L) == 0
+    assert (out == 0).all()
+    for p in bufs.values():
+        lib.gat_free(h, p)
+    assert lib.gat_destroy(h) == 0
