@@ -206,11 +206,23 @@ class Context:
 
     def gen_signal(self, re: torch.Tensor, im: torch.Tensor | None, layout: int, num_samples: int,
                    num_ants: int, ant_stride: int, block_stride: int, num_blocks: int, num_channels: int,
-                   params_dev: torch.Tensor, sampling_frequency: float, amplitude: float = 1.0):
-        rc = self.lib.gat_gen_signal(self._h, C.c_void_p(_ptr(re)), C.c_void_p(_ptr(im)), layout, num_samples,
-                                     num_ants, ant_stride, block_stride, num_blocks, num_channels,
-                                     C.c_void_p(_ptr(params_dev)), float(sampling_frequency), float(amplitude))
-        self.check(rc, "gat_gen_signal")
+                   params_dev: torch.Tensor, sampling_frequency: float, amplitude: float = 1.0,
+                   steering_cycles: torch.Tensor | None = None, noise_sigma: float = 0.0, seed: int = 0):
+        """``steering_cycles`` (float32 [M] on the device) / ``noise_sigma`` / ``seed``: gat_gen_signal_noisy (per-antenna
+        steering phases, complex white Gaussian noise); without them the reference's noise-free generator."""
+        if steering_cycles is None and noise_sigma == 0.0:
+            rc = self.lib.gat_gen_signal(self._h, C.c_void_p(_ptr(re)), C.c_void_p(_ptr(im)), layout, num_samples,
+                                         num_ants, ant_stride, block_stride, num_blocks, num_channels,
+                                         C.c_void_p(_ptr(params_dev)), float(sampling_frequency), float(amplitude))
+            self.check(rc, "gat_gen_signal")
+            return
+        if steering_cycles is not None and (steering_cycles.dtype != torch.float32 or steering_cycles.numel() < num_ants):
+            raise ValueError("steering_cycles must be float32 [num_ants]")
+        rc = self.lib.gat_gen_signal_noisy(self._h, C.c_void_p(_ptr(re)), C.c_void_p(_ptr(im)), layout, num_samples,
+                                           num_ants, ant_stride, block_stride, num_blocks, num_channels,
+                                           C.c_void_p(_ptr(params_dev)), float(sampling_frequency), float(amplitude),
+                                           C.c_void_p(_ptr(steering_cycles)), float(noise_sigma), int(seed) & (2 ** 64 - 1))
+        self.check(rc, "gat_gen_signal_noisy")
 
     def reduce_cplx_multi(self, in_re: torch.Tensor, in_im: torch.Tensor, n: int, cols: int,
                           out_re: torch.Tensor, out_im: torch.Tensor):

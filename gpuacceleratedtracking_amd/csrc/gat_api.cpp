@@ -1039,9 +1039,30 @@ GAT_API int32_t gat_downconvert_and_accumulate(gat_ctx *c, const gat_signal_desc
     return GAT_OK;
 }
 
+static int32_t gen_signal_impl(gat_ctx *c, void *re, void *im, int32_t layout, int64_t N, int32_t M, int64_t ant_stride,
+                               int64_t block_stride, int32_t B, int32_t K, const gat_channel_params *params_dev, double fs,
+                               double amplitude, const float *steering_cycles_dev, double noise_sigma, uint64_t seed);
+
 GAT_API int32_t gat_gen_signal(gat_ctx *c, void *re, void *im, int32_t layout, int64_t N, int32_t M,
                                int64_t ant_stride, int64_t block_stride, int32_t B, int32_t K,
                                const gat_channel_params *params_dev, double fs, double amplitude)
+{
+    return gen_signal_impl(c, re, im, layout, N, M, ant_stride, block_stride, B, K, params_dev, fs, amplitude, nullptr, 0.0, 0);
+}
+
+GAT_API int32_t gat_gen_signal_noisy(gat_ctx *c, void *re, void *im, int32_t layout, int64_t N, int32_t M,
+                                     int64_t ant_stride, int64_t block_stride, int32_t B, int32_t K,
+                                     const gat_channel_params *params_dev, double fs, double amplitude,
+                                     const float *steering_cycles_dev, double noise_sigma, uint64_t seed)
+{
+    if (c && (!(noise_sigma >= 0.0) || !std::isfinite(noise_sigma))) return fail(c, GAT_ERR_ARG, "noise sigma must be finite and >= 0");
+    return gen_signal_impl(c, re, im, layout, N, M, ant_stride, block_stride, B, K, params_dev, fs, amplitude,
+                           steering_cycles_dev, noise_sigma, seed);
+}
+
+static int32_t gen_signal_impl(gat_ctx *c, void *re, void *im, int32_t layout, int64_t N, int32_t M, int64_t ant_stride,
+                               int64_t block_stride, int32_t B, int32_t K, const gat_channel_params *params_dev, double fs,
+                               double amplitude, const float *steering_cycles_dev, double noise_sigma, uint64_t seed)
 {
     if (!c || !re || !params_dev) return fail(c, GAT_ERR_ARG, "null argument");
     if (!c->d_codes) return fail(c, GAT_ERR_STATE, "gat_set_codes has not been called");
@@ -1053,7 +1074,8 @@ GAT_API int32_t gat_gen_signal(gat_ctx *c, void *re, void *im, int32_t layout, i
     c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
     const TraceRange trace("gat_gen_signal");
     GAT_HIP(c, launch_gen_signal(re, im, layout, N, M, ant_stride, block_stride, B, K, params_dev, c->d_codes,
-                                 c->code_row_stride, c->Lc, c->P, fs, (float)amplitude, c->stream));
+                                 c->code_row_stride, c->Lc, c->P, fs, (float)amplitude, steering_cycles_dev, (float)noise_sigma,
+                                 (unsigned long long)seed, c->stream));
     return GAT_OK;
 }
 

@@ -184,7 +184,8 @@ hipError_t launch_accumulate_debug(const float *sig_re, const float *sig_im, lon
 hipError_t launch_gen_signal(void *re, void *im, int format, long long N, int M,
                              long long ant_stride, long long block_stride, int B, int K,
                              const gat_channel_params *params, const int8_t *codes, int code_row_stride,
-                             int Lc, int num_prns, double fs, float amplitude, hipStream_t s);
+                             int Lc, int num_prns, double fs, float amplitude, const float *steering_cycles, float noise_sigma,
+                             unsigned long long seed, hipStream_t s);
 hipError_t launch_reduce_stage1(const float *in_re, const float *in_im, long long n, int cols,
                                 int chunks, float *partial, hipStream_t s);
 hipError_t launch_tracking_update(const float *acc_re, const float *acc_im, int K, int M, const gat_loop_config &cfg,

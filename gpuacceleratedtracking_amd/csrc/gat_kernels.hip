@@ -184,11 +184,30 @@ accumulate_debug_kernel(const float *__restrict__ sig_re, const float *__restric
 // gen_signal! (src/gen_signal.jl:64-70, :86-90): Float64 code phase, carrier phase evaluated in
 // Float64 then rounded to Float32 BEFORE cos/sin (src/gen_signal.jl:88), identical antennas.
 // `amplitude` scales the sum (1 = the reference); integer formats store rint(value) saturated.
+// Counter-based noise for the synthetic generator (SURVEY section 8-d "build additions": AWGN + per-antenna steering; the
+// reference's generator is noise-free, paper/paper.tex:116): splitmix64 of (seed, sample index) -> two uniforms ->
+// Box-Muller.  A sample's noise depends on (seed, block, antenna, n) only, never on the launch geometry.
+__device__ __forceinline__ void gauss_pair(unsigned long long seed, unsigned long long idx, float &g0, float &g1)
+{
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u0 = ((float)(unsigned)(z >> 40) + 0.5f) * (1.0f / 16777216.0f); // (0, 1): 24 bits
+    const float u1 = ((float)(unsigned)((z >> 8) & 0xffffffu) + 0.5f) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * logf(u0));
+    float sn, cs;
+    sincosf(6.2831853071795865f * u1, &sn, &cs);
+    g0 = r * cs;
+    g1 = r * sn;
+}
+
 __global__ void __launch_bounds__(kThreads)
 gen_signal_kernel(void *__restrict__ re_v, void *__restrict__ im_v, int format, long long N,
                   int M, long long ant_stride, long long block_stride, int K,
                   const gat_channel_params *__restrict__ params, const int8_t *__restrict__ codes,
-                  int code_row_stride, int Lc, int num_prns, double fs, float amplitude)
+                  int code_row_stride, int Lc, int num_prns, double fs, float amplitude,
+                  const float *__restrict__ steering_cycles, float noise_sigma, unsigned long long seed)
 {
     const int b = blockIdx.y;
     const float inv_lc = 1.0f / (float)Lc;
@@ -210,8 +229,21 @@ gen_signal_kernel(void *__restrict__ re_v, void *__restrict__ im_v, int format, 
         }
         sr *= amplitude;
         si *= amplitude;
+        const float sr0 = sr, si0 = si;
         for (int m = 0; m < M; ++m) {
             const size_t e = (size_t)b * block_stride + (size_t)m * ant_stride + n;
+            if (steering_cycles) { // per-antenna unit-modulus steering phase
+                float c_, s_;
+                sincos_cycles((double)steering_cycles[m], c_, s_);
+                sr = sr0 * c_ - si0 * s_;
+                si = sr0 * s_ + si0 * c_;
+            }
+            if (noise_sigma > 0.f) { // complex white Gaussian noise, variance sigma^2 per component (scaled like the signal)
+                float g0, g1;
+                gauss_pair(seed, ((unsigned long long)b * (unsigned long long)M + (unsigned long long)m) * (unsigned long long)N + (unsigned long long)n, g0, g1);
+                sr = (steering_cycles ? sr : sr0) + amplitude * noise_sigma * g0;
+                si = (steering_cycles ? si : si0) + amplitude * noise_sigma * g1;
+            }
             if (format == GAT_LAYOUT_PLANAR) {
                 static_cast<float *>(re_v)[e] = sr;
                 static_cast<float *>(im_v)[e] = si;
@@ -420,13 +452,14 @@ hipError_t launch_accumulate_debug(const float *sig_re, const float *sig_im, lon
 hipError_t launch_gen_signal(void *re, void *im, int format, long long N, int M,
                              long long ant_stride, long long block_stride, int B, int K,
                              const gat_channel_params *params, const int8_t *codes, int code_row_stride,
-                             int Lc, int num_prns, double fs, float amplitude, hipStream_t s)
+                             int Lc, int num_prns, double fs, float amplitude, const float *steering_cycles, float noise_sigma,
+                             unsigned long long seed, hipStream_t s)
 {
     long long bx = (N + kThreads - 1) / kThreads;
     if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(gen_signal_kernel, dim3((unsigned)bx, (unsigned)B), dim3(kThreads), 0, s, re,
                        im, format, N, M, ant_stride, block_stride, K, params, codes, code_row_stride, Lc,
-                       num_prns, fs, amplitude);
+                       num_prns, fs, amplitude, steering_cycles, noise_sigma, seed);
     return hipGetLastError();
 }
 

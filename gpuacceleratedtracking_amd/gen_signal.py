@@ -66,14 +66,17 @@ _LAYOUT_DTYPE = {_lib.GAT_LAYOUT_INTERLEAVED: torch.float32, _lib.GAT_LAYOUT_INT
 
 def gen_signal_stream(system: GNSSSystem, params: np.ndarray, sampling_frequency: float, num_samples: int,
                       num_ants: int = 1, layout: int = _lib.GAT_LAYOUT_PLANAR, device=None,
-                      amplitude: float = 1.0, ant_pad: int = 0):
+                      amplitude: float = 1.0, ant_pad: int = 0, steering_cycles=None, noise_sigma: float = 0.0,
+                      seed: int = 0):
     """Batched form used by the stream benchmark: ``params`` is [B, K] (carrier phase in
     RADIANS, as ``start_carrier_phase`` in src/gen_signal.jl:88); block b holds the sum of its K
     channels times ``amplitude``.  Returns tensors: planar (re [M, B*N], im [M, B*N]) float32;
     interleaved layouts (x [M, B*N, 2], None) of float32 / int16 / int8 (integer layouts store
     ``rint(amplitude * x)`` saturated -- what an ADC front-end delivers).  ``ant_pad``: extra samples between
     the antennas' streams (the returned tensors are views [M, B*N(, 2)] of a padded allocation): antenna planes
-    whose distance is a large power-of-two multiple collide on the same memory channels."""
+    whose distance is a large power-of-two multiple collide on the same memory channels.  ``steering_cycles`` (M phases in
+    cycles), ``noise_sigma``, ``seed``: per-antenna steering and complex white Gaussian noise (gat_gen_signal_noisy; the
+    reference's generator is noise-free with identical antennas)."""
     ctx = get_context(device)
     ctx.set_codes(system.codes)
     params = np.ascontiguousarray(params, dtype=_lib.PARAMS_DTYPE)
@@ -89,8 +92,11 @@ def gen_signal_stream(system: GNSSSystem, params: np.ndarray, sampling_frequency
     else:
         re = torch.empty((m, row, 2), dtype=_LAYOUT_DTYPE[layout], device=ctx.device)[:, :B * num_samples]
         im = None
+    steer = None
+    if steering_cycles is not None:
+        steer = torch.as_tensor(np.ascontiguousarray(steering_cycles, dtype=np.float32)).to(ctx.device)
     ctx.gen_signal(re, im, layout, num_samples, m, row, num_samples, B, K, dparams,
-                   sampling_frequency, amplitude)
+                   sampling_frequency, amplitude, steering_cycles=steer, noise_sigma=noise_sigma, seed=seed)
     return re, im
 
 

@@ -219,6 +219,18 @@ GAT_API int32_t gat_gen_signal(gat_ctx *ctx, void *re_dev, void *im_dev, int32_t
                                const gat_channel_params *params_dev, double sampling_freq_hz,
                                double amplitude);
 
+/* The same generator with what a receiver's input has and the reference's noise-free one lacks (paper/paper.tex:116;
+ * SURVEY section 8-d "build additions"): a unit-modulus steering phase per antenna (steering_cycles_dev: M floats in cycles on
+ * the device, or NULL: identical antennas) and complex white Gaussian noise of standard deviation noise_sigma per component
+ * (in units of one satellite's amplitude; scaled by `amplitude` like the signal).  The noise of sample (block, antenna, n) is a
+ * pure function of (seed, block, antenna, n) -- counter-based, independent of the launch geometry and of the layout. */
+GAT_API int32_t gat_gen_signal_noisy(gat_ctx *ctx, void *re_dev, void *im_dev, int32_t layout,
+                                     int64_t num_samples, int32_t num_ants, int64_t ant_stride,
+                                     int64_t block_stride, int32_t num_blocks, int32_t num_channels,
+                                     const gat_channel_params *params_dev, double sampling_freq_hz,
+                                     double amplitude, const float *steering_cycles_dev, double noise_sigma,
+                                     uint64_t seed);
+
 /* reduce_cplx_multi_3/4/5 two-pass sum (src/reduction.jl:93, :331, :548; launch sequence
  * src/algorithms.jl:914-922): column sums of a planar complex [n x num_cols] array.
  * Deterministic; no single-block second pass limit (SURVEY defect D6). */

@@ -283,6 +283,18 @@ function downconvert_and_accumulate!(ctx::Context, signal::HipSignal, prm::Chann
                      dw_re, dw_im, accum_re, accum_im))
 end
 
+# ---- synthetic input on the device: gen_signal! (src/gen_signal.jl:53-175) and its noisy, steered form (AWGN sigma per
+#      component, per-antenna steering phases in cycles; the reference's generator is noise-free, paper/paper.tex:116)
+function gen_signal!(ctx::Context, signal::HipSignal, params_dev::Ptr{Cvoid}, K::Integer, sampling_frequency_hz::Float64;
+                     amplitude = 1.0, steering_cycles_dev::Ptr{Cfloat} = Ptr{Cfloat}(C_NULL), noise_sigma = 0.0, seed = UInt64(0))
+    check(ctx, ccall((:gat_gen_signal_noisy, libgat), Int32,
+                     (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int64, Int32, Int64, Int64, Int32, Int32, Ptr{Cvoid}, Float64, Float64,
+                      Ptr{Cfloat}, Float64, UInt64),
+                     ctx.handle, signal.re, signal.im, signal.layout, signal.num_samples, signal.num_ants, signal.num_samples,
+                     signal.num_samples, 1, K, params_dev, sampling_frequency_hz, Float64(amplitude), steering_cycles_dev,
+                     Float64(noise_sigma), UInt64(seed)))
+end
+
 # ---- several GPUs from one Julia task: one context per device, channels sharded contiguously, no collective
 #      (include/gat.h gat_group_*; the C form of this sequence is examples/gat_multi_gpu.c)
 mutable struct DeviceGroup

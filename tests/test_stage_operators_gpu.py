@@ -145,3 +145,54 @@ def test_gen_code_replica_nsat_bit_exact(g):
     one = torch.zeros(n, dtype=torch.float32, device=ctx.device)
     ctx.gen_code_replica(one, n, int(prns[2]) - 1, fc[2], fs, tau[2], first)
     assert torch.equal(one, rep[2, :n])
+
+
+def test_noisy_generator_steering_noise_statistics_and_parity(g):
+    """gat_gen_signal_noisy (SURVEY section 8-d build additions; the reference's generator is noise-free with identical
+    antennas, src/gen_signal.jl:86-90): (1) sigma = 0 + steering == the noise-free signal rotated per antenna; (2) the noise
+    is zero-mean white Gaussian of the requested sigma, a pure function of the seed (same seed -> same bits, in another
+    layout too), different per antenna and per seed; (3) the correlator on the noisy multi-antenna signal still matches the
+    FP64 oracle run on the very same samples."""
+    import torch
+    import oracle
+    system = g.GPSL1(use_gpu=True)
+    N, M, B, K = 20000, 4, 3, 2
+    fs = N / 1e-3
+    prm = g.make_params(np.array([[2, 9]] * B), 1.023e6, np.array([[1500.0, -2300.0]] * B), np.array([[100.25, 811.5]] * B), 0.0)
+    steer = np.array([0.0, 0.125, 0.5, 0.71], dtype=np.float32)
+    base_re, base_im = g.gen_signal_stream(system, prm, fs, N, M)
+    st_re, st_im = g.gen_signal_stream(system, prm, fs, N, M, steering_cycles=steer)
+    rot = np.exp(2j * np.pi * steer.astype(np.float64))[:, None]
+    want = (base_re.cpu().numpy() + 1j * base_im.cpu().numpy()) * rot
+    got = st_re.cpu().numpy() + 1j * st_im.cpu().numpy()
+    assert np.abs(got - want).max() < 2e-6
+    sigma = 1.5
+    n1 = g.gen_signal_stream(system, prm, fs, N, M, steering_cycles=steer, noise_sigma=sigma, seed=7)
+    n2 = g.gen_signal_stream(system, prm, fs, N, M, steering_cycles=steer, noise_sigma=sigma, seed=7)
+    n3 = g.gen_signal_stream(system, prm, fs, N, M, steering_cycles=steer, noise_sigma=sigma, seed=8)
+    assert torch.equal(n1[0], n2[0]) and torch.equal(n1[1], n2[1])
+    assert not torch.equal(n1[0], n3[0])
+    noise = (n1[0].cpu().numpy() + 1j * n1[1].cpu().numpy()) - got
+    assert abs(noise.real.mean()) < 0.02 and abs(noise.imag.mean()) < 0.02
+    assert abs(noise.real.std() - sigma) < 0.02 and abs(noise.imag.std() - sigma) < 0.02
+    assert abs(np.corrcoef(noise.real.ravel(), noise.imag.ravel())[0, 1]) < 0.01
+    assert abs(np.corrcoef(noise[0].real, noise[1].real)[0, 1]) < 0.02            # antennas: independent noise
+    assert abs(np.corrcoef(noise[0].real[:-1], noise[0].real[1:])[0, 1]) < 0.02    # white
+    kurt = np.mean(noise.real ** 4) / sigma ** 4
+    assert abs(kurt - 3.0) < 0.1                                                    # Gaussian
+    il = g.gen_signal_stream(system, prm, fs, N, M, layout=g.GAT_LAYOUT_INTERLEAVED, steering_cycles=steer, noise_sigma=sigma, seed=7)[0]
+    assert torch.equal(il[..., 0], n1[0]) and torch.equal(il[..., 1], n1[1])        # same noise in another layout
+    # parity on the noisy signal
+    corr = g.EarlyPromptLateCorrelator(g.NumAnts(M), g.NumAccumulators(3))
+    shifts = g.get_correlator_sample_shifts(system, corr, fs, 0.5)
+    op = g.StreamCorrelator(system, N, M, B, K, shifts, fs)
+    op.set_params(prm)
+    op(n1[0], n1[1])
+    oprm = oracle.make_params(prm["prn"], prm["code_freq_hz"], prm["carrier_freq_hz"], prm["code_phase_chips"], prm["carrier_phase_cycles"])
+    ref = oracle.correlate_f64(n1[0].cpu().numpy(), n1[1].cpu().numpy(), system.codes, oprm, fs, shifts, N=N)
+    res = op.result()
+    err = np.max(np.abs(res - ref) / np.abs(ref).max(axis=(2, 3), keepdims=True))
+    assert err <= 1e-5, err
+    # each antenna's prompt carries its steering phase
+    ph = np.angle(res[0, 0, 1, :] / res[0, 0, 1, 0]) / (2 * np.pi)
+    assert np.allclose((ph - steer + 0.5) % 1.0 - 0.5, 0.0, atol=0.01)
