@@ -169,6 +169,9 @@ __device__ __forceinline__ void frag_wait(FragSet<RT, X1> &s)
 template <int RT>
 constexpr int frag_depth() { return (15 / (2 + RT)) < 4 ? (15 / (2 + RT)) : 4; }
 
+template <int J, int RT, bool X1>
+__device__ __forceinline__ void mfma_apply(f32x16 (&acc)[RT == 1 ? 2 : RT], FragSet<RT, X1> &cur);
+
 template <int J, int NM, int RT, bool X1>
 __device__ __forceinline__ void mfma_slice(f32x16 (&acc)[RT == 1 ? 2 : RT], FragSet<RT, X1> (&fs)[frag_depth<RT>() + 1], unsigned w_addr,
                                            unsigned r_addr, const unsigned (&x_addr)[RT])
@@ -179,6 +182,12 @@ __device__ __forceinline__ void mfma_slice(f32x16 (&acc)[RT == 1 ? 2 : RT], Frag
     constexpr int newer = (NM - 1 - J) < (D - 1) ? (NM - 1 - J) : (D - 1);
     frag_wait<RT, X1, newer *(2 + RT)>(cur);
     if constexpr (J + D < NM) frag_issue<J + D, RT, X1>(fs[(J + D) % (D + 1)], w_addr, r_addr, x_addr);
+    mfma_apply<J, RT, X1>(acc, cur);
+}
+// the arithmetic of one k-slice: chip signs onto W, the {a, a} halves of the X fragments, RT MFMAs
+template <int J, int RT, bool X1>
+__device__ __forceinline__ void mfma_apply(f32x16 (&acc)[RT == 1 ? 2 : RT], FragSet<RT, X1> &cur)
+{
     u32x4 w = cur.w;
 #if defined(GAT_ABLATE) && (GAT_ABLATE & 64)
     if constexpr (!X1) w = u32x4{cur.wl[0], cur.wl[1], cur.wl[0], cur.wl[1]};
@@ -237,6 +246,42 @@ __device__ __forceinline__ void mfma_step(f32x16 (&acc)[RT == 1 ? 2 : RT], unsig
     if constexpr (NM > 2 && D > 2) frag_issue<2, RT, X1>(fs[2], w_addr, r_addr, x_addr);
     if constexpr (NM > 3 && D > 3) frag_issue<3, RT, X1>(fs[3], w_addr, r_addr, x_addr);
     (mfma_slice<J, NM, RT, X1>(acc, fs, w_addr, r_addr, x_addr), ...);
+}
+
+// ---- k-slices pipelined ACROSS the step barrier (round 3) ---------------------------------------------------------
+// mfma_step above starts every step with an empty pipeline: after the barrier the first fragments have to come in before the
+// first MFMA can issue -- one LDS round trip under load per 32-sample step, ~12 % of the consumers' time at configs[4].
+// Here the fragment ring lives across steps: the last D slices of a step are fetched BEFORE the barrier (all of the step's
+// reads are home by then: the producers may overwrite its buffer) and their MFMAs run AFTER it, while the first D slices of
+// the next step -- from the other buffer, complete at the barrier -- are already on their way.  R = ring position of the
+// step's slice 0 (the ring has D + 1 sets and a step NM slices: R advances by NM mod (D + 1) per step).  There are always
+// exactly D - 1 newer slices in flight at a wait (after the last step too: its "next step" reads fetch stale data nobody uses).
+template <int J, int NM, int RT, bool X1, int R>
+__device__ __forceinline__ void xstep_slice(f32x16 (&acc)[RT == 1 ? 2 : RT], FragSet<RT, X1> (&fs)[frag_depth<RT>() + 1], unsigned w_addr,
+                                            unsigned r_addr, const unsigned (&x_addr)[RT], int dw, int dr, int dx)
+{
+    constexpr int D = frag_depth<RT>(), RING = D + 1;
+    FragSet<RT, X1> &cur = fs[(R + J) % RING];
+    frag_wait<RT, X1, (D - 1) * (2 + RT)>(cur);
+    if constexpr (J + D < NM) {
+        frag_issue<J + D, RT, X1>(fs[(R + J + D) % RING], w_addr, r_addr, x_addr);
+    } else {
+        if constexpr (J + D == NM) { // the first fetch that belongs to the next step: this step's reads are home, then the barrier
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        unsigned x_next[RT]; // the other buffer: a wave-uniform distance away
+#pragma unroll
+        for (int t = 0; t < RT; ++t) x_next[t] = x_addr[t] + (unsigned)dx;
+        frag_issue<J + D - NM, RT, X1>(fs[(R + J + D) % RING], w_addr + (unsigned)dw, r_addr + (unsigned)dr, x_next);
+    }
+    mfma_apply<J, RT, X1>(acc, cur);
+}
+template <int NM, int RT, bool X1, int R, int... J>
+__device__ __forceinline__ void xstep(f32x16 (&acc)[RT == 1 ? 2 : RT], FragSet<RT, X1> (&fs)[frag_depth<RT>() + 1], unsigned w_addr,
+                                      unsigned r_addr, const unsigned (&x_addr)[RT], int dw, int dr, int dx, std::integer_sequence<int, J...>)
+{
+    (xstep_slice<J, NM, RT, X1, R>(acc, fs, w_addr, r_addr, x_addr, dw, dr, dx), ...);
 }
 
 struct ChanInfoB { // per channel slot of the workgroup, in LDS
@@ -680,6 +725,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         default: producer_loop(std::integral_constant<int, 4>{}); break;
         }
     } else {
+#if defined(GAT_MB_STEP_PIPELINE_OFF) || defined(GAT_MFMA_STAMPS) || (defined(GAT_ABLATE) && (GAT_ABLATE & 8))
         __syncthreads();
         for (int st = s_begin; st < s_end; st += 2) {
             GAT_STAMP(t0_);
@@ -698,6 +744,56 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
             GAT_ACC(t_work, t0_, t1_);
             GAT_ACC(t_wait, t1_, t2_);
         }
+#else
+        // k-slices pipelined across the step barrier (xstep above): one barrier per step as before, inside the slice stream.
+        // The ring position of a step's first slice advances by NM mod RING per step, so RING consecutive steps are
+        // unrolled (each with its position as a constant: no run-time choice between code copies -- a merge of copies
+        // would make the register allocator move fragment registers that are still being loaded); what is left over at the
+        // end (fewer than RING steps) runs unpipelined.
+        constexpr int D = frag_depth<RT>(), RING = D + 1;
+        static_assert(NM >= D, "a step holds at least as many slices as the fetch distance");
+        const int nsteps = s_end - s_begin, groups = nsteps > 0 ? nsteps / RING : 0;
+        // this lane's stream addresses in the CURRENT buffer only; the other buffer is a wave-uniform distance away (its
+        // addresses are formed when the look-ahead fetches are issued: six persistent registers less)
+        unsigned xa_c[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) xa_c[t] = lds_x + 8u * (unsigned)((t * 32) * XS + x_off);
+        unsigned wa_c = lds_w + 8u * WE * (unsigned)w_off;
+        unsigned ra_c = lds_r + 4u * (unsigned)r_off;
+        int dx = 8 * (RT * 32 * XS), dw = __builtin_amdgcn_readfirstlane(8 * WE * (wrows * WS)),
+            dr = __builtin_amdgcn_readfirstlane(4 * (nslots * RS)); // bytes from the current buffer to the other one (sign flips per step)
+        __syncthreads(); // the first step's buffer is complete
+        if (groups > 0) {
+            FragSet<RT, X1> fs[RING];
+            frag_issue<0, RT, X1>(fs[0], wa_c, ra_c, xa_c);
+            if constexpr (D > 1) frag_issue<1, RT, X1>(fs[1], wa_c, ra_c, xa_c);
+            if constexpr (D > 2) frag_issue<2, RT, X1>(fs[2], wa_c, ra_c, xa_c);
+            if constexpr (D > 3) frag_issue<3, RT, X1>(fs[3], wa_c, ra_c, xa_c);
+            auto one = [&](auto r_c) {
+                constexpr int R = decltype(r_c)::value;
+                xstep<NM, RT, X1, R>(acc, fs, wa_c, ra_c, xa_c, dw, dr, dx, std::make_integer_sequence<int, NM>{});
+                wa_c += (unsigned)dw; // the buffers change roles
+                ra_c += (unsigned)dr;
+#pragma unroll
+                for (int t = 0; t < RT; ++t) xa_c[t] += (unsigned)dx;
+                dw = -dw;
+                dr = -dr;
+                dx = -dx;
+            };
+            for (int g = 0; g < groups; ++g) {
+                one(std::integral_constant<int, 0>{});
+                if constexpr (RING > 1) one(std::integral_constant<int, (1 * NM) % RING>{});
+                if constexpr (RING > 2) one(std::integral_constant<int, (2 * NM) % RING>{});
+                if constexpr (RING > 3) one(std::integral_constant<int, (3 * NM) % RING>{});
+                if constexpr (RING > 4) one(std::integral_constant<int, (4 * NM) % RING>{});
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the last step's look-ahead reads (unused)
+        }
+        for (int st = s_begin + groups * RING; st < s_end; ++st) { // the remainder, unpipelined
+            consume((st - s_begin) & 1);
+            __syncthreads();
+        }
+#endif
     }
 #ifdef GAT_MFMA_STAMPS
     if (lane == 0 && a.dbg) { // [workgroup][wave][4]
