@@ -8,6 +8,7 @@
  *   dev    : gat_downconvert_and_correlate_dev (parameters already on the device) + gat_sync
  *   graph  : the same call with GAT_FLAG_GRAPH (the launch sequence replayed as one instantiated hipGraph) + gat_sync
  *   enqueue: the call alone, many in a row, one sync at the end (what the device needs per call when the host does not wait)
+ *   call   : host time inside the `dev` call itself (planning + the launches), median -- the rest of `dev` is waiting
  * Output: one line per grid point, minimum / median in microseconds.   build/gat_latency [reps]
  */
 #include <math.h>
@@ -46,10 +47,10 @@ int main(int argc, char **argv)
     int8_t *codes = malloc((size_t)lc * 32);
     CHECK(gat_gen_codes("GPSL1", 32, codes, &lc, &fc));
     CHECK(gat_set_codes(ctx, codes, lc, 32));
-    double *t = malloc(sizeof(double) * (size_t)reps);
+    double *t = malloc(sizeof(double) * (size_t)reps), *tc = malloc(sizeof(double) * (size_t)reps);
     const int Ms[2] = {1, 4}, Ls[2] = {3, 7};
     printf("# GPSL1, one 1 ms block per call, prn 1, 1500 Hz (src/benchmarks.jl:96-99); %d calls per point; microseconds\n", reps);
-    printf("# %8s %2s %2s | %-15s | %-15s | %-15s | %s\n", "N", "M", "L", "host min/med", "dev min/med", "graph min/med", "enqueue-only per call");
+    printf("# %8s %2s %2s | %-15s | %-15s | %-15s | %s | %s\n", "N", "M", "L", "host min/med", "dev min/med", "graph min/med", "enqueue-only per call", "call med");
     for (int e = 11; e <= 18; ++e)
         for (int mi = 0; mi < 2; ++mi)
             for (int li = 0; li < 2; ++li) {
@@ -64,19 +65,26 @@ int main(int argc, char **argv)
                 CHECK(gat_malloc(ctx, sizeof(float) * M * L, &o_re));
                 CHECK(gat_malloc(ctx, sizeof(float) * M * L, &o_im));
                 const gat_channel_params p = {0, 0, fc, 1500.0, 0.0, 0.0};
+                float h[4 * 7] = {0};
+                CHECK(gat_memcpy_h2d(ctx, o_re, h, sizeof(float) * M * L)); /* the prompt printed below is this run's */
                 CHECK(gat_memcpy_h2d(ctx, prm_dev, &p, sizeof p));
                 CHECK(gat_gen_signal(ctx, re, im, GAT_LAYOUT_PLANAR, N, M, N, N, 1, 1, prm_dev, fs, 1.0));
                 const gat_signal_desc sig = {re, im, GAT_LAYOUT_PLANAR, M, N, N, N, 0};
-                double res[3][2];
+                double res[3][2], call_med = 0.0;
                 for (int mode = 0; mode < 3; ++mode) {
                     for (int r = -50; r < reps; ++r) { /* 50 untimed calls first */
                         const double t0 = now_us();
                         if (mode == 0) CHECK(gat_downconvert_and_correlate(ctx, &sig, &p, 1, 1, L, shifts, fs, o_re, o_im, 0));
                         else CHECK(gat_downconvert_and_correlate_dev(ctx, &sig, prm_dev, 1, 1, L, shifts, fs, o_re, o_im, mode == 2 ? GAT_FLAG_GRAPH : 0));
+                        const double t1 = now_us();
                         CHECK(gat_sync(ctx));
-                        if (r >= 0) t[r] = now_us() - t0;
+                        if (r >= 0) t[r] = now_us() - t0, tc[r] = t1 - t0;
                     }
                     qsort(t, (size_t)reps, sizeof(double), cmp_d);
+                    if (mode == 1) {
+                        qsort(tc, (size_t)reps, sizeof(double), cmp_d);
+                        call_med = tc[reps / 2];
+                    }
                     res[mode][0] = t[0];
                     res[mode][1] = t[reps / 2];
                 }
@@ -85,14 +93,14 @@ int main(int argc, char **argv)
                 for (int r = 0; r < reps; ++r) CHECK(gat_downconvert_and_correlate_dev(ctx, &sig, prm_dev, 1, 1, L, shifts, fs, o_re, o_im, 0));
                 CHECK(gat_sync(ctx));
                 const double per = (now_us() - t0) / reps;
-                float h[4 * 7];
                 CHECK(gat_memcpy_d2h(ctx, h, o_re, sizeof(float) * M * L));
-                printf("  %8d %2d %2d | %6.2f / %6.2f | %6.2f / %6.2f | %6.2f / %6.2f | %6.2f   (prompt %.0f)\n", N, M, L, res[0][0], res[0][1],
-                       res[1][0], res[1][1], res[2][0], res[2][1], per, h[(L / 2) * M]);
+                printf("  %8d %2d %2d | %6.2f / %6.2f | %6.2f / %6.2f | %6.2f / %6.2f | %6.2f | %5.2f   (prompt %.0f)\n", N, M, L, res[0][0], res[0][1],
+                       res[1][0], res[1][1], res[2][0], res[2][1], per, call_med, h[(L / 2) * M]);
                 fflush(stdout);
                 gat_free(ctx, re); gat_free(ctx, im); gat_free(ctx, prm_dev); gat_free(ctx, o_re); gat_free(ctx, o_im);
             }
     free(t);
+    free(tc);
     free(codes);
     gat_destroy(ctx);
     return 0;

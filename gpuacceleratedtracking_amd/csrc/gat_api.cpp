@@ -165,13 +165,32 @@ int32_t ensure_partial(gat_ctx *c, size_t bytes)
     return GAT_OK;
 }
 
+// the parameter records of a host call reach the device: into the context's buffer, on the context's stream
+int32_t upload_params(gat_ctx *c, const gat_channel_params *params_host, size_t n)
+{
+    if (n > c->params_cap) {
+        if (c->d_params) {
+            GAT_HIP(c, hipStreamSynchronize(c->stream));
+            GAT_HIP(c, hipFree(c->d_params));
+            c->d_params = nullptr;
+            c->params_cap = 0;
+        }
+        GAT_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->d_params), n * sizeof(gat_channel_params)));
+        c->params_cap = n;
+    }
+    GAT_HIP(c, hipMemcpyAsync(c->d_params, params_host, n * sizeof(gat_channel_params), hipMemcpyHostToDevice, c->stream));
+    return GAT_OK;
+}
+
+// params_dev: [B*K] records on the device -- or null with params_inline: B*K <= kInlineParams validated HOST records that
+// travel inside the vector kernel's arguments (uploaded after all if a matrix-core kernel takes the call)
 int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel_params *params_dev,
                        int32_t B, int32_t K, int32_t L, const int32_t *shifts, double fs,
-                       float *out_re, float *out_im, uint32_t flags)
+                       float *out_re, float *out_im, uint32_t flags, const gat_channel_params *params_inline = nullptr)
 {
     c->wait_seq = 0;
     const TraceRange trace("gat_downconvert_and_correlate");
-    if (!sig || !params_dev || !shifts || !out_re || !out_im) return fail(c, GAT_ERR_ARG, "null argument");
+    if (!sig || (!params_dev && !params_inline) || !shifts || !out_re || !out_im) return fail(c, GAT_ERR_ARG, "null argument");
     if (!c->d_codes) return fail(c, GAT_ERR_STATE, "gat_set_codes has not been called");
     const int fmt = sig->layout;
     if (fmt < GAT_LAYOUT_PLANAR || fmt > GAT_LAYOUT_INTERLEAVED_I8) return fail(c, GAT_ERR_ARG, "unknown signal layout");
@@ -277,6 +296,11 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         if (kind) {
             if (kind == 2) nct = nct_b;
             const int T = kind == 2 ? mfma_bf16_tile_samples(rt, nct) : 256;
+            if (!params_dev) {
+                const int32_t rc = upload_params(c, params_inline, (size_t)B * K);
+                if (rc != GAT_OK) return rc;
+                params_dev = c->d_params;
+            }
             MfArgs m{};
             m.re = sig->re;
             m.im = sig->im;
@@ -464,6 +488,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     a.re = sig->re;
     a.im = sig->im;
     a.params = params_dev;
+    if (!params_dev) std::memcpy(a.inl, params_inline, (size_t)B * K * sizeof(gat_channel_params));
     a.codes = c->d_codes;
     a.out_re = out_re;
     a.out_im = out_im;
@@ -936,18 +961,10 @@ GAT_API int32_t gat_downconvert_and_correlate(gat_ctx *c, const gat_signal_desc 
         if (!code_span_ok(p.code_freq_hz / fs, p.code_phase_chips, (double)(sig->num_samples + max_shift), c->Lc))
             return fail(c, GAT_ERR_RANGE, "code phase span too large");
     }
-    if (n > c->params_cap) {
-        if (c->d_params) {
-            GAT_HIP(c, hipStreamSynchronize(c->stream));
-            GAT_HIP(c, hipFree(c->d_params));
-            c->d_params = nullptr;
-            c->params_cap = 0;
-        }
-        GAT_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->d_params), n * sizeof(gat_channel_params)));
-        c->params_cap = n;
-    }
-    GAT_HIP(c, hipMemcpyAsync(c->d_params, params_host, n * sizeof(gat_channel_params),
-                              hipMemcpyHostToDevice, c->stream));
+    if (n <= (size_t)kInlineParams) // no upload: the records ride in the kernel arguments
+        return correlate_impl(c, sig, nullptr, B, K, L, shifts, fs, out_re, out_im, flags, params_host);
+    const int32_t rc = upload_params(c, params_host, n);
+    if (rc != GAT_OK) return rc;
     return correlate_impl(c, sig, c->d_params, B, K, L, shifts, fs, out_re, out_im, flags);
 }
 

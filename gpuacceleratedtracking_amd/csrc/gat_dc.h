@@ -195,10 +195,29 @@ struct SampleIO {
 // pinned host memory, where gat_sync spins on it -- a kernel's end reaches the host ~5 us sooner that way than through
 // hipStreamSynchronize (scripts/sync_probe.hip: 7.0 vs 11.7 us for an empty kernel).  Called by every thread of every
 // workgroup that did work, after its result stores.
+// Kernel arguments live in host memory on this platform (the runtime's kernarg pool): a scalar load that misses the
+// scalar cache crosses PCIe (~1 us), and the compiler sinks each argument's load to its first use -- a kernel with 300
+// bytes of arguments then pays that round trip once per 64-byte line, one after the other (set-up, replica, steps, tail:
+// scripts/r03_latency_cuts.sh).  Touching every line at the kernel's first instruction overlaps them into one.
+template <int BYTES>
+__device__ __forceinline__ void kernarg_prefetch()
+{
+    typedef const unsigned __attribute__((address_space(4))) *kptr;
+    kptr k = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned s = 0;
+#pragma unroll
+    for (int i = 0; i < (BYTES + 63) / 64; ++i) s |= __builtin_nontemporal_load(k + i * 16);
+    asm volatile("" ::"s"(s));
+}
+
 __device__ __forceinline__ void completion_flag(unsigned *done_counter, unsigned *host_flag, unsigned seq, unsigned total_wgs)
 {
     if (!done_counter) return; // launch-uniform
     __syncthreads(); // every thread of this workgroup has issued its result stores
+    if (total_wgs == 1u) { // nobody else to wait for: the release store alone (0.6 us less than with the counter, sync_probe2.hip)
+        if (threadIdx.x == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
     if (threadIdx.x == 0) {
         // this XCD's L2 holds the workgroup's results: written back before it counts as arrived (the host may hand the
         // buffers to a copy engine or another stream as soon as it sees the flag)
@@ -222,6 +241,22 @@ __device__ __forceinline__ void completion_flag(unsigned *done_counter, unsigned
 #define GAT_DC_MINW 3
 #endif
 constexpr int dc_min_waves(int mt, int l, int kt, int d = 1) { return 2 * mt * l * kt <= 40 ? (d == 1 && 2 * mt * l * kt >= 40 ? GAT_DC_MINW : 3) : 1; }
+
+// Diagnostic builds (-DGAT_DC_LAT_CUT=n, scripts/r03_latency_cuts.sh): the kernel ends at cut point n -- 1 entry, 2 block
+// set-up + chip tables, 3 first replica segment + carrier anchors, 4 step loop -- so that the single-block latency can be
+// attributed to its phases (5: + reduction up to its barrier, 6: everything but the result stores).  Results are wrong by
+// construction; never part of the product build.
+#ifdef GAT_DC_LAT_CUT
+#define GAT_DC_LAT_CUT_AT(n)                                                                  \
+    do {                                                                                      \
+        if (GAT_DC_LAT_CUT == (n)) {                                                          \
+            completion_flag(a.done_counter, a.host_flag, a.flag_seq, a.total_wgs);            \
+            return;                                                                           \
+        }                                                                                     \
+    } while (0)
+#else
+#define GAT_DC_LAT_CUT_AT(n) do { } while (0)
+#endif
 
 template <int MT, int L, int VEC, int FMT, int AW, int KT, bool KEEP, int NW, int D>
 __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel(const DcArgs a)
@@ -247,6 +282,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
     static_assert(AW == 1 || AW == 2 || AW == 4, "antenna-tile waves");
     static_assert(KT == 1 || KT == 2 || KT == 4, "channels per workgroup");
 
+    kernarg_prefetch<sizeof(DcArgs)>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     struct ChanConst { double ratio, tau, step, phi; }; // per channel slot: read at segment starts and on ragged ends
     ChanConst *s_const = reinterpret_cast<ChanConst *>(smem);                          // [KT]
@@ -273,6 +309,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
     const int kg = (int)(jq % (unsigned)a.KG);
     unsigned tile = (jq / (unsigned)a.KG) * 8u + xcd;
     if (tile >= (unsigned)a.num_tiles) return; // padding of the last group of 8 (whole workgroup exits)
+    GAT_DC_LAT_CUT_AT(1);
     const int split = tile % a.splits;
     tile /= a.splits;
     const int ag = tile % a.ant_groups;
@@ -314,6 +351,59 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
         if (b >= a.B) break;
         const bool next_block = bb + 1 < a.blocks_per_wg && b + 1 < a.B && c_begin < c_full; // splits == 1 here
 
+        // Sample loads are raw buffer loads through ONE descriptor per plane that spans the wave's MT antennas of this
+        // block (built once per step from wave-uniform values); the antenna is the instruction's scalar offset, the lane
+        // offset is shared by every load of a step.  Lanes beyond the block's end get the offset 2^31: beyond every
+        // record (the host keeps a tile's span below 2^31), they read zeros without touching memory -- the ragged
+        // last chunk needs no special path (measured on gfx950: the range check is per dword and covers voffset +
+        // soffset).  (A descriptor per (antenna, plane) of one block's length needs no lane mask but ~6 scalar
+        // instructions per load: a fifth of all instructions of the four-antenna five-tap step.)  The cache policy is a template parameter: a
+        // wave-uniform `if (keep) plain else non-temporal` pair of ordinary loads is merged by the compiler into plain
+        // loads (the hint is only metadata; that cost 7 % at configs[1]), and the same branch around buffer loads
+        // breaks the step into many basic blocks (+ 50 registers).
+        const size_t base = (size_t)b * a.block_stride + (size_t)kg * a.chan_stride /* != 0 only with KT == 1 */ +
+                            (size_t)((ag * AW + at_w) * MT) * a.ant_stride;
+        const char *const p_re = static_cast<const char *>(a.re) + base * EB;
+        const char *const p_im = static_cast<const char *>(FMT == GAT_LAYOUT_PLANAR ? a.im : a.re) + base * EB;
+        const size_t ant_bytes = (size_t)a.ant_stride * EB;
+        const size_t blk_bytes = (size_t)a.block_stride * EB;
+        const int blk_len = N * EB; // bytes of one antenna's block
+        const unsigned tile_len = (unsigned)((MT - 1) * ant_bytes) + (unsigned)blk_len; // the descriptors' num_records (host: < 2^31)
+        constexpr unsigned kNoRecord = 0x80000000u;
+        auto plane_rsrc = [&](const char *p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p), 0, (int)tile_len, 0x00020000); };
+        auto lane_offset = [&](unsigned off) { return off < (unsigned)blk_len ? off : kNoRecord; };
+
+        // 16-byte loads of antenna m's group at byte offset `off` of the block that starts at (bre, bim) (KEEP: plain
+        // loads that stay in L2 for the other channel groups, otherwise non-temporal: aux bit 1)
+        auto load_ant = [&](i32x4 (&raw)[IO::NV], int m, __amdgpu_buffer_rsrc_t rr, __amdgpu_buffer_rsrc_t ri, unsigned off) {
+#if defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 1)
+            off &= 0x3ff0u; // every load hits the same 16 KB (cache-resident): the arithmetic without the HBM stream
+#endif
+            constexpr int aux = KEEP ? 0 : 2;
+            const int soff = (int)((unsigned)m * (unsigned)ant_bytes); // wave-uniform
+            raw[0] = (i32x4)__builtin_amdgcn_raw_buffer_load_b128(rr, off, soff, aux);
+            if constexpr (IO::NV == 2) raw[1] = (i32x4)__builtin_amdgcn_raw_buffer_load_b128(ri, off, soff, aux);
+        };
+        // ---- the block's first samples: requested before anything else (they depend on the launch geometry only), so
+        // that their trip from HBM overlaps the parameter fetch, the chip-table staging and the first replica segment --
+        // in a single-block call that trip is a fifth of the kernel's time (scripts/r03_latency_cuts.sh)
+        if (c_begin < c_full && !preloaded) {
+            const __amdgpu_buffer_rsrc_t rr = plane_rsrc(p_re), ri = plane_rsrc(p_im);
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const unsigned off = lane_offset((unsigned)((c_begin + d) * CHUNK + g * GSTRIDE + rel0) * EB);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        load_ant(raw[d][g][m], m, rr, ri, off);
+                        // the order of the step loop's refills: the scheduler would group the preload by plane, and the
+                        // compiler's wait counts at the loop head are exact only if both orders agree
+                        if constexpr (D > 1) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        }
+
         // ---- per-channel constants of this block --------------------------------------------------------------
         // The double-precision ones (code rate, code phase, carrier step, carrier phase) are needed at segment starts
         // and on ragged ends only: they live in LDS.  In registers (wave-uniform -> scalar): the one-sample and
@@ -326,7 +416,22 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
         for (int kk = 0; kk < KT; ++kk) {
             const int k = kg * KT + kk;
             const bool valid = k < a.K;
-            const gat_channel_params P = a.params[(size_t)b * a.K + (valid ? k : a.K - 1)];
+            const size_t pi_ = (size_t)b * a.K + (valid ? k : a.K - 1); // wave-uniform
+            gat_channel_params P;
+            if (a.params) {
+                P = a.params[pi_];
+            } else { // records inside the kernel arguments: scalar loads from the constant address space (written as
+                     // `a.inl[pi_]` the compiler merges both sources into one FLAT vector load)
+                typedef const unsigned long long __attribute__((address_space(4))) *kwords;
+                kwords w = (kwords)__builtin_amdgcn_kernarg_segment_ptr() + (offsetof(DcArgs, inl) / 8 + pi_ * 5);
+                static_assert(sizeof(gat_channel_params) == 40 && offsetof(DcArgs, inl) % 8 == 0, "record = five 8-byte words");
+                P.prn = (int)(unsigned)w[0];
+                P.reserved = 0;
+                P.code_freq_hz = __longlong_as_double((long long)w[1]);
+                P.carrier_freq_hz = __longlong_as_double((long long)w[2]);
+                P.code_phase_chips = __longlong_as_double((long long)w[3]);
+                P.carrier_phase_cycles = __longlong_as_double((long long)w[4]);
+            }
             double ratio = P.code_freq_hz / a.fs;         // src/algorithms.jl:179 (Float64 division)
             double tau = P.code_phase_chips;
             double step = P.carrier_freq_hz / a.fs;       // cycles per sample
@@ -365,6 +470,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
             }
         }
         __syncthreads(); // s_const and the tables are in place
+        GAT_DC_LAT_CUT_AT(2);
 
         // ---- replica producer: walk constants of this thread's channel ----------------------------------------
         // one producer step advances RPC samples (the thread's next entry)
@@ -392,28 +498,6 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int l = 0; l < L; ++l) acc[kk][m][l] = f32x2{0.f, 0.f};
-
-        // Sample loads are raw buffer loads through ONE descriptor per plane that spans the wave's MT antennas of this
-        // block (built once per step from wave-uniform values); the antenna is the instruction's scalar offset, the lane
-        // offset is shared by every load of a step.  Lanes beyond the block's end get the offset 2^31: beyond every
-        // record (the host keeps a tile's span below 2^31), they read zeros without touching memory -- the ragged
-        // last chunk needs no special path (measured on gfx950: the range check is per dword and covers voffset +
-        // soffset).  (A descriptor per (antenna, plane) of one block's length needs no lane mask but ~6 scalar
-        // instructions per load: a fifth of all instructions of the four-antenna five-tap step.)  The cache policy is a template parameter: a
-        // wave-uniform `if (keep) plain else non-temporal` pair of ordinary loads is merged by the compiler into plain
-        // loads (the hint is only metadata; that cost 7 % at configs[1]), and the same branch around buffer loads
-        // breaks the step into many basic blocks (+ 50 registers).
-        const size_t base = (size_t)b * a.block_stride + (size_t)kg * a.chan_stride /* != 0 only with KT == 1 */ +
-                            (size_t)((ag * AW + at_w) * MT) * a.ant_stride;
-        const char *const p_re = static_cast<const char *>(a.re) + base * EB;
-        const char *const p_im = static_cast<const char *>(FMT == GAT_LAYOUT_PLANAR ? a.im : a.re) + base * EB;
-        const size_t ant_bytes = (size_t)a.ant_stride * EB;
-        const size_t blk_bytes = (size_t)a.block_stride * EB;
-        const int blk_len = N * EB; // bytes of one antenna's block
-        const unsigned tile_len = (unsigned)((MT - 1) * ant_bytes) + (unsigned)blk_len; // the descriptors' num_records (host: < 2^31)
-        constexpr unsigned kNoRecord = 0x80000000u;
-        auto plane_rsrc = [&](const char *p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p), 0, (int)tile_len, 0x00020000); };
-        auto lane_offset = [&](unsigned off) { return off < (unsigned)blk_len ? off : kNoRecord; };
 
         // chips of the sample at segment-relative position rel, for the L taps (scalar path)
         auto get_chips = [&](float (&chip)[L], int rel, const float *rep) {
@@ -498,17 +582,6 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
                     ac[l][0] = __builtin_fmaf(chip[j][l], dr[j], ac[l][0]);
                     ac[l][1] = __builtin_fmaf(chip[j][l], di[j], ac[l][1]);
                 }
-        };
-        // 16-byte loads of antenna m's group at byte offset `off` of the block that starts at (bre, bim) (KEEP: plain
-        // loads that stay in L2 for the other channel groups, otherwise non-temporal: aux bit 1)
-        auto load_ant = [&](i32x4 (&raw)[IO::NV], int m, __amdgpu_buffer_rsrc_t rr, __amdgpu_buffer_rsrc_t ri, unsigned off) {
-#if defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 1)
-            off &= 0x3ff0u; // every load hits the same 16 KB (cache-resident): the arithmetic without the HBM stream
-#endif
-            constexpr int aux = KEEP ? 0 : 2;
-            const int soff = (int)((unsigned)m * (unsigned)ant_bytes); // wave-uniform
-            raw[0] = (i32x4)__builtin_amdgcn_raw_buffer_load_b128(rr, off, soff, aux);
-            if constexpr (IO::NV == 2) raw[1] = (i32x4)__builtin_amdgcn_raw_buffer_load_b128(ri, off, soff, aux);
         };
         // the S phasors of one group: carried phasor + S-1 rotations
         auto group_phasors = [&](float (&pr)[S], float (&pi)[S], int kk, int g) {
@@ -606,22 +679,6 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
             else fill_impl(std::false_type{}, c0, seg_cnt);
         };
 
-        if (c_begin < c_full && !preloaded) {
-            const __amdgpu_buffer_rsrc_t rr = plane_rsrc(p_re), ri = plane_rsrc(p_im);
-#pragma unroll
-            for (int d = 0; d < D; ++d)
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const unsigned off = lane_offset((unsigned)((c_begin + d) * CHUNK + g * GSTRIDE + rel0) * EB);
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) {
-                        load_ant(raw[d][g][m], m, rr, ri, off);
-                        // the order of the step loop's refills: the scheduler would group the preload by plane, and the
-                        // compiler's wait counts at the loop head are exact only if both orders agree
-                        if constexpr (D > 1) __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-        }
         preloaded = next_block;
         const int c_last = VEC == 4 ? c_stop : c_end;
         for (int c0 = c_begin; c0 < c_last; c0 += SEG) {
@@ -641,6 +698,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
 #if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 8))
             __syncthreads();
 #endif
+            GAT_DC_LAT_CUT_AT(3);
 
             // ---- whole chunks.  The samples of step c+1 are loaded while step c is consumed: antenna by antenna, into
             // the registers that antenna's samples of step c have just left (loads in flight all the time, no second
@@ -772,6 +830,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
             }
         }
 
+        GAT_DC_LAT_CUT_AT(4);
         // ---- block reduction: per channel 2*MT*L values per wave -> butterfly -> waves sharing an antenna tile ----
 #pragma unroll
         for (int kk = 0; kk < KT; ++kk) {
@@ -788,7 +847,11 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
             s_part[(kk * NW + wave) * 64 + Butterfly<NV, 32>::index(lane)] = v[0];
         }
         __syncthreads();
+        GAT_DC_LAT_CUT_AT(5);
 
+#if defined(GAT_DC_LAT_CUT) && GAT_DC_LAT_CUT == 6
+        if (false)
+#endif
         for (int o = tid; o < KT * AW * NV; o += T) {
             const int kk = o / (AW * NV);
             const int r = o - kk * (AW * NV);
@@ -804,7 +867,11 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
             const int comp = vi & 1;
             const int ml = vi >> 1;
             const int m = (ag * AW + at) * MT + (ml % MT);
-            const int l = a.tap_index[ml / MT]; // position of this tap in the caller's shift list
+            // position of this tap in the caller's shift list (a select chain over scalar registers: indexed by a lane
+            // value the argument array would be read with a VECTOR load -- from host memory, uncached, ~2 us)
+            int l = a.tap_index[0];
+#pragma unroll
+            for (int q = 1; q < L; ++q) l = ml / MT == q ? a.tap_index[q] : l;
             const size_t bk = (size_t)b * a.K + k;
             const size_t oidx = (bk * a.Ltot + l) * a.M + m;
             if (a.flags & GAT_FLAG_ATOMIC) {

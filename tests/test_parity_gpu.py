@@ -117,6 +117,41 @@ def test_parity_grid(gat, cfg, layout):
     check_close(got, oracle_result(case), what=str(cfg))
 
 
+@pytest.mark.parametrize("cfg", [("GPSL1", 2048, 1, 3, 1, 1), ("GPSL1", 2048, 4, 7, 1, 1), ("GPSL1", 16384, 4, 3, 1, 1),
+                                 ("GPSL1", 5000, 2, 3, 2, 2), ("GPSL1", 5000, 2, 3, 5, 1), ("GPSL5", 20000, 4, 5, 3, 1),
+                                 ("GPSL1", 20000, 16, 3, 4, 1), ("GPSL1", 4099, 1, 9, 3, 1)],
+                         ids=lambda c: f"{c[0]}-N{c[1]}-M{c[2]}-L{c[3]}-K{c[4]}-B{c[5]}")
+def test_host_parameter_calls(gat, cfg):
+    """gat_downconvert_and_correlate (HOST parameter records -- the reference's call shape, scalars per call): up to four
+    records travel inside the kernel arguments (no upload in front of the launch), more are uploaded; a matrix-core kernel
+    that takes an inline call uploads them after all.  Every route must give the device-parameter call's result bit for bit."""
+    import torch
+    from gpuacceleratedtracking_amd import _lib
+    system, N, M, L, K, B = cfg
+    case = make_case(zlib.crc32(repr(("host", cfg)).encode()), system=system, N=N, M=M, L=L, K=K, B=B)
+    ctx = gat.get_context()
+    dev = ctx.device
+    ctx.set_codes(gat.GNSSDICT[system](use_gpu=True).codes)
+    re = torch.from_numpy(case["re"]).to(dev).contiguous()
+    im = torch.from_numpy(case["im"]).to(dev).contiguous()
+    assert re.shape == (M, B * N)
+    desc = _lib.SignalDesc(re.data_ptr(), im.data_ptr(), gat.GAT_LAYOUT_PLANAR, M, N, B * N, N, 0)
+    p = case["prm"]
+    prm = gat.make_params(p["prn0"], p["code_freq_hz"], p["carrier_freq_hz"], p["code_phase_chips"], p["carrier_phase_cycles"])
+    prm = np.ascontiguousarray(prm.reshape(-1))
+    prm_dev = torch.from_numpy(prm.view(np.uint8).copy()).to(dev)
+    outs = []
+    for params in (prm, prm_dev):
+        o_re = torch.full((B * K * L * M,), float("nan"), dtype=torch.float32, device=dev)
+        o_im = torch.full_like(o_re, float("nan"))
+        ctx.downconvert_and_correlate(desc, params, B, K, case["shifts"], case["fs"], o_re, o_im)
+        torch.cuda.synchronize()
+        outs.append((o_re.cpu().numpy(), o_im.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    got = (outs[0][0] + 1j * outs[0][1]).reshape(B, K, L, M)
+    check_close(got, oracle_result(case), what=str(cfg))
+
+
 @pytest.mark.parametrize("N", [1, 3, 255, 256, 1021, 1025, 4099])
 def test_ragged_lengths_and_scalar_path(gat, N):
     """N not a multiple of the vector width / workgroup chunk, on both the 16-byte-vector kernel
