@@ -148,7 +148,11 @@ GAT_API int32_t gat_sample_shifts(int32_t num_taps, double sampling_freq_hz, dou
  * several workgroups).  Outputs are OVERWRITTEN (the reference's `+=` into stale buffers,
  * src/algorithms.jl:207, is not reproduced).  params: [num_channels x num_blocks], channel
  * fastest.  out_re/out_im: dev float [M x L x K x B].  The replica / carrier / downconverted
- * scratch arguments of the reference call do not exist: nothing is materialised. */
+ * scratch arguments of the reference call do not exist: nothing is materialised.
+ * params_host is validated (GAT_ERR_RANGE / GAT_ERR_ARG instead of NaN results) and consumed before the call returns: up
+ * to 4 records (num_blocks * num_channels <= 4: the single-block call of a receiver loop, the reference's kernel_algorithm
+ * with scalar arguments) travel inside the kernel arguments -- no upload in front of the launch --, more are copied to a
+ * context-owned device buffer on the context's stream. */
 GAT_API int32_t gat_downconvert_and_correlate(gat_ctx *ctx, const gat_signal_desc *signal,
                                               const gat_channel_params *params_host,
                                               int32_t num_blocks, int32_t num_channels,

@@ -15,7 +15,7 @@ cpu={(r["GNSS"],r["num_samples"],r["num_ants"],r["num_correlators"]):r["Minimum"
 nat={}
 for line in open("gpurun_out/r03s/sweep_gpu_native.txt"):
     if line.startswith("#") or "|" not in line: continue
-    head, host, dev, graph, rest = line.split("|")
+    head, host, dev, graph, rest = line.split("|")[:5]
     n, m, l = (int(x) for x in head.split())
     nat[("GPSL1", n, m, l)] = (float(host.split("/")[0]), float(dev.split("/")[0]), float(rest.split()[0]))
 print("# one 1 ms block per call, minimum over repeated calls (BenchmarkTools 'Minimum', paper/paper.tex:150); CPU: %s, one thread" % c[0]["CPU_model"])
