@@ -633,14 +633,15 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
                 rep[0] = v;
                 if (TWO && gr > 0) rep1[0] = v;
             }
-            // one batch of four walked entries j0 .. j0 + 3 (stored at w[0], w[RPC], ...)
-            auto batch = [&](auto partial_c, int j0) {
+            // one batch of NB walked entries j0 .. j0 + NB - 1 (stored at w[0], w[RPC], ...)
+            auto batch = [&](auto partial_c, auto nb_c, int j0) {
                 constexpr bool PARTIAL = decltype(partial_c)::value;
+                constexpr int NB = decltype(nb_c)::value;
                 float *const w = rep + j0 * RPC;
-                unsigned id[4];
+                unsigned id[NB];
                 bool amb = w_exact;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < NB; ++u) {
                     const unsigned f2 = frac + w_rate_lo;
                     idx += w_rate_hi + (f2 < frac ? 1u : 0u); // carry of the fraction = one more chip
                     frac = f2;
@@ -651,15 +652,15 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
                 }
                 if (__builtin_expect(amb, 0)) { // some entry of the batch is not proven (or nothing is): evaluate exactly
 #pragma unroll 1
-                    for (int u = 0; u < 4; ++u) id[u] = (unsigned)chip_index(ratio, tau, x0 + RPC * (j0 + u), Lc, inv_lc);
+                    for (int u = 0; u < NB; ++u) id[u] = (unsigned)chip_index(ratio, tau, x0 + RPC * (j0 + u), Lc, inv_lc);
                 }
-                // all four table reads first: the table is int8 (a character type may alias anything), so a read written
-                // after a replica store would have to wait for it -- four serial LDS round trips per batch
-                int8_t t[4];
+                // all table reads first: the table is int8 (a character type may alias anything), so a read written
+                // after a replica store would have to wait for it -- one serial LDS round trip per entry
+                int8_t t[NB];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) t[u] = tab[id[u]];
+                for (int u = 0; u < NB; ++u) t[u] = tab[id[u]];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < NB; ++u)
                     if (!PARTIAL || j0 + u < run) { // wave-uniform bound
                         const float v = (float)t[u];
                         w[u * RPC] = v;
@@ -667,8 +668,10 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
                     }
             };
             int j0 = 1;
-            for (; j0 + 4 <= run; j0 += 4) batch(std::false_type{}, j0);
-            if (j0 < run) batch(std::true_type{}, j0);
+            // (eight entries per LDS round trip, NB = 8, measured: configs[2] 1.186 -> 1.195 ms, the rest unchanged --
+            // profiles/r03/r03x_ab_fill_batch8_not_kept.txt)
+            for (; j0 + 4 <= run; j0 += 4) batch(std::false_type{}, std::integral_constant<int, 4>{}, j0);
+            if (j0 < run) batch(std::true_type{}, std::integral_constant<int, 4>{}, j0);
         };
         auto fill_segment = [&](int c0, int seg_cnt) {
 #if defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 4)
@@ -734,6 +737,11 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
 #pragma unroll
                         for (int h = 0; h < NH; ++h) {
                             float pr[SB], pi[SB], chip[SB][L];
+                            // the chips' LDS reads go out first: left alone the scheduler issues them behind the first
+                            // antenna's wipe-off (and its wait for the samples), right in front of their first use
+                            // (configs[2] 1.178 -> 1.169 ms, the other shapes unchanged: profiles/r03/r03x_ab_chips_first.txt)
+                            get_chips_sub(chip, rel + h * SB, s_rep);
+                            __builtin_amdgcn_sched_barrier(0);
                             pr[0] = run_r;
                             pi[0] = run_i;
 #pragma unroll
@@ -745,7 +753,6 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
                                 run_r = __builtin_fmaf(pr[SB - 1], wr_k[0], -(pi[SB - 1] * wi_k[0]));
                                 run_i = __builtin_fmaf(pr[SB - 1], wi_k[0], pi[SB - 1] * wr_k[0]);
                             }
-                            get_chips_sub(chip, rel + h * SB, s_rep);
 #pragma unroll
                             for (int m = 0; m < MT; ++m) {
                                 accumulate_sub(acc[0][m], raw[DI][g][m], h * SB, pr, pi, chip);
