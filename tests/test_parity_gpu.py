@@ -149,7 +149,14 @@ def test_host_parameter_calls(gat, cfg):
         outs.append((o_re.cpu().numpy(), o_im.cpu().numpy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     got = (outs[0][0] + 1j * outs[0][1]).reshape(B, K, L, M)
-    check_close(got, oracle_result(case), what=str(cfg))
+    ref = oracle_result(case)
+    check_close(got, ref, what=str(cfg))
+    # the same host records through the atomic second stage (memsets + launch; summation order is not fixed: tolerance only)
+    o_re = torch.full((B * K * L * M,), float("nan"), dtype=torch.float32, device=dev)
+    o_im = torch.full_like(o_re, float("nan"))
+    ctx.downconvert_and_correlate(desc, prm, B, K, case["shifts"], case["fs"], o_re, o_im, flags=gat.GAT_FLAG_ATOMIC)
+    torch.cuda.synchronize()
+    check_close((o_re.cpu().numpy() + 1j * o_im.cpu().numpy()).reshape(B, K, L, M), ref, what=f"atomic {cfg}")
 
 
 @pytest.mark.parametrize("N", [1, 3, 255, 256, 1021, 1025, 4099])
