@@ -11,6 +11,7 @@ import platform
 import time
 
 import numpy as np
+import torch
 
 from . import _lib
 from .algorithms import ALGODICT, ALGODICTINV, MEMDICT, REDDICT, KernelAlgorithm, algorithm_flags
@@ -63,7 +64,9 @@ def _run_kernel_benchmark(gnss, num_samples: int, num_ants: int, num_correlators
     """``_run_kernel_benchmark(gnss, ::Val{true}, ...)`` (src/benchmarks.jl:83-174): build the
     inputs exactly as the reference does, then time sync-inclusive calls (BenchmarkTools'
     ``@benchmark CUDA.@sync ...``: one evaluation per sample, time budget or sample cap)."""
-    ctx = get_context(device)
+    # a library-owned stream: the call + wait the harness times then ends on the completion flag in pinned host memory
+    # instead of hipStreamSynchronize (what a Julia / C host on GAT_OWN_STREAM sees; ~6 us of a 20 us call)
+    ctx = get_context(device, own_stream=True)
     system = gnss(use_gpu=True)
     code_frequency = get_code_frequency(system)
     start_code_phase, carrier_phase, carrier_frequency, prn = 0.0, 0.0, 1500.0, 1
@@ -74,6 +77,7 @@ def _run_kernel_benchmark(gnss, num_samples: int, num_ants: int, num_correlators
     op = StreamCorrelator(system, num_samples, num_ants, 1, 1, shifts, fs, flags=algorithm_flags(algorithm), ctx=ctx)
     op.set_params(make_params(prn - 1, code_frequency, carrier_frequency, start_code_phase, carrier_phase, shape=(1, 1)))
     desc = op.describe(signal.re, signal.im)
+    torch.cuda.synchronize()  # inputs and parameters were produced on PyTorch's stream; ctx runs on its own
     for _ in range(3):  # warm-up (BenchmarkTools tunes/warms before sampling)
         op.launch(desc)
     ctx.sync()

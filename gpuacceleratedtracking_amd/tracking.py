@@ -220,6 +220,8 @@ class StreamCorrelator:
 
     def result(self) -> np.ndarray:
         """complex64 [B, K, L, M] on the host (synchronises)."""
+        if getattr(self.ctx, "own_stream", False):
+            self.ctx.sync()  # the copies below are ordered with PyTorch's stream only
         return (self.out_re.cpu().numpy() + 1j * self.out_im.cpu().numpy()).astype(np.complex64)
 
 
