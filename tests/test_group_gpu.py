@@ -200,3 +200,48 @@ def test_sync_after_flagged_launch_sees_results_and_later_work_falls_back(gat):
     for p in bufs.values():
         lib.gat_free(h, p)
     assert lib.gat_destroy(h) == 0
+
+
+@pytest.mark.parametrize("N,M", [(2500, 4), (65536, 4), (20000, 1)])
+def test_completion_flag_results_are_out_when_the_flag_is(gat, N, M):
+    """The completion flag must not reach the host before the results are in memory.  The copies in the test above are
+    stream-ordered behind the kernel and would pass either way; here the outputs are read by PyTorch's stream, which is NOT
+    ordered with the context's own stream -- the read is correct only if gat_sync returned after the results were written
+    back.  The carrier phase changes from call to call (a rotation of every accumulator), so a stale or half-written result
+    shows as the previous call's rotation; one-workgroup launches (N = 2500: no arrival counter), a split block with the
+    second stage carrying the flag (N = 65536), and host-parameter records inside the kernel arguments."""
+    import torch
+    from gpuacceleratedtracking_amd import _lib
+    from gpuacceleratedtracking_amd.context import Context
+    g = gat
+    ctx = Context(0, "own")
+    dev = ctx.device
+    system = g.GPSL1(use_gpu=True)
+    ctx.set_codes(system.codes)
+    fs, L = N / 1e-3, 3
+    sig = g.gen_signal(system, 1, 1500.0, N, num_ants=g.NumAnts(M))[0]
+    re, im = sig.re.reshape(M, N).contiguous(), sig.im.reshape(M, N).contiguous()
+    desc = _lib.SignalDesc(re.data_ptr(), im.data_ptr(), g.GAT_LAYOUT_PLANAR, M, N, N, N, 0)
+    o_re = torch.zeros(L * M, dtype=torch.float32, device=dev)
+    o_im = torch.zeros_like(o_re)
+    shifts = [-1, 0, 1]
+    torch.cuda.synchronize()
+
+    def call(phase):
+        prm = g.make_params(np.zeros((1, 1), dtype=np.int32), 1.023e6, 1500.0, 0.0, phase)
+        ctx.downconvert_and_correlate(desc, prm, 1, 1, shifts, fs, o_re, o_im)
+        ctx.sync()  # completion flag
+        return (o_re.cpu().numpy() + 1j * o_im.cpu().numpy()).copy()  # PyTorch's stream: not ordered with ctx's
+
+    base = call(0.0)
+    assert abs(base.reshape(L, M)[1, 0] - N) < 1e-3 * N
+    assert ctx.last_launch_info()["finalize_launched"] == (0 if N == 2500 else 1)
+    bad = 0
+    for i in range(1, 1500):
+        phase = (i * 0.0371) % 1.0
+        got = call(phase)
+        want = base * np.exp(-2j * np.pi * phase)
+        if not np.allclose(got, want, rtol=0, atol=2e-4 * N):
+            bad += 1
+    assert bad == 0, f"{bad} of 1499 calls returned before their results were visible"
+    ctx.close()
