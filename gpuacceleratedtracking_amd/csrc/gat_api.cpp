@@ -61,6 +61,7 @@ struct gat_ctx {
     unsigned long long *dbg_ptr = nullptr; // diagnostic builds only
     int max_ant_tile = kMaxAntTile; // env GAT_MAX_ANT_TILE (experiments)
     int max_aw = 4, max_kt = 4, max_bpw = 16; // env GAT_DC_AW / GAT_DC_KT / GAT_DC_BPW: caps of the vector kernel's geometry
+    int force_bpw = 0;                        // env GAT_DC_BPW_FORCE: blocks per workgroup whatever the planner's rule says (A/B runs)
     int wgs_per_cu = 0;                       // env GAT_DC_WGS_PER_CU: workgroups per CU the split planner aims for (0: by instance)
     int one_wave = 1;                         // env GAT_DC_ONE_WAVE=0: never use one-wave workgroups
     long long one_wave_min = -1;              // env GAT_DC_ONE_WAVE_MIN: fewest (block, channel, tile) groups for them (default 32 per CU)
@@ -468,6 +469,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         const long long by_fill = std::max<long long>(1, groups / (16ll * c->num_cus * (nw == 1 ? 4 : 1)));
         const long long by_len = std::max<long long>(1, (nw == 1 ? 64 : 16) / chunks);
         bpw = std::min<long long>(std::min(by_fill, by_len), c->max_bpw);
+        if (c->force_bpw > 0) bpw = std::min<long long>(c->force_bpw, B); // experiments: GAT_DC_BPW_FORCE
     }
     const long long BG = (B + bpw - 1) / bpw;
     const long long tiles = BG * AG * splits;
@@ -705,7 +707,7 @@ int32_t graph_replay_or_record(gat_ctx *c, MakeKey make_key, Enqueue enqueue)
 // the part of a graph key every recorded launch sequence shares: kernel-selection knobs and library-owned buffers
 void key_put_ctx(std::vector<unsigned char> &key, const gat_ctx *c)
 {
-    key_put(key, c->mc_mode); key_put(key, c->max_aw); key_put(key, c->max_kt); key_put(key, c->max_bpw);
+    key_put(key, c->mc_mode); key_put(key, c->max_aw); key_put(key, c->max_kt); key_put(key, c->max_bpw); key_put(key, c->force_bpw);
     key_put(key, c->wgs_per_cu); key_put(key, c->max_depth); key_put(key, c->one_wave);
     key_put(key, c->d_codes); key_put(key, c->d_code_bits); key_put(key, c->Lc); key_put(key, c->P);
     key_put(key, c->d_partial); key_put(key, c->partial_bytes);
@@ -757,6 +759,7 @@ GAT_API int32_t gat_create(int32_t device, void *hip_stream, gat_ctx **out_ctx)
     if (const char *e = std::getenv("GAT_DC_AW")) c->max_aw = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("GAT_DC_KT")) c->max_kt = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("GAT_DC_BPW")) c->max_bpw = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("GAT_DC_BPW_FORCE")) c->force_bpw = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("GAT_DC_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("GAT_DC_ONE_WAVE")) c->one_wave = std::atoi(e) != 0;
     if (const char *e = std::getenv("GAT_DC_ONE_WAVE_MIN")) c->one_wave_min = std::atoll(e);
