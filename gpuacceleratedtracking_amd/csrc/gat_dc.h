@@ -191,14 +191,11 @@ struct SampleIO {
 };
 
 
-// Completion flag (latency regime): the last workgroup of a launch to get here stores the call's sequence number into
-// pinned host memory, where gat_sync spins on it -- a kernel's end reaches the host ~5 us sooner that way than through
-// hipStreamSynchronize (scripts/sync_probe.hip: 7.0 vs 11.7 us for an empty kernel).  Called by every thread of every
-// workgroup that did work, after its result stores.
-// Kernel arguments live in host memory on this platform (the runtime's kernarg pool): a scalar load that misses the
-// scalar cache crosses PCIe (~1 us), and the compiler sinks each argument's load to its first use -- a kernel with 300
-// bytes of arguments then pays that round trip once per 64-byte line, one after the other (set-up, replica, steps, tail:
-// scripts/r03_latency_cuts.sh).  Touching every line at the kernel's first instruction overlaps them into one.
+// The compiler sinks every kernel-argument load to its first use, so a kernel with several hundred bytes of arguments
+// pays one scalar-cache miss per 64-byte line, one after the other, each a full trip to the runtime's argument buffer
+// (set-up, replica, steps, tail: in a single-block call these serial trips were a third of the kernel's time,
+// scripts/r03_latency_cuts.sh; HIP_FORCE_DEV_KERNARG=1 changes nothing).  Touching every line at the kernel's first
+// instruction overlaps them into one.
 template <int BYTES>
 __device__ __forceinline__ void kernarg_prefetch()
 {
@@ -210,6 +207,10 @@ __device__ __forceinline__ void kernarg_prefetch()
     asm volatile("" ::"s"(s));
 }
 
+// Completion flag (latency regime): the last workgroup of a launch to get here stores the call's sequence number into
+// pinned host memory, where gat_sync spins on it -- a kernel's end reaches the host ~5 us sooner that way than through
+// hipStreamSynchronize (scripts/sync_probe.hip: 7.0 vs 11.7 us for an empty kernel).  Called by every thread of every
+// workgroup that did work, after its result stores.
 __device__ __forceinline__ void completion_flag(unsigned *done_counter, unsigned *host_flag, unsigned seq, unsigned total_wgs)
 {
     if (!done_counter) return; // launch-uniform
@@ -875,7 +876,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
             const int ml = vi >> 1;
             const int m = (ag * AW + at) * MT + (ml % MT);
             // position of this tap in the caller's shift list (a select chain over scalar registers: indexed by a lane
-            // value the argument array would be read with a VECTOR load -- from host memory, uncached, ~2 us)
+            // value the argument array would be read with a VECTOR load -- through the vector memory path, a serial uncached trip at the very end of the kernel)
             int l = a.tap_index[0];
 #pragma unroll
             for (int q = 1; q < L; ++q) l = ml / MT == q ? a.tap_index[q] : l;
