@@ -4,7 +4,9 @@
 # binary.  It is the thin `ccall` shim a maintainer of the reference would add (INTEGRATION.md);
 # every entry point it binds is exercised through the same C ABI by the Python host layer, by
 # examples/gat_known_answer.c (the same call sequence as `downconvert_and_correlate!` below, in C) and
-# by the tests.  Keep it mechanical: one ccall per exported symbol, no logic of its own.
+# by the tests.  Keep it mechanical: one ccall per exported symbol, no logic of its own.  Since it cannot run, it is
+# linted instead: tests/test_julia_shim_lint.py parses every `ccall` below and checks symbol, argument count and
+# argument type classes against include/gat.h, the struct mirrors field by field, and that every export is bound.
 #
 # Usage inside the reference (src/GPUAcceleratedTracking.jl), no other edits:
 #     include("GATHip.jl"); using .GATHip
@@ -54,6 +56,50 @@ struct SignalDesc
     chan_stride::Int64
 end
 
+# struct gat_loop_config (80 bytes: 7 doubles, 5 int32, 4 bytes of tail padding)
+struct LoopConfig
+    block_seconds::Float64
+    pll_bandwidth_hz::Float64
+    dll_bandwidth_hz::Float64
+    code_freq_nominal_hz::Float64
+    carrier_center_hz::Float64
+    if_hz::Float64
+    early_late_spacing_chips::Float64
+    code_length::Int32
+    num_taps::Int32
+    early_index::Int32
+    prompt_index::Int32
+    late_index::Int32
+end
+
+# struct gat_loop_state (72 bytes), one per channel, device-resident
+struct LoopState
+    init_carrier_doppler_hz::Float64
+    carrier_doppler_hz::Float64
+    code_doppler_hz::Float64
+    pll_acc1::Float64
+    pll_acc2::Float64
+    dll_acc::Float64
+    last_pll_error_cycles::Float64
+    last_dll_error_chips::Float64
+    prompt_power::Float64
+end
+
+# struct gat_launch_info (44 bytes): geometry of the last correlate call
+struct LaunchInfo
+    workgroups::Int32
+    threads::Int32
+    splits::Int32
+    ant_tile::Int32
+    vec::Int32
+    lds_bytes::Int32
+    finalize_launched::Int32
+    matrix_core::Int32
+    channels_per_wg::Int32
+    blocks_per_wg::Int32
+    prefetch_depth::Int32
+end
+
 struct GatError <: Exception
     status::Int32
     msg::String
@@ -99,6 +145,70 @@ sync(ctx::Context) = check(ctx, ccall((:gat_sync, libgat), Int32, (Ptr{Cvoid},),
 set_matrix_core(ctx::Context, mode::Integer) =
     check(ctx, ccall((:gat_set_matrix_core, libgat), Int32, (Ptr{Cvoid}, Int32), ctx.handle, Int32(mode)))
 
+set_stream(ctx::Context, stream::Ptr{Cvoid}) =
+    check(ctx, ccall((:gat_set_stream, libgat), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), ctx.handle, stream))
+set_vector_tiling(ctx::Context, max_antenna_tiles::Integer, max_channels::Integer, max_blocks::Integer) =
+    check(ctx, ccall((:gat_set_vector_tiling, libgat), Int32, (Ptr{Cvoid}, Int32, Int32, Int32), ctx.handle,
+                     Int32(max_antenna_tiles), Int32(max_channels), Int32(max_blocks)))
+function last_launch_info(ctx::Context)
+    info = Ref(LaunchInfo(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
+    check(ctx, ccall((:gat_last_launch_info, libgat), Int32, (Ptr{Cvoid}, Ref{LaunchInfo}, Csize_t), ctx.handle, info,
+                     sizeof(LaunchInfo)))
+    info[]
+end
+
+# library build identity: "libgat <version> (gfx950) git:<sha> flags:<-D list | none>"
+version() = unsafe_string(ccall((:gat_version, libgat), Cstring, ()))
+
+# ---- what add_metadata! needs (src/benchmarks.jl:11-32: GPU_model = name(CUDA.CuDevice(0)), CUDA = CUDA.version()):
+#      (device name, HIP runtime version as "major.minor.patch", compute units)
+function device_info(ctx::Context)
+    name = Vector{UInt8}(undef, 256)
+    ver, cus = Ref{Int32}(0), Ref{Int32}(0)
+    check(ctx, ccall((:gat_device_info, libgat), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Csize_t, Ref{Int32}, Ref{Int32}),
+                     ctx.handle, name, length(name), ver, cus))
+    v = Int(ver[])                                   # HIP_VERSION = major * 10^7 + minor * 10^5 + patch
+    unsafe_string(pointer(name)), string(v ÷ 10_000_000, ".", (v ÷ 100_000) % 100, ".", v % 100_000), Int(cus[])
+end
+function device_info(device::Integer = 0)
+    ctx = Context(device, Ptr{Cvoid}(C_NULL))        # default stream: nothing is launched
+    info = device_info(ctx)
+    finalize(ctx)
+    info
+end
+
+# ---- get_correlator_sample_shifts(system, correlator, fs, preferred_code_shift) (src/benchmarks.jl:105-107) as the
+#      library computes it: s = max(1, round(spacing * fs / fc)), shifts[l] = (l - L ÷ 2) * s
+function sample_shifts(num_taps::Integer, sampling_frequency_hz::Float64, code_frequency_hz::Float64, spacing_chips::Float64 = 0.5)
+    shifts = Vector{Int32}(undef, num_taps)
+    rc = ccall((:gat_sample_shifts, libgat), Int32, (Int32, Float64, Float64, Float64, Ptr{Int32}),
+               Int32(num_taps), sampling_frequency_hz, code_frequency_hz, spacing_chips, shifts)
+    rc == GAT_OK || throw(GatError(rc, "gat_sample_shifts"))
+    shifts
+end
+
+# ---- the library's own PRN generators ("GPSL1" / "GPSL5"; IS-GPS-200 / -705) for hosts without GNSSSignals.jl:
+#      (codes Int8 [code_length x num_prns], code frequency in Hz)
+function gen_codes(system::AbstractString, num_prns::Integer)
+    lc, fc = Ref{Int32}(0), Ref{Float64}(0.0)
+    rc = ccall((:gat_gen_codes, libgat), Int32, (Cstring, Int32, Ptr{Int8}, Ref{Int32}, Ref{Float64}),
+               system, Int32(num_prns), Ptr{Int8}(C_NULL), lc, fc)               # size query
+    rc == GAT_OK || throw(GatError(rc, "gat_gen_codes"))
+    codes = Matrix{Int8}(undef, lc[], num_prns)
+    rc = ccall((:gat_gen_codes, libgat), Int32, (Cstring, Int32, Ptr{Int8}, Ref{Int32}, Ref{Float64}),
+               system, Int32(num_prns), codes, lc, fc)
+    rc == GAT_OK || throw(GatError(rc, "gat_gen_codes"))
+    codes, fc[]
+end
+
+# ---- hipEvent pair on the context's stream (CUDA.@elapsed of test/algorithms.jl:1242): device time of what is enqueued between
+timer_start(ctx::Context) = check(ctx, ccall((:gat_timer_start, libgat), Int32, (Ptr{Cvoid},), ctx.handle))
+function timer_stop(ctx::Context)                   # synchronises; milliseconds
+    ms = Ref{Cfloat}(0)
+    check(ctx, ccall((:gat_timer_stop, libgat), Int32, (Ptr{Cvoid}, Ref{Cfloat}), ctx.handle, ms))
+    Float64(ms[])
+end
+
 # ---- device memory (for hosts without AMDGPU.jl; with AMDGPU.jl pass ROCArray pointers instead)
 function dmalloc(ctx::Context, bytes::Integer)
     p = Ref{Ptr{Cvoid}}(C_NULL)
@@ -110,6 +220,9 @@ h2d(ctx::Context, dst, src::Array) = check(ctx, ccall((:gat_memcpy_h2d, libgat),
     (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), ctx.handle, dst, src, sizeof(src)))
 d2h(ctx::Context, dst::Array, src, bytes::Integer = sizeof(dst)) = check(ctx, ccall((:gat_memcpy_d2h, libgat), Int32,
     (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), ctx.handle, dst, src, bytes))
+
+dmemset(ctx::Context, dst, value::Integer, bytes::Integer) = check(ctx, ccall((:gat_memset, libgat), Int32,
+    (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Csize_t), ctx.handle, dst, Int32(value), bytes))
 
 # make room for `n` output floats per plane (device + host); a no-op once the buffers are large enough
 function reserve_outputs!(ctx::Context, n::Integer)
@@ -192,6 +305,42 @@ end
 function fetch_result!(ctx::Context, n::Integer)
     d2h(ctx, ctx.host_re, ctx.out_re, 4n); d2h(ctx, ctx.host_im, ctx.out_im, 4n)   # gat_memcpy_d2h synchronises
     view(ctx.host_re, 1:n), view(ctx.host_im, 1:n)
+end
+
+# ---- the same launch with the [K x B] parameter records already on the device (a tracking loop that produces them
+#      there; flags may carry GAT_FLAG_GRAPH: the call's launches replayed as one hipGraph when it repeats)
+function correlate_dev_async!(ctx::Context, desc::SignalDesc, params_dev::Ptr{Cvoid}, B::Integer, K::Integer,
+                              shifts::Vector{Int32}, sampling_frequency_hz::Float64, out_re::Ptr{Cfloat}, out_im::Ptr{Cfloat},
+                              flags::UInt32 = UInt32(0))
+    check(ctx, ccall((:gat_downconvert_and_correlate_dev, libgat), Int32,
+                     (Ptr{Cvoid}, Ref{SignalDesc}, Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Int32}, Float64,
+                      Ptr{Cfloat}, Ptr{Cfloat}, UInt32),
+                     ctx.handle, Ref(desc), params_dev, Int32(B), Int32(K), Int32(length(shifts)), shifts,
+                     sampling_frequency_hz, out_re, out_im, flags))
+end
+
+# ---- closed tracking loop around the correlator (what Tracking.track does around downconvert_and_correlate!; the
+#      reference only borrows TrackingState buffers, src/benchmarks.jl:54-61).  All arrays device-resident:
+#      acc [M x L x K] of one block, state LoopState[K], cur / next ChannelParams[K] (may alias)
+function tracking_update!(ctx::Context, acc_re::Ptr{Cfloat}, acc_im::Ptr{Cfloat}, K::Integer, M::Integer, cfg::LoopConfig,
+                          state_dev::Ptr{Cvoid}, cur_dev::Ptr{Cvoid}, next_dev::Ptr{Cvoid})
+    check(ctx, ccall((:gat_tracking_update, libgat), Int32,
+                     (Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Int32, Int32, Ref{LoopConfig}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                     ctx.handle, acc_re, acc_im, Int32(K), Int32(M), Ref(cfg), state_dev, cur_dev, next_dev))
+end
+# num_blocks x {correlate, update} enqueued from native code, parameters ping-ponging between params_a (current at
+# entry) and params_b; returns true when params_b holds the parameters of the block after the last one
+function tracking_run!(ctx::Context, desc::SignalDesc, num_blocks::Integer, K::Integer, shifts::Vector{Int32},
+                       sampling_frequency_hz::Float64, cfg::LoopConfig, state_dev::Ptr{Cvoid}, params_a_dev::Ptr{Cvoid},
+                       params_b_dev::Ptr{Cvoid}, acc_re::Ptr{Cfloat}, acc_im::Ptr{Cfloat}, acc_block_stride::Integer = 0,
+                       flags::UInt32 = UInt32(0))
+    cur_is_b = Ref{Int32}(0)
+    check(ctx, ccall((:gat_tracking_run, libgat), Int32,
+                     (Ptr{Cvoid}, Ref{SignalDesc}, Int32, Int32, Int32, Ptr{Int32}, Float64, Ref{LoopConfig}, Ptr{Cvoid}, Ptr{Cvoid},
+                      Ptr{Cvoid}, Ptr{Cfloat}, Ptr{Cfloat}, Int64, UInt32, Ref{Int32}),
+                     ctx.handle, Ref(desc), Int32(num_blocks), Int32(K), Int32(length(shifts)), shifts, sampling_frequency_hz,
+                     Ref(cfg), state_dev, params_a_dev, params_b_dev, acc_re, acc_im, Int64(acc_block_stride), flags, cur_is_b))
+    cur_is_b[] != 0
 end
 
 # ---- the operator: same argument list as Tracking.downconvert_and_correlate!
@@ -295,6 +444,16 @@ function gen_signal!(ctx::Context, signal::HipSignal, params_dev::Ptr{Cvoid}, K:
                      Float64(noise_sigma), UInt64(seed)))
 end
 
+# the reference's noise-free generator itself (src/gen_signal.jl:53-175), B blocks of K satellites summed
+function gen_signal_plain!(ctx::Context, signal::HipSignal, params_dev::Ptr{Cvoid}, B::Integer, K::Integer,
+                           sampling_frequency_hz::Float64, block_samples::Integer = signal.num_samples; amplitude = 1.0)
+    check(ctx, ccall((:gat_gen_signal, libgat), Int32,
+                     (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int64, Int32, Int64, Int64, Int32, Int32, Ptr{Cvoid}, Float64, Float64),
+                     ctx.handle, signal.re, signal.im, signal.layout, Int64(block_samples), Int32(signal.num_ants),
+                     Int64(signal.num_samples), Int64(block_samples), Int32(B), Int32(K), params_dev, sampling_frequency_hz,
+                     Float64(amplitude)))
+end
+
 # ---- several GPUs from one Julia task: one context per device, channels sharded contiguously, no collective
 #      (include/gat.h gat_group_*; the C form of this sequence is examples/gat_multi_gpu.c)
 mutable struct DeviceGroup
@@ -344,6 +503,23 @@ function gather(g::DeviceGroup, out_re::Vector{Ptr{Cfloat}}, out_im::Vector{Ptr{
     complex.(re, im)
 end
 sync(g::DeviceGroup) = gcheck(g, ccall((:gat_group_sync, libgat), Int32, (Ptr{Cvoid},), g.handle))
+function group_size(g::DeviceGroup)
+    n = Ref{Int32}(0)
+    gcheck(g, ccall((:gat_group_size, libgat), Int32, (Ptr{Cvoid}, Ref{Int32}), g.handle, n))
+    Int(n[])
+end
+# member `rank`'s context handle (borrowed: destroyed with the group) for the single-device entry points
+function member_handle(g::DeviceGroup, rank::Integer)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    gcheck(g, ccall((:gat_group_ctx, libgat), Int32, (Ptr{Cvoid}, Int32, Ref{Ptr{Cvoid}}), g.handle, Int32(rank), h))
+    h[]
+end
+# dst (on member dst_rank's device) <- src (on member src_rank's device), asynchronous on the destination's stream,
+# ordered behind the source's stream and ahead of the source's later work
+function memcpy_peer!(g::DeviceGroup, dst_rank::Integer, dst::Ptr{Cvoid}, src_rank::Integer, src::Ptr{Cvoid}, bytes::Integer)
+    gcheck(g, ccall((:gat_memcpy_peer, libgat), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
+                    member_handle(g, dst_rank), dst, member_handle(g, src_rank), src, bytes))
+end
 
 # ---- Tracking.gen_code_replica! (scripts/code_replica_experiment.jl:70)
 function gen_code_replica!(ctx::Context, code_replica_dev::Ptr{Cfloat}, code_frequency, sampling_frequency,
@@ -353,6 +529,18 @@ function gen_code_replica!(ctx::Context, code_replica_dev::Ptr{Cfloat}, code_fre
                      (Ptr{Cvoid}, Ptr{Cfloat}, Int64, Int32, Float64, Float64, Float64, Int64),
                      ctx.handle, code_replica_dev + (start_sample - 1) * sizeof(Cfloat), count, prn - 1,
                      ustrip(Hz, code_frequency), ustrip(Hz, sampling_frequency), Float64(start_code_phase), shifts[1]))
+end
+
+
+# ---- gen_code_replica_texture_mem_kernel! (src/algorithms.jl:121-140): the replica addressed through a Float32 normalised
+#      coordinate -- emulation for the code-phase-error study (scripts/code_replica_experiment.jl:81-82); study use only
+function gen_code_replica_f32coord!(ctx::Context, code_replica_dev::Ptr{Cfloat}, count::Integer, prn::Integer,
+                                    code_frequency_hz::Float64, sampling_frequency_hz::Float64, start_code_phase::Float64,
+                                    first_shift::Integer)
+    check(ctx, ccall((:gat_gen_code_replica_f32coord, libgat), Int32,
+                     (Ptr{Cvoid}, Ptr{Cfloat}, Int64, Int32, Float64, Float64, Float64, Int64),
+                     ctx.handle, code_replica_dev, Int64(count), Int32(prn - 1), code_frequency_hz, sampling_frequency_hz,
+                     start_code_phase, Int64(first_shift)))
 end
 
 end # module

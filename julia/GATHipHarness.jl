@@ -1,10 +1,12 @@
-# GATHipHarness.jl -- the two methods that plug libgat into the reference's own harness.
+# GATHipHarness.jl -- the three methods that plug libgat into the reference's own harness.
 #
 # `include` this file from src/GPUAcceleratedTracking.jl AFTER `include("GATHip.jl"); using .GATHip` (it is written
 # against the parent module's names: KernelAlgorithm, gen_signal, NumAnts, ..., exactly as src/benchmarks.jl and
 # src/algorithms.jl use them).  With the ALGODICT entry "hip_fused" => 9000, `run_kernel_benchmark(d)`
-# (src/benchmarks.jl:963-979) dispatches here unchanged, and scripts/run_benchmarks_gpsl1.jl needs no edit beyond
-# naming the algorithm.  NOT EXECUTED IN THIS PROJECT (no `julia` binary); the same sequence runs in C
+# (src/benchmarks.jl:963-979) dispatches here unchanged -- its three calls are `_run_kernel_benchmark` (method below),
+# `add_results!` (generic: works on any BenchmarkTools.Trial) and `add_metadata!` (method below: the reference's own
+# calls CUDA.version() and name(CUDA.CuDevice(0)), src/benchmarks.jl:20-24, which throw on a host without an NVIDIA
+# device) -- and scripts/run_benchmarks_gpsl1.jl needs no edit beyond naming the algorithm.  NOT EXECUTED IN THIS PROJECT (no `julia` binary); the same sequence runs in C
 # (examples/gat_known_answer.c) and in Python (gpuacceleratedtracking_amd/benchmarks.py::_run_kernel_benchmark).
 
 # _run_kernel_benchmark(gnss, ::Val{true}, num_samples, num_ants, num_correlators, ::KernelAlgorithm{N})
@@ -47,6 +49,24 @@ function _run_kernel_benchmark(
     end
     GATHip.free!(system.ctx, signal)
     return result
+end
+
+# add_metadata!(benchmark_results_w_params, processor, ::KernelAlgorithm{ALGN}) (src/benchmarks.jl:11-32) for id 9000:
+# more specific than the reference's `where ALGN` method, so `run_kernel_benchmark` (src/benchmarks.jl:977) lands here.
+# Same keys as the reference writes ("os", "CPU_model", "GPU_model", "CUDA", "algorithm" -- `collect_results` builds its
+# DataFrame columns from them) plus "HIP" (runtime version) and "libgat" (library version, git commit and build flags of
+# the kernels that were timed; the script's @tagsave adds the harness's own commit, scripts/run_benchmarks_gpsl1.jl:24-27).
+function add_metadata!(benchmark_results_w_params, processor, algorithm::KernelAlgorithm{9000})
+    os_name = @static Sys.iswindows() ? "windows" : (@static Sys.isapple() ? "macos" : @static Sys.islinux() ? "linux" : @static Sys.isunix() ? "generic_unix" : throw("Can't determine OS name"))
+    cpu_name = Sys.cpu_info()[1].model
+    gpu_name, hip_version, _ = GATHip.device_info(0)          # gat_device_info: "AMD Instinct MI355X (gfx950...)", "7.2.x"
+    benchmark_results_w_params["os"] = os_name
+    benchmark_results_w_params["CPU_model"] = cpu_name
+    benchmark_results_w_params["GPU_model"] = gpu_name
+    benchmark_results_w_params["CUDA"] = "n/a"                # column kept for collect_results / plot scripts
+    benchmark_results_w_params["HIP"] = hip_version
+    benchmark_results_w_params["libgat"] = GATHip.version()
+    processor == "GPU" ? benchmark_results_w_params["algorithm"] = ALGODICTINV[9000] : nothing
 end
 
 # kernel_algorithm(..., ::KernelAlgorithm{9000}) with the 26-argument form of the reference's single-launch
