@@ -80,6 +80,8 @@ def parse_args(argv=None):
                     help="CPU-baseline leg only (no GPU): time the oracle's FP32 4-pass port, 1 thread, on the reference's "
                          "single-block sweep grid (scripts/run_benchmarks_gpsl1.jl / _gpsl5.jl with processor = CPU) and "
                          "write the rows to OUT.json -- the CPU series scripts/plot_benchmarks.py draws beside the GPU's")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="launch-geometry option of the library (include/gat.h gat_set_option), repeatable; recorded in the line")
     ap.add_argument("--baseline-config", type=int, choices=[1, 2, 3, 4], default=None,
                     help="shape of BASELINE.json configs[i] (1 = the default headline workload; 2 = GPS L5, 4 ants, 12 PRNs, "
                          "5 taps @ 50 MHz; 3 = the per-GPU shard of 16 ants x 32 PRNs @ 50 MHz; 4 = 64 ants x 64 channels, "
@@ -315,6 +317,9 @@ def measure(args, g, torch, dist, world, rank, shape_kw, steps, warmup, settle, 
     op, desc, sig, prm = g.build_stream(shape_kw["gnss"], N, M, L, K, B, layout=layout, first_prn=plan.lo, flags=flags,
                                         block_seconds=shape_kw["block_ms"] * 1e-3, ant_pad=args.ant_pad)
     ctx = op.ctx
+    for opt in args.option:
+        name, _, val = opt.partition("=")
+        ctx.set_option(name.strip(), int(val))
     fs = N / (shape_kw["block_ms"] * 1e-3)
 
     def barrier():
@@ -473,6 +478,10 @@ def main():
             "roofline": roofline(m["shape"], m["launch_s"], info.get("matrix_core", 0), traffic),
             "parity_max_rel_err_vs_f64_oracle": err,
         }
+        from gpuacceleratedtracking_amd.benchmarks import provenance
+        out.update(provenance())  # "libgat": version + kernel-source commit + build flags, "git": repository commit
+        if args.option:
+            out["config"]["options"] = list(args.option)
         if world > 1:
             out["ranks"] = {"world_size": world, "backend": backend, "ms_per_step_by_rank": [round(x, 6) for x in m["per_rank_ms"]]}
         if world == 1 and not args.no_cpu_baseline:

@@ -31,7 +31,7 @@ EXPORTS = [
     "gat_gen_code_replica_f32coord",
     "gat_gen_signal", "gat_reduce_cplx_multi", "gat_tracking_update", "gat_malloc", "gat_free", "gat_memcpy_h2d",
     "gat_memcpy_d2h", "gat_memset", "gat_timer_start", "gat_timer_stop", "gat_last_launch_info", "gat_set_matrix_core", "gat_tracking_run", "gat_set_vector_tiling", "gat_gen_code_replica_multi",
-    "gat_downconvert_and_accumulate", "gat_gen_signal_noisy",
+    "gat_downconvert_and_accumulate", "gat_gen_signal_noisy", "gat_set_option",
     # several devices from one host thread (channel sharding, no collective)
     "gat_device_count", "gat_memcpy_peer", "gat_group_create", "gat_group_destroy", "gat_group_size", "gat_group_ctx",
     "gat_group_last_error", "gat_group_shard", "gat_group_set_codes", "gat_group_replicate", "gat_group_correlate",
@@ -148,6 +148,7 @@ def load(build_if_missing: bool = True):
         "gat_last_launch_info": (i32, [vp, C.POINTER(LaunchInfo), C.c_size_t]),
         "gat_set_matrix_core": (i32, [vp, i32]),
         "gat_set_vector_tiling": (i32, [vp, i32, i32, i32]),
+        "gat_set_option": (i32, [vp, C.c_char_p, i64]),
         "gat_gen_code_replica_multi": (i32, [vp, vp, i64, i64, i32, vp, dbl, i64]),
         "gat_downconvert_and_accumulate": (i32, [vp, sp, pp, i32, i32p, dbl, vp, vp, vp, vp, vp, vp]),
         "gat_gen_signal_noisy": (i32, [vp, vp, vp, i32, i64, i32, i64, i64, i32, i32, vp, dbl, dbl, vp, dbl, C.c_uint64]),

@@ -46,9 +46,13 @@ def _cpu_model() -> str:
 
 
 def add_metadata(results: dict, processor: str, algorithm: KernelAlgorithm | None, ctx=None) -> dict:
-    """``add_metadata!`` (src/benchmarks.jl:11-32); "CUDA" becomes the HIP runtime version."""
+    """``add_metadata!`` (src/benchmarks.jl:11-32); "CUDA" becomes the HIP runtime version.  Provenance as the
+    reference's ``@tagsave`` records it (scripts/run_benchmarks_gpsl1.jl:24-27): ``libgat`` = the library's version, the
+    commit of its kernel sources and its build flags (gat_version); ``git`` = the commit of the repository it was built in."""
     results["os"] = platform.system().lower()
     results["CPU_model"] = _cpu_model()
+    results["libgat"] = _lib.load().gat_version().decode()
+    results["git"] = provenance()["git"]
     if ctx is not None:
         info = ctx.device_info()
         results["GPU_model"] = info["name"]
@@ -56,6 +60,17 @@ def add_metadata(results: dict, processor: str, algorithm: KernelAlgorithm | Non
     if processor in ("GPU", "HIP") and algorithm is not None:
         results["algorithm"] = ALGODICTINV[algorithm.id]
     return results
+
+
+def provenance() -> dict:
+    """Which code produced a record: the library's own identity string and the repository commit (from .git when the
+    run has one, else the commit recorded when libgat.so was built -- the GPU box receives no .git)."""
+    from . import build as _build
+
+    info = _build.build_info()
+    head = _build.repo_head()
+    return {"libgat": _lib.load().gat_version().decode(), "git": head if head != "unknown" else info.get("repo_head_git", "unknown"),
+            "build": {k: info.get(k) for k in ("kernel_sources_git", "flags", "hipcc", "built_utc")}}
 
 
 def _run_kernel_benchmark(gnss, num_samples: int, num_ants: int, num_correlators: int,

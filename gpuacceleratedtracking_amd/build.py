@@ -15,6 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgat.so")
 SOURCES = ["gat_dc_f0.hip", "gat_dc_f1.hip", "gat_dc_f2.hip", "gat_dc_f3.hip", "gat_kernels.hip", "gat_mfma.hip",
            "gat_mfma_bf16.hip", "gat_api.cpp", "gat_codes.cpp"]
+# gat_version.cpp is not in SOURCES: it is compiled at every link with the build's identity (git commit, flags)
 HEADERS = [os.path.join(CSRC, "gat_internal.h"), os.path.join(CSRC, "gat_phase.h"), os.path.join(CSRC, "gat_dc.h"),
            os.path.join(ROOT, "include", "gat.h")]
 
@@ -33,17 +34,56 @@ def _flags(extra: tuple[str, ...] = ()) -> list[str]:
             "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *extra]
 
 
+def source_identity() -> str:
+    """Short commit of the last change to the kernel sources (csrc/, include/), '+dirty' when the working tree differs from
+    it there; 'unknown' outside a git checkout (the GPU box receives the built .so, not .git)."""
+    paths = ["gpuacceleratedtracking_amd/csrc", "include", "gpuacceleratedtracking_amd/build.py"]
+    try:
+        sha = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", *paths], capture_output=True, text=True,
+                             check=True).stdout.strip()
+        if not sha:
+            return "unknown"
+        dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", *paths], capture_output=True, text=True,
+                               check=True).stdout.strip()
+        return sha + ("+dirty" if dirty else "")
+    except Exception:
+        return "unknown"
+
+
+def repo_head() -> str:
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              check=True).stdout.strip() or "unknown"
+    except Exception:
+        return "unknown"
+
+
+BUILD_INFO = os.path.join(HERE, "_build_info.json")  # git-ignored, travels with the .so: what built it, from which commit
+
+
+def build_info() -> dict:
+    """The record build_libgat() left next to libgat.so (bench lines and benchmark records quote it)."""
+    import json
+
+    try:
+        with open(BUILD_INFO) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
 def command(out: str = LIB) -> list[str]:
     """The one-line recipe (what INTEGRATION.md quotes); build_libgat() runs the same flags per source
     so that an edit to one kernel file does not recompile the others."""
-    return [hipcc_path(), *_flags(), "-fno-slp-vectorize", "-shared", *[os.path.join(CSRC, s) for s in SOURCES], "-ldl", "-o", out]
+    return [hipcc_path(), *_flags(), "-fno-slp-vectorize", "-shared", *[os.path.join(CSRC, s) for s in SOURCES],
+            os.path.join(CSRC, "gat_version.cpp"), "-ldl", "-o", out]
 
 
 def is_stale(lib: str = LIB) -> bool:
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.join(CSRC, "gat_version.cpp")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -55,13 +95,16 @@ def build_libgat(force: bool = False, verbose: bool = False, extra_flags: tuple[
         return out
     from concurrent.futures import ThreadPoolExecutor
 
+    if extra_flags and "-DGAT_DEV" not in extra_flags:
+        extra_flags = ("-DGAT_DEV",) + tuple(extra_flags)  # every variant is a development build and says so (gat_version)
+
     tag = "obj" + ("_" + "_".join(f.lstrip("-").replace("=", "_") for f in extra_flags) if extra_flags else "")
     objdir = os.path.join(ROOT, "build", tag)
     os.makedirs(objdir, exist_ok=True)
     os.makedirs(os.path.dirname(out), exist_ok=True)
     hdr_t = max(os.path.getmtime(h) for h in HEADERS + [os.path.abspath(__file__)])
     jobs, objs = [], []
-    dc_only = bool(extra_flags) and all(f.startswith("-DGAT_DC_") for f in extra_flags)
+    dc_only = bool(extra_flags) and all(f.startswith("-DGAT_DC_") or f == "-DGAT_DEV" for f in extra_flags)
     base_objdir = os.path.join(ROOT, "build", "obj")
     os.makedirs(base_objdir, exist_ok=True)
     for src in SOURCES:
@@ -87,7 +130,23 @@ def build_libgat(force: bool = False, verbose: bool = False, extra_flags: tuple[
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
         list(ex.map(run, jobs))
-    run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", out])
+    # build identity (gat_version): compiled at every link
+    ident, flag_str = source_identity(), (" ".join(extra_flags) if extra_flags else "none")
+    vobj = os.path.join(objdir, "gat_version.o")
+    run(["g++", "-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DGAT_BUILD", "-I" + os.path.join(ROOT, "include"),
+         f'-DGAT_GIT_SHA="{ident}"', f'-DGAT_BUILD_FLAGS="{flag_str}"', "-c", os.path.join(CSRC, "gat_version.cpp"), "-o", vobj])
+    run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, vobj, "-ldl", "-o", out])
+    if out == LIB:
+        import json
+        import time
+
+        try:
+            hipcc_v = subprocess.run([hipcc_path(), "--version"], capture_output=True, text=True).stdout.splitlines()[0].strip()
+        except Exception:
+            hipcc_v = "unknown"
+        with open(BUILD_INFO, "w") as f:
+            json.dump({"kernel_sources_git": ident, "repo_head_git": repo_head(), "flags": flag_str, "hipcc": hipcc_v,
+                       "recipe": " ".join(_flags()[:-2]), "built_utc": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())}, f)
     return out
 
 

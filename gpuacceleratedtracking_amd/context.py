@@ -46,7 +46,6 @@ class Context:
             raise GatError(rc, "gat_create")
         self._codes_key = None
         self._codes_obj = None
-        self._codes_fp = None
 
     # -- plumbing -----------------------------------------------------------------------
     def check(self, rc: int, where: str):
@@ -90,6 +89,11 @@ class Context:
         self.check(self.lib.gat_set_vector_tiling(self._h, int(max_antenna_tiles), int(max_channels), int(max_blocks)),
                    "gat_set_vector_tiling")
 
+    def set_option(self, name: str, value: int):
+        """Launch-geometry option by name (include/gat.h gat_set_option): tests force a code path on a small case, A/B
+        runs compare geometries; never changes a result beyond summation order."""
+        self.check(self.lib.gat_set_option(self._h, name.encode(), int(value)), f"gat_set_option({name})")
+
     def timer_start(self):
         self.check(self.lib.gat_timer_start(self._h), "gat_timer_start")
 
@@ -105,10 +109,10 @@ class Context:
         The table is per-context state in libgat while the reference passes `system` with every call, and one context
         serves every operator on a (device, stream): each operator therefore re-binds its own table before every launch
         (a dual-frequency receiver alternates L1 and L5 on one context).  Cheap: the table bound last is remembered by
-        identity; only a different array object is hashed, and only different contents are uploaded."""
-        # identity + a fingerprint of the first chips of every row: a caller that patches a PRN row of system.codes in
-        # place is noticed (the full table is hashed only when the object or the fingerprint changed)
-        if codes is self._codes_obj and self._codes_fp == hash(np.asarray(codes)[:, :64].tobytes()):
+        IDENTITY -- a code table is immutable once it has been bound (as ``system.codes`` is in the reference: a constant of
+        the GNSS system); to change chips, bind a new array object.  Only a different object is hashed, and only
+        different contents are uploaded."""
+        if codes is self._codes_obj:
             return
         arr = np.ascontiguousarray(codes, dtype=np.int8)
         key = (arr.shape, hash(arr.tobytes()))
@@ -116,7 +120,6 @@ class Context:
             p, lc = arr.shape
             self.check(self.lib.gat_set_codes(self._h, arr.ctypes.data_as(C.POINTER(C.c_int8)), lc, p), "gat_set_codes")
             self._codes_key = key
-        self._codes_fp = hash(np.asarray(codes)[:, :64].tobytes())
         self._codes_obj = codes  # keeps the array alive, so the identity test above cannot be fooled by a recycled id
 
     # -- operators ----------------------------------------------------------------------

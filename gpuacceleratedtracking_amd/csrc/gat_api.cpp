@@ -11,6 +11,7 @@
 //              finalize launch sums the per-split partials in fixed order.
 //   matrix-core kernels where they measured faster (auto rule below).
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -52,22 +53,22 @@ struct gat_ctx {
     unsigned *d_done = nullptr;      // device: arrival counter of a launch's workgroups
     unsigned flag_seq = 0;           // last sequence number handed to a launch
     unsigned wait_seq = 0;           // != 0: the newest work on the stream is a flagged launch with this number
-    int flag_max_wgs = 1024;         // env GAT_SYNC_FLAG_WGS: largest launch that carries the flag (0: never)
+    int flag_max_wgs = 1024;         // option sync_flag_wgs: largest launch that carries the flag (0: never)
     gat_channel_params *d_params = nullptr;
     size_t params_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timer_running = false;
     int num_cus = 256;
     unsigned long long *dbg_ptr = nullptr; // diagnostic builds only
-    int max_ant_tile = kMaxAntTile; // env GAT_MAX_ANT_TILE (experiments)
-    int max_aw = 4, max_kt = 4, max_bpw = 16; // env GAT_DC_AW / GAT_DC_KT / GAT_DC_BPW: caps of the vector kernel's geometry
-    int force_bpw = 0;                        // env GAT_DC_BPW_FORCE: blocks per workgroup whatever the planner's rule says (A/B runs)
-    int wgs_per_cu = 0;                       // env GAT_DC_WGS_PER_CU: workgroups per CU the split planner aims for (0: by instance)
-    int one_wave = 1;                         // env GAT_DC_ONE_WAVE=0: never use one-wave workgroups
-    long long one_wave_min = -1;              // env GAT_DC_ONE_WAVE_MIN: fewest (block, channel, tile) groups for them (default 32 per CU)
-    int one_wave_seg = kOneWaveSegSteps;      // env GAT_DC_OW_SEG: steps per replica segment of a one-wave workgroup
-    int max_depth = 2;                        // env GAT_DC_DEPTH: cap of the sample prefetch depth (register sets per wave)
-    int mc_mode = 1; // GAT_MC_* kernel selection (gat_set_matrix_core); env GAT_NO_MFMA=1 starts at 0
+    int max_ant_tile = kMaxAntTile; // option max_ant_tile (gat_set_option)
+    int max_aw = 4, max_kt = 4, max_bpw = 16; // options dc_aw / dc_kt / dc_bpw (gat_set_vector_tiling): caps of the vector kernel's geometry
+    int force_bpw = 0;                        // option dc_bpw_force: blocks per workgroup whatever the planner's rule says (A/B runs)
+    int wgs_per_cu = 0;                       // option dc_wgs_per_cu: workgroups per CU the split planner aims for (0: by instance)
+    int one_wave = 1;                         // option dc_one_wave = 0: never use one-wave workgroups
+    long long one_wave_min = -1;              // option dc_one_wave_min: fewest (block, channel, tile) groups for them (default 32 per CU)
+    int one_wave_seg = kOneWaveSegSteps;      // option dc_ow_seg: steps per replica segment of a one-wave workgroup
+    int max_depth = 2;                        // option dc_depth: cap of the sample prefetch depth (register sets per wave)
+    int mc_mode = 1; // GAT_MC_* kernel selection (gat_set_matrix_core)
     std::string err;
     gat_launch_info last{};
 };
@@ -469,7 +470,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         const long long by_fill = std::max<long long>(1, groups / (16ll * c->num_cus * (nw == 1 ? 4 : 1)));
         const long long by_len = std::max<long long>(1, (nw == 1 ? 64 : 16) / chunks);
         bpw = std::min<long long>(std::min(by_fill, by_len), c->max_bpw);
-        if (c->force_bpw > 0) bpw = std::min<long long>(c->force_bpw, B); // experiments: GAT_DC_BPW_FORCE
+        if (c->force_bpw > 0) bpw = std::min<long long>(c->force_bpw, B); // A/B runs: option dc_bpw_force
     }
     const long long BG = (B + bpw - 1) / bpw;
     const long long tiles = BG * AG * splits;
@@ -715,9 +716,53 @@ void key_put_ctx(std::vector<unsigned char> &key, const gat_ctx *c)
 
 } // namespace
 
-extern "C" {
+namespace {
 
-GAT_API const char *gat_version(void) { return "libgat 0.1.0 (gfx950)"; }
+// gat_set_option: launch-geometry options (tests force a code path on a small case with them, A/B measurements compare
+// geometries).  None changes a result beyond summation order.
+struct OptionDesc {
+    const char *name;
+    long long lo, hi;
+};
+constexpr OptionDesc kOptions[] = {
+    {"sync_flag_wgs", 0, 1 << 20},   // largest launch (workgroups) that carries the completion flag; 0: never
+    {"max_ant_tile", 1, kMaxAntTile}, // antennas per wave
+    {"dc_aw", 1, 4},                 // antenna tiles (waves) per workgroup, cap
+    {"dc_kt", 1, 4},                 // channels per workgroup, cap
+    {"dc_bpw", 1, 1 << 20},          // consecutive blocks per workgroup, cap
+    {"dc_bpw_force", 0, 1 << 20},    // blocks per workgroup whatever the planner's rule says (0: planner)
+    {"dc_wgs_per_cu", 0, 1024},      // workgroups per CU the split planner aims for (0: by instance)
+    {"dc_one_wave", 0, 1},           // one-wave workgroups allowed
+    {"dc_one_wave_min", -1, 1ll << 40}, // fewest (block, channel, tile) groups for them (-1: 32 per CU)
+    {"dc_ow_seg", 1, 64},            // steps per replica segment of a one-wave workgroup
+    {"dc_depth", 1, 2},              // cap of the sample prefetch depth (register sets per wave)
+};
+
+int32_t set_option(gat_ctx *c, const char *name, long long v)
+{
+    const OptionDesc *o = nullptr;
+    for (const auto &d : kOptions)
+        if (std::strcmp(d.name, name) == 0) o = &d;
+    if (!o) return fail(c, GAT_ERR_ARG, "unknown option");
+    if (v < o->lo || v > o->hi) return fail(c, GAT_ERR_RANGE, "option value out of range");
+    const std::string n = name;
+    if (n == "sync_flag_wgs") c->flag_max_wgs = (int)v;
+    else if (n == "max_ant_tile") c->max_ant_tile = (int)v;
+    else if (n == "dc_aw") c->max_aw = (int)v;
+    else if (n == "dc_kt") c->max_kt = (int)v;
+    else if (n == "dc_bpw") c->max_bpw = (int)v;
+    else if (n == "dc_bpw_force") c->force_bpw = (int)v;
+    else if (n == "dc_wgs_per_cu") c->wgs_per_cu = (int)v;
+    else if (n == "dc_one_wave") c->one_wave = (int)v;
+    else if (n == "dc_one_wave_min") c->one_wave_min = v;
+    else if (n == "dc_ow_seg") c->one_wave_seg = (int)v;
+    else if (n == "dc_depth") c->max_depth = (int)v;
+    return GAT_OK;
+}
+
+} // namespace
+
+extern "C" {
 
 GAT_API int32_t gat_create(int32_t device, void *hip_stream, gat_ctx **out_ctx)
 {
@@ -753,19 +798,18 @@ GAT_API int32_t gat_create(int32_t device, void *hip_stream, gat_ctx **out_ctx)
         else c->d_flag = nullptr;
     }
     (void)hipGetLastError();
-    if (const char *e = std::getenv("GAT_SYNC_FLAG_WGS")) c->flag_max_wgs = std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("GAT_NO_MFMA")) c->mc_mode = e[0] == '1' ? 0 : 1;
-    if (const char *e = std::getenv("GAT_MAX_ANT_TILE")) c->max_ant_tile = std::min(kMaxAntTile, std::max(1, std::atoi(e)));
-    if (const char *e = std::getenv("GAT_DC_AW")) c->max_aw = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("GAT_DC_KT")) c->max_kt = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("GAT_DC_BPW")) c->max_bpw = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("GAT_DC_BPW_FORCE")) c->force_bpw = std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("GAT_DC_WGS_PER_CU")) c->wgs_per_cu = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("GAT_DC_ONE_WAVE")) c->one_wave = std::atoi(e) != 0;
-    if (const char *e = std::getenv("GAT_DC_ONE_WAVE_MIN")) c->one_wave_min = std::atoll(e);
-    if (const char *e = std::getenv("GAT_DC_OW_SEG")) c->one_wave_seg = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("GAT_DC_DEPTH")) c->max_depth = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("GAT_MC_MODE")) c->mc_mode = (e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;
+#ifdef GAT_DEV
+    // development builds only (-DGAT_DEV; gat_version() names the flag): the launch-geometry options of gat_set_option
+    // taken from the environment, so that scripts can A/B them without code changes.  The product library reads no
+    // environment variable that selects kernels or geometry.
+    for (const auto &o : kOptions) {
+        std::string env = "GAT_";
+        for (const char *p = o.name; *p; ++p) env += (char)std::toupper((unsigned char)*p);
+        if (const char *v = std::getenv(env.c_str())) (void)set_option(c, o.name, std::atoll(v));
+    }
+    if (const char *v = std::getenv("GAT_NO_MFMA")) c->mc_mode = v[0] == '1' ? 0 : 1;
+    if (const char *v = std::getenv("GAT_MC_MODE")) c->mc_mode = (v[0] >= '0' && v[0] <= '3') ? v[0] - '0' : 1;
+#endif
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
         delete c;
         return -(int32_t)e;
@@ -1279,6 +1323,14 @@ GAT_API int32_t gat_set_vector_tiling(gat_ctx *c, int32_t max_antenna_tiles, int
     return GAT_OK;
 }
 
+GAT_API int32_t gat_set_option(gat_ctx *c, const char *name, int64_t value)
+{
+    if (!c || !name) return fail(c, GAT_ERR_ARG, "null argument");
+    const int32_t rc = set_option(c, name, (long long)value);
+    if (rc == GAT_OK) drop_loop_graphs(c); // recorded launch sequences bake the geometry in
+    return rc;
+}
+
 GAT_API int32_t gat_last_launch_info(const gat_ctx *c, gat_launch_info *out, size_t struct_size)
 {
     if (!c || !out || struct_size == 0) return GAT_ERR_ARG;
@@ -1296,8 +1348,6 @@ GAT_API int32_t gat_last_launch_info(const gat_ctx *c, gat_launch_info *out, siz
 struct gat_group {
     std::vector<gat_ctx *> ctx;
     std::vector<gat_channel_params> staging; // host copy of one shard's parameters ([K_r x B]); reused per rank
-    hipEvent_t ready = nullptr;              // "source buffer is complete" marker of gat_group_replicate
-    int ready_device = -1;
     std::string err;
 };
 
@@ -1330,21 +1380,31 @@ GAT_API int32_t gat_memcpy_peer(gat_ctx *dst_ctx, void *dst_dev, gat_ctx *src_ct
     if (!dst_ctx || !src_ctx || !dst_dev || !src_dev) return fail(dst_ctx, GAT_ERR_ARG, "null argument");
     if (bytes == 0) return GAT_OK;
     dst_ctx->wait_seq = 0;
-    // order: everything enqueued so far on the SOURCE stream (the upload / generator that fills src) completes before
-    // the copy, which runs on the DESTINATION stream (its correlator launches follow in stream order)
-    hipEvent_t ev = nullptr;
+    src_ctx->wait_seq = 0;
+    // Order, both ways: everything enqueued so far on the SOURCE stream (the upload / generator that fills src) completes
+    // before the copy, which runs on the DESTINATION stream (its correlator launches follow in stream order); and whatever
+    // the source stream is given AFTER this call (the next block's ingest overwriting src) waits for the copy to have read
+    // it -- a streaming receiver refills its ingest buffer every millisecond without a group-wide sync in between.
+    hipEvent_t filled = nullptr, copied = nullptr;
     GAT_HIP(dst_ctx, hipSetDevice(src_ctx->device));
-    GAT_HIP(dst_ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    hipError_t e = hipEventRecord(ev, src_ctx->stream);
+    GAT_HIP(dst_ctx, hipEventCreateWithFlags(&filled, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(filled, src_ctx->stream);
     if (e == hipSuccess) e = hipSetDevice(dst_ctx->device);
-    if (e == hipSuccess) e = hipStreamWaitEvent(dst_ctx->stream, ev, 0);
+    if (e == hipSuccess) e = hipStreamWaitEvent(dst_ctx->stream, filled, 0);
     if (e == hipSuccess) {
         if (dst_ctx->device == src_ctx->device)
             e = hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, dst_ctx->stream);
         else
             e = hipMemcpyPeerAsync(dst_dev, dst_ctx->device, src_dev, src_ctx->device, bytes, dst_ctx->stream);
     }
-    (void)hipEventDestroy(ev); // released once the recorded work has completed
+    if (e == hipSuccess && dst_ctx->stream != src_ctx->stream) {
+        e = hipEventCreateWithFlags(&copied, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(copied, dst_ctx->stream);
+        if (e == hipSuccess) e = hipSetDevice(src_ctx->device);
+        if (e == hipSuccess) e = hipStreamWaitEvent(src_ctx->stream, copied, 0);
+    }
+    (void)hipEventDestroy(filled); // released once the recorded work has completed
+    if (copied) (void)hipEventDestroy(copied);
     if (e != hipSuccess) return hipfail(dst_ctx, e, "gat_memcpy_peer");
     return GAT_OK;
 }

@@ -222,8 +222,10 @@ __device__ __forceinline__ void completion_flag(unsigned *done_counter, unsigned
     if (threadIdx.x == 0) {
         // this XCD's L2 holds the workgroup's results: written back before it counts as arrived (the host may hand the
         // buffers to a copy engine or another stream as soon as it sees the flag)
+        // (acquire-release on the counter: the last arriver's system-scope store below is then ordered after EVERY
+        // workgroup's result stores, not only its own -- each arrival releases, the last one acquires them all)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const unsigned arrived = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned arrived = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (arrived == total_wgs - 1u) {
             __hip_atomic_store(done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

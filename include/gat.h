@@ -109,6 +109,10 @@ GAT_API int32_t gat_destroy(gat_ctx *ctx);
 GAT_API int32_t gat_set_stream(gat_ctx *ctx, void *hip_stream);
 GAT_API int32_t gat_sync(gat_ctx *ctx); /* CUDA.@sync equivalent: wait for the ctx stream  */
 GAT_API const char *gat_last_error(const gat_ctx *ctx);
+/* "libgat <version> (gfx950) git:<short commit of the kernel sources>[+dirty] flags:<-D flags beyond the product recipe | none>":
+ * which library a result came from (the reference tags saved results with its commit: @tagsave,
+ * scripts/run_benchmarks_gpsl1.jl:24-27).  A product build says "flags:none"; development builds (-DGAT_DEV: A/B knobs
+ * from the environment, diagnostic kernels) name theirs. */
 GAT_API const char *gat_version(void);
 
 /* Device properties used for metadata (add_metadata!, src/benchmarks.jl:11-32: GPU_model, CUDA
@@ -333,6 +337,14 @@ GAT_API int32_t gat_set_matrix_core(gat_ctx *ctx, int32_t enable);
 GAT_API int32_t gat_set_vector_tiling(gat_ctx *ctx, int32_t max_antenna_tiles, int32_t max_channels,
                                       int32_t max_blocks);
 
+/* Launch-geometry options by name, for tests (force a code path on a small case) and A/B measurements; none changes a
+ * result beyond summation order.  The library reads NO environment variable that selects kernels or geometry (development
+ * builds, -DGAT_DEV, map GAT_<NAME> onto these).  Names: "sync_flag_wgs" (largest launch in workgroups that carries the
+ * completion flag; 0: never), "max_ant_tile", "dc_aw", "dc_kt", "dc_bpw" (the caps of gat_set_vector_tiling),
+ * "dc_bpw_force", "dc_wgs_per_cu", "dc_one_wave", "dc_one_wave_min", "dc_ow_seg", "dc_depth".
+ * GAT_ERR_ARG: unknown name; GAT_ERR_RANGE: value outside the option's range. */
+GAT_API int32_t gat_set_option(gat_ctx *ctx, const char *name, int64_t value);
+
 /* Launch geometry chosen for the last correlate call (diagnostics / DESIGN.md tables). */
 typedef struct gat_launch_info {
     int32_t workgroups, threads, splits, ant_tile, vec, lds_bytes, finalize_launched;
@@ -368,7 +380,9 @@ GAT_API int32_t gat_group_shard(const gat_group *group, int32_t num_channels, in
 GAT_API int32_t gat_group_set_codes(gat_group *group, const int8_t *codes_host, int32_t code_length,
                                     int32_t num_prns);
 /* dst (on dst_ctx's device) <- src (on src_ctx's device), asynchronous: the copy runs on dst_ctx's stream after
- * everything enqueued so far on src_ctx's stream (hipMemcpyPeerAsync; a plain device copy when both are one device). */
+ * everything enqueued so far on src_ctx's stream (hipMemcpyPeerAsync; a plain device copy when both are one device),
+ * and work enqueued on src_ctx's stream AFTER this call waits for the copy: the source buffer may be refilled on its
+ * own stream right away (a receiver replicating every millisecond needs no group-wide sync between blocks). */
 GAT_API int32_t gat_memcpy_peer(gat_ctx *dst_ctx, void *dst_dev, gat_ctx *src_ctx, const void *src_dev, size_t bytes);
 /* bufs_dev[r] (r != src_rank) <- bufs_dev[src_rank], `bytes` each: the ingest device's signal to its peers */
 GAT_API int32_t gat_group_replicate(gat_group *group, int32_t src_rank, void *const *bufs_dev, size_t bytes);

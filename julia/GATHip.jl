@@ -150,6 +150,9 @@ set_stream(ctx::Context, stream::Ptr{Cvoid}) =
 set_vector_tiling(ctx::Context, max_antenna_tiles::Integer, max_channels::Integer, max_blocks::Integer) =
     check(ctx, ccall((:gat_set_vector_tiling, libgat), Int32, (Ptr{Cvoid}, Int32, Int32, Int32), ctx.handle,
                      Int32(max_antenna_tiles), Int32(max_channels), Int32(max_blocks)))
+# launch-geometry option by name ("dc_one_wave_min", "dc_depth", "sync_flag_wgs", ...: include/gat.h gat_set_option)
+set_option(ctx::Context, name::AbstractString, value::Integer) =
+    check(ctx, ccall((:gat_set_option, libgat), Int32, (Ptr{Cvoid}, Cstring, Int64), ctx.handle, name, Int64(value)))
 function last_launch_info(ctx::Context)
     info = Ref(LaunchInfo(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
     check(ctx, ccall((:gat_last_launch_info, libgat), Int32, (Ptr{Cvoid}, Ref{LaunchInfo}, Csize_t), ctx.handle, info,

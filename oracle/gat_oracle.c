@@ -230,7 +230,7 @@ GAT_ORACLE_API int gat_oracle_correlate_f64(const float *re, const float *im, in
  *           is redone with that expression: the replica is bit-identical to gen_code_replica above.
  *   pass 2: 64-bit carrier NCO (one cycle = 2^64), float32 polynomial sincos on the quadrant-
  *           reduced top 32 bits (|err| < 2e-7).
- * scratch must hold (N+nshift) + 2N + 2NM + 2Lc + 4*GAT_ORACLE_BATCH floats; N < 2^30.  This is the
+ * scratch must hold (N+nshift) + 2N + 2NM + 2Lc + GAT_ORACLE_BATCH floats (gat_oracle_dc_f32_scratch_floats); N < 2^30.  This is the
  * "port" timed by bench.py's cpu_baseline leg; it is itself checked against correlate_f64.
  * ---------------------------------------------------------------------------------------- */
 #define GAT_ORACLE_BATCH 1024
@@ -286,7 +286,11 @@ static void pass_carrier_replica(double f, double fs, double phi_cycles, int64_t
                                  float *restrict car_im, uint32_t *restrict ubuf /* [BATCH] */)
 {
     const double step = f / fs; /* cycles per sample */
-    const double sfrac = step - floor(step), pfrac = phi_cycles - floor(phi_cycles);
+    double sfrac = step - floor(step), pfrac = phi_cycles - floor(phi_cycles);
+    /* x - floor(x) rounds to exactly 1.0 for a tiny negative x (-1e-20): ldexp(1.0, 64) does not fit a uint64_t and
+     * the cast would be undefined -- the phase is then a whole cycle, i.e. 0 */
+    if (sfrac >= 1.0) sfrac = 0.0;
+    if (pfrac >= 1.0) pfrac = 0.0;
     const uint64_t step64 = (uint64_t)ldexp(sfrac, 64), phi64 = (uint64_t)ldexp(pfrac, 64);
     for (int64_t n0 = 0; n0 < N; n0 += GAT_ORACLE_BATCH) {
         const int len = (int)((N - n0) < GAT_ORACLE_BATCH ? (N - n0) : GAT_ORACLE_BATCH);

@@ -35,6 +35,28 @@ def test_library_exports_every_declared_symbol(g):
     assert lib.gat_version().startswith(b"libgat")
 
 
+def test_in_tree_library_is_a_product_build(g):
+    """gat_version() names the library's version, the commit of its kernel sources and every -D flag beyond the product
+    recipe: the in-tree libgat.so (what the GPU tests and bench.py load) is built without development flags -- no
+    environment knobs (-DGAT_DEV), no diagnostic kernels -- and reads no kernel-selecting environment variable."""
+    import re
+    import subprocess
+    from gpuacceleratedtracking_amd import _lib, build
+    v = g.load_library().gat_version().decode()
+    m = re.fullmatch(r"libgat (\d+\.\d+\.\d+) \(gfx950\) git:([0-9a-f]{7,12}(?:\+dirty)?|unknown) flags:(.+)", v)
+    assert m, v
+    assert m.group(3) == "none", f"in-tree libgat.so carries development flags: {v}"
+    assert tuple(int(x) for x in m.group(1).split(".")) >= (0, 2, 0)
+    # the only environment variable the product library looks at is the tracing toggle
+    strings = subprocess.run(["strings", "-a", _lib.library_path()], capture_output=True, text=True, check=True).stdout
+    envs = set(re.findall(r"\bGAT_[A-Z0-9_]{3,}\b", strings)) - {"GAT_ROCTX"}
+    assert not {e for e in envs if e.startswith(("GAT_DC_", "GAT_MC_MODE", "GAT_NO_MFMA", "GAT_MAX_ANT", "GAT_SYNC_FLAG"))}, envs
+    info = build.build_info()
+    assert info.get("flags") == "none" and info.get("kernel_sources_git") == m.group(2)
+    # development variants say what they are
+    assert "-DGAT_DEV" in open(build.__file__).read()
+
+
 def test_constants_match_header(g):
     """Every numeric #define of include/gat.h that the Python host layer mirrors has the same value there."""
     import re

@@ -110,6 +110,53 @@ def test_memcpy_peer_orders_after_the_source_stream(gat):
     grp.close()
 
 
+def test_source_may_be_refilled_right_after_replication(gat):
+    """A streaming receiver refills its ingest buffer for the next block as soon as gat_group_replicate has returned:
+    the refill (enqueued on the SOURCE member's stream) must wait for the asynchronous peer copies that still read the
+    buffer -- gat_memcpy_peer orders both ways.  Block i is generated with carrier frequency f_i, replicated, and the
+    buffer is overwritten at once (memset + the next block's generator); every replica must hold block i, not a torn mix."""
+    import ctypes as C
+
+    import torch
+    g = gat
+    lib = g.load_library()
+    grp = g.DeviceGroup([0, 0, 0])
+    sysobj = g.GPSL1(use_gpu=True)
+    grp.set_codes(sysobj.codes)
+    ctxs = []
+    for r in range(3):
+        h = C.c_void_p()
+        assert lib.gat_group_ctx(grp._h, r, C.byref(h)) == 0
+        ctxs.append(h)
+    N, M, rounds = 1 << 21, 4, 6  # 32 MB per plane: the copies take far longer than the calls that enqueue the refill
+    dev = torch.device("cuda", 0)
+    src = [torch.zeros((M, N), device=dev) for _ in range(2)]
+    keep = [[[torch.empty((M, N), device=dev) for _ in range(2)] for _ in range(rounds)] for _ in range(2)]  # [peer][round][plane]
+    prms = []
+    for i in range(rounds):
+        prm = g.make_params(np.zeros((1, 1), dtype=np.int32), 1.023e6, 1000.0 * (i + 1), 0.0, 0.0)
+        prms.append(torch.from_numpy(np.ascontiguousarray(prm).view(np.uint8).reshape(-1).copy()).to(dev))
+    fs = float(N / 1e-3)
+    torch.cuda.synchronize()
+    for i in range(rounds):
+        assert lib.gat_gen_signal(ctxs[0], src[0].data_ptr(), src[1].data_ptr(), 0, N, M, N, N, 1, 1, prms[i].data_ptr(), fs, 1.0) == 0
+        for peer in (1, 2):
+            for pl in range(2):
+                assert lib.gat_memcpy_peer(ctxs[peer], keep[peer - 1][i][pl].data_ptr(), ctxs[0], src[pl].data_ptr(), src[pl].numel() * 4) == 0
+        # no synchronisation: the source stream overwrites the buffer at once
+        assert lib.gat_memset(ctxs[0], src[0].data_ptr(), 0xFF, src[0].numel() * 4) == 0
+        assert lib.gat_memset(ctxs[0], src[1].data_ptr(), 0xFF, src[1].numel() * 4) == 0
+    grp.sync()
+    # what block i looked like: generate it again, undisturbed
+    for i in range(rounds):
+        assert lib.gat_gen_signal(ctxs[0], src[0].data_ptr(), src[1].data_ptr(), 0, N, M, N, N, 1, 1, prms[i].data_ptr(), fs, 1.0) == 0
+        grp.sync()
+        for peer in range(2):
+            for pl in range(2):
+                assert torch.equal(keep[peer][i][pl], src[pl]), f"round {i} peer {peer + 1} plane {pl}: torn replica"
+    grp.close()
+
+
 @pytest.mark.parametrize("args", [["1", "4", "4"], ["2", "4", "4"], ["3", "2", "2"]])
 def test_multi_gpu_c_example(gat, args):
     """examples/gat_multi_gpu.c from plain C: members over the visible devices (more members than devices wrap around),

@@ -177,13 +177,13 @@ ONE_WAVE_SHAPES = [
 
 @pytest.mark.parametrize("layout", [0, 1, 2, 3], ids=["planar", "interleaved", "i16", "i8"])
 @pytest.mark.parametrize("shape", ONE_WAVE_SHAPES, ids=[f"N{s[1]}-M{s[2]}-L{s[3]}-K{s[4]}-B{s[5]}" for s in ONE_WAVE_SHAPES])
-def test_one_wave_workgroups_match_the_oracle(gat, shape, layout, monkeypatch):
+def test_one_wave_workgroups_match_the_oracle(gat, shape, layout):
     """Short blocks in a long stream run one wave per block (gat_dc.h, NW = 1).  The planner takes that path from 32
-    groups per CU on; GAT_DC_ONE_WAVE_MIN=1 (read when a context is created) takes it for these small cases too."""
+    groups per CU on; the option dc_one_wave_min = 1 (gat_set_option) takes it for these small cases too."""
     import torch
-    monkeypatch.setenv("GAT_DC_ONE_WAVE_MIN", "1")
     ctx = gat.Context(torch.cuda.current_device())
     try:
+        ctx.set_option("dc_one_wave_min", 1)
         ctx.set_matrix_core(gat.GAT_MC_VECTOR)
         system, N, M, L, K, B = shape
         case = make_case(zlib.crc32(repr(shape).encode()), system=system, N=N, M=M, L=L, K=K, B=B)
@@ -248,10 +248,10 @@ DEEP_SHAPES = [
 
 @pytest.mark.parametrize("layout", [0, 1, 2, 3], ids=["planar", "interleaved", "i16", "i8"])
 @pytest.mark.parametrize("shape", DEEP_SHAPES, ids=[f"N{s[1]}-L{s[3]}-B{s[5]}" for s in DEEP_SHAPES])
-def test_two_sample_sets_match_the_oracle_and_one_set(gat, shape, layout, monkeypatch):
+def test_two_sample_sets_match_the_oracle_and_one_set(gat, shape, layout):
     """The streaming regime of the four-antenna tile keeps two steps of samples in flight (gat_dc.h, D = 2): against
-    the oracle (first and last blocks of long streams) and against the same launch with one set (GAT_DC_DEPTH=1, read
-    when a context is created): same chips, same order of summation -> bit-identical."""
+    the oracle (first and last blocks of long streams) and against the same launch with one set (option dc_depth = 1,
+    gat_set_option): same chips, same order of summation -> bit-identical."""
     import torch
     system, N, M, L, K, B = shape
     if layout == 3 and N % 8:
@@ -272,9 +272,9 @@ def test_two_sample_sets_match_the_oracle_and_one_set(gat, shape, layout, monkey
         case["B"] = B
     outs = []
     for depth in ("2", "1"):
-        monkeypatch.setenv("GAT_DC_DEPTH", depth)
         ctx = gat.Context(torch.cuda.current_device())
         try:
+            ctx.set_option("dc_depth", int(depth))
             ctx.set_matrix_core(gat.GAT_MC_VECTOR)
             got, info = run_case(gat, ctx, case, layout=layout)
             steps = -(-N // (2048 if layout == 3 else 1024))  # a block of one step has nothing to prefetch
