@@ -20,8 +20,12 @@ Prints ONE JSON line on rank 0:
                duration (HIP events on the launch stream); `bound` names the winning term
   cpu_baseline = the oracle's FP32 4-pass CPU restatement ("port") timed on this host on a bounded
                sample of the same stream (the reference's Julia CPU path cannot run here)
-  shard_config3 (N > 1 only) = the same measurement on BASELINE configs[3]'s per-GPU shard
-               (16 antennas, 4 of the 32 PRNs per GPU, 1 ms @ 50 MHz)
+  shard_config3 (N > 1 only) = the same measurement, same settle / warm-up / steps, on BASELINE configs[3]'s per-GPU
+               shard (16 antennas, 4 of the 32 PRNs per GPU, 1 ms @ 50 MHz)
+  group_check (N > 1 only) = build/gat_multi_gpu run in a FRESH process after the ranks have finished: every visible
+               device as one device group from one host thread -- peer replication of the signal (hipMemcpyPeerAsync
+               between distinct devices), sharded launch, gather; bit_identical vs shard-by-shard on device 0, peer_copy_GBps
+  ranks (N > 1 only) = per rank: ms per step, device name, PCI bus id; world size and backend
 Multi-GPU: satellite channels shard with no collective; every rank holds the full antenna signal
 and correlates its own PRNs ("weak" scaling: per-GPU work fixed).  RCCL carries only the timing
 barrier and the max-over-ranks reduction.
@@ -71,6 +75,8 @@ def parse_args(argv=None):
     ap.add_argument("--atomic", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shard-config3", action="store_true", help="N > 1: skip the configs[3] shard measurement")
+    ap.add_argument("--no-group-check", action="store_true",
+                    help="N > 1: skip the device-group self-check (build/gat_multi_gpu in a fresh process after the ranks are done)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
     ap.add_argument("--block-ms", type=float, default=1.0, help="duration of one integration block (fs = N / block)")
     ap.add_argument("--ant-pad", type=int, default=0,
@@ -105,9 +111,34 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def self_launch(n: int) -> int:
+def group_check(members: int | None = None, timeout: float = 300.0) -> dict:
+    """The device-group path of the C ABI over every visible device, in a FRESH child process (this process is never
+    replaced, and the child starts from a program that has not touched the GPU): examples/gat_multi_gpu.c -- ingest on
+    device 0, peer replication, sharded launch, gather, bit-comparison with shard-by-shard on device 0.  Its last output
+    line is the JSON object returned here.  ``members``: member count when it differs from the device count (the
+    one-GPU rehearsal puts two members on device 0).  GAT_BENCH_GROUP_CHECK_CMD replaces the command (tests without a GPU)."""
+    import shlex
+
+    cmd = os.environ.get("GAT_BENCH_GROUP_CHECK_CMD")
+    argv = shlex.split(cmd) if cmd else [os.path.join(ROOT, "build", "gat_multi_gpu")] + ([str(members)] if members else [])
+    try:
+        p = subprocess.run(argv, capture_output=True, text=True, timeout=timeout)
+    except (OSError, subprocess.TimeoutExpired) as exc:
+        return {"error": f"{type(exc).__name__}: {exc}", "cmd": " ".join(argv)}
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    try:
+        rec = json.loads(lines[-1])
+    except (IndexError, ValueError):
+        return {"error": "no JSON line", "rc": p.returncode, "stdout": p.stdout[-400:], "stderr": p.stderr[-400:]}
+    rec["rc"] = p.returncode
+    rec["cmd"] = " ".join(os.path.relpath(a, ROOT) if os.path.isabs(a) else a for a in argv)
+    return rec
+
+
+def self_launch(n: int, want_group_check: bool) -> int:
     """Start n ranks of this script as CHILD processes (no GPU call has happened in this process, and it
-    is never replaced by exec), forward rank 0's stdout, return the worst exit status."""
+    is never replaced by exec), take rank 0's line, add the device-group self-check (a further child process, run after
+    every rank has exited and released its device) and print the line; return the worst exit status."""
     port = _free_port()
     procs = []
     for r in range(n):
@@ -115,7 +146,13 @@ def self_launch(n: int) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GAT_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True if r == 0 else None))
+    # rank 0 prints one line at its very end: a reader thread keeps the pipe drained whatever else it writes
+    import threading
+
+    rank0_out: list[str] = []
+    reader = threading.Thread(target=lambda: rank0_out.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     # poll ALL children: the first one that fails takes the others down with it (they would otherwise sit in the
     # rendezvous / barrier until the deadline), and so does the deadline.  Only the exact children started above.
     rc = 0
@@ -144,6 +181,21 @@ def self_launch(n: int) -> int:
             live = []
         elif live:
             time.sleep(0.05)
+    reader.join(timeout=10.0)
+    text = rank0_out[0] if rank0_out else ""
+    for line in text.splitlines():
+        if rc == 0 and line.strip().startswith("{"):
+            try:
+                rec = json.loads(line)
+            except ValueError:
+                print(line, flush=True)
+                continue
+            if want_group_check and rec.get("n_gpus", 1) > 1:
+                share = os.environ.get("GAT_BENCH_SHARE_GPU") == "1"
+                rec["group_check"] = group_check(rec["n_gpus"] if share else None)
+            print(json.dumps(rec), flush=True)
+        else:
+            print(line, flush=True)
     return rc
 
 
@@ -344,6 +396,12 @@ def measure(args, g, torch, dist, world, rank, shape_kw, steps, warmup, settle, 
     barrier()
     elapsed = time.perf_counter() - t0
     per_rank = [elapsed * 1e3 / steps]
+    props = torch.cuda.get_device_properties(torch.cuda.current_device())
+    ident = {"rank": rank, "device": torch.cuda.current_device(), "name": props.name,
+             "pci_bus_id": "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
+                                                 getattr(props, "pci_device_id", 0)),
+             "uuid": str(getattr(props, "uuid", ""))}
+    idents = [ident]
     if dist is not None:
         dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
         t = torch.tensor([elapsed, kernel_ms_total], dtype=torch.float64, device=dev)
@@ -352,7 +410,9 @@ def measure(args, g, torch, dist, world, rank, shape_kw, steps, warmup, settle, 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms_total = float(t[0]), float(t[1])
         per_rank = [float(x[0]) * 1e3 / steps for x in gathered]
-    res = dict(op=op, desc=desc, sig=sig, prm=prm, ctx=ctx, fs=fs, layout=layout, shape=(B, N, M, L, K, layout),
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+    res = dict(devices=idents, op=op, desc=desc, sig=sig, prm=prm, ctx=ctx, fs=fs, layout=layout, shape=(B, N, M, L, K, layout),
                elapsed=elapsed, launch_s=kernel_ms_total * 1e-3 / steps, per_rank_ms=per_rank, steps=steps)
     return res
 
@@ -392,7 +452,7 @@ def main():
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
         # no external launcher: become the launcher.  Nothing above has touched the GPU (torch is not even imported).
-        sys.exit(self_launch(args.gpus))
+        sys.exit(self_launch(args.gpus, not args.no_group_check))
 
     import torch
 
@@ -413,10 +473,12 @@ def main():
         got = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(got, t)
         dist.barrier()
-        if rank == 0:
-            print(json.dumps({"dryrun": True, "n_gpus": world, "ranks_seen": [int(x[0]) for x in got],
-                              "local_rank": local_rank}), flush=True)
         dist.destroy_process_group()
+        if rank == 0:
+            rec = {"dryrun": True, "n_gpus": world, "ranks_seen": [int(x[0]) for x in got], "local_rank": local_rank}
+            if world > 1 and os.environ.get("GAT_BENCH_CHILD") != "1" and not args.no_group_check:
+                rec["group_check"] = group_check()  # external launcher: rank 0 runs it once the group is gone
+            print(json.dumps(rec), flush=True)
         return
     if not torch.cuda.is_available():
         print("bench.py: no HIP device", file=sys.stderr)
@@ -483,7 +545,8 @@ def main():
         if args.option:
             out["config"]["options"] = list(args.option)
         if world > 1:
-            out["ranks"] = {"world_size": world, "backend": backend, "ms_per_step_by_rank": [round(x, 6) for x in m["per_rank_ms"]]}
+            out["ranks"] = {"world_size": world, "backend": backend, "ms_per_step_by_rank": [round(x, 6) for x in m["per_rank_ms"]],
+                            "devices": m["devices"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, h_re, h_im, m["prm"], m["op"].shifts, fs, m["op"].system)
     del m
@@ -492,8 +555,11 @@ def main():
     if world > 1 and not args.no_shard_config3 and args.baseline_config is None:
         torch.cuda.empty_cache()
         kw3 = dict(PRESETS[3], layout="planar", block_ms=1.0)
-        steps3 = max(5, min(args.steps, 40))
-        m3 = measure(args, g, torch, dist, world, rank, kw3, steps3, min(args.warmup, 5), min(args.settle, 8), False)
+        # the same protocol as the headline: this shape reads 0.70 ms per launch in the first dozens of launches after an idle
+        # device and 0.58 ms in the steady state (profiles/r03/r03d_steady_state_by_warmup.txt) -- a shortened settle /
+        # warm-up would publish the cold number
+        steps3 = args.steps
+        m3 = measure(args, g, torch, dist, world, rank, kw3, steps3, args.warmup, args.settle, False)
         if rank == 0:
             B3, N3, M3, L3, K3, _ = m3["shape"]
             v3 = float(B3) * N3 * K3 * world * steps3 / m3["elapsed"] / 1e6
@@ -502,8 +568,8 @@ def main():
             out["shard_config3"] = {
                 "workload": f"GPSL1, {M3} ants, {K3 * world} PRNs sharded {K3}/GPU over {world} GPUs, {L3} correlators, 1 ms @ "
                             f"{m3['fs'] / 1e6:g} MHz, {B3} blocks/launch (BASELINE configs[3]: 32 PRNs at 8 GPUs)",
-                "value": round(v3, 3), "unit": "Msamples/s", "n_gpus": world, "steps": steps3,
-                "ms_per_step": round(m3["elapsed"] * 1e3 / steps3, 6),
+                "value": round(v3, 3), "unit": "Msamples/s", "n_gpus": world, "steps": steps3, "warmup": args.warmup,
+                "settle": args.settle, "ms_per_step": round(m3["elapsed"] * 1e3 / steps3, 6),
                 "ms_per_step_by_rank": [round(x, 6) for x in m3["per_rank_ms"]],
                 "real_time_factor": round(v3 * 1e6 / m3["fs"] / (K3 * world), 3),
                 "rccl_world_size": world, "backend": backend, "launch": info3,
@@ -512,11 +578,17 @@ def main():
                 "parity_max_rel_err_vs_f64_oracle": err3,
             }
         del m3
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if world > 1 and os.environ.get("GAT_BENCH_CHILD") != "1" and not args.no_group_check:
+            # external launcher (the driver's torch.distributed.run form): the ranks are past their last barrier and
+            # this one holds no buffer any more; the check runs in a fresh child process over every visible device
+            # (under self-launch the parent, which never touched the GPU, does it after every rank has exited)
+            torch.cuda.empty_cache()
+            out["group_check"] = group_check(world if share else None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -10,6 +10,9 @@
  * device 0 alone from device 0's original signal (same launch geometry per shard -> same summation order), and agree
  * to 1e-6 with all channels in one single-device launch.
  *
+ * The last line of output is one JSON object (what bench.py's N > 1 line quotes as "group_check"): devices, members,
+ * bit_identical, peer_copy_GBps (the signal planes replicated from member 0 to every peer, all peers at once) ...
+ *
  *   build/gat_multi_gpu [members [channels_per_member [blocks]]]
  * members defaults to the device count; more members than devices wrap around (members = 2 on a one-GPU box puts two
  * contexts with their own streams on device 0 and exercises every code path, peer copy included).
@@ -21,6 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "gat.h"
 
@@ -108,6 +112,25 @@ int main(int argc, char **argv)
         gat_free(ctx[0], prm_dev);
         free(gp);
     }
+    /* the replication, timed: both planes to all G - 1 peers at once (hipMemcpyPeerAsync between distinct devices: xGMI
+     * links of the node, one per peer; members that share a device copy inside it) */
+    double peer_gbps = 0.0, peer_ms = 0.0;
+    int distinct = 0;
+    for (int r = 1; r < G; ++r) distinct += devices[r] != devices[0];
+    if (G > 1) {
+        const int reps = 5;
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (int rep = 0; rep < reps; ++rep) {
+            CHECKG(gat_group_replicate(grp, 0, sig[0], plane));
+            CHECKG(gat_group_replicate(grp, 0, sig[1], plane));
+            CHECKG(gat_group_sync(grp));
+        }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        const double dt = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        peer_ms = dt / reps * 1e3;
+        peer_gbps = 2.0 * (double)plane * (G - 1) * reps / dt / 1e9;
+    }
 
     /* the sharded call + gather */
     const size_t out_n = (size_t)B * K * L * M;
@@ -174,6 +197,12 @@ int main(int argc, char **argv)
            G, ndev, K, KPG, M, B, fs / 1e6, bit_exact ? "BIT-IDENTICAL" : "MISMATCH", max_rel, prompt_min, N, ms);
 
     const int ok = bit_exact && max_rel <= 1e-6 && prompt_min > 0.5 * N / K; /* every PRN found its signal on every antenna */
+    printf("{\"devices\": %d, \"members\": %d, \"peers_on_other_devices\": %d, \"bit_identical\": %s, "
+           "\"max_rel_diff_vs_one_launch\": %.3e, \"peer_copy_GBps\": %.2f, \"peer_copy_ms\": %.4f, "
+           "\"peer_copy_bytes_per_peer\": %zu, \"ms_per_sharded_call\": %.4f, \"channels\": %d, \"antennas\": %d, "
+           "\"blocks\": %d, \"ok\": %s, \"libgat\": \"%s\"}\n",
+           ndev, G, distinct, bit_exact ? "true" : "false", max_rel, peer_gbps, peer_ms, 2 * plane, ms, K, M, B,
+           ok ? "true" : "false", gat_version());
     for (int r = 0; r < G; ++r) {
         gat_free(ctx[r], sig[0][r]); gat_free(ctx[r], sig[1][r]); gat_free(ctx[r], o_re[r]); gat_free(ctx[r], o_im[r]);
     }

@@ -945,15 +945,6 @@ GAT_API int32_t gat_set_codes(gat_ctx *c, const int8_t *codes_host, int32_t code
     return GAT_OK;
 }
 
-GAT_API int32_t gat_sample_shifts(int32_t L, double fs, double fc, double spacing, int32_t *shifts)
-{
-    if (!shifts || L < 1 || !(fs > 0.0) || !(fc > 0.0)) return GAT_ERR_ARG;
-    long long s = (long long)std::nearbyint(spacing * fs / fc); // round-half-even like Julia round(Int, x)
-    if (s < 1) s = 1;
-    for (int l = 0; l < L; ++l) shifts[l] = (int32_t)((l - L / 2) * s);
-    return GAT_OK;
-}
-
 GAT_API int32_t gat_downconvert_and_correlate_dev(gat_ctx *c, const gat_signal_desc *sig,
                                                   const gat_channel_params *params_dev, int32_t B,
                                                   int32_t K, int32_t L, const int32_t *shifts, double fs,
@@ -1375,38 +1366,65 @@ GAT_API int32_t gat_device_count(int32_t *count)
     return GAT_OK;
 }
 
+namespace {
+// one peer copy on dst's stream behind `filled` (an event recorded on the source stream); *copied (optional) receives an
+// event recorded behind the copy on dst's stream
+hipError_t peer_copy_after(gat_ctx *dst, void *dst_dev, gat_ctx *src, const void *src_dev, size_t bytes, hipEvent_t filled,
+                           hipEvent_t *copied)
+{
+    hipError_t e = hipSetDevice(dst->device);
+    if (e == hipSuccess) e = hipStreamWaitEvent(dst->stream, filled, 0);
+    if (e == hipSuccess) {
+        if (dst->device == src->device)
+            e = hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, dst->stream);
+        else
+            e = hipMemcpyPeerAsync(dst_dev, dst->device, src_dev, src->device, bytes, dst->stream);
+    }
+    if (e == hipSuccess && copied && dst->stream != src->stream) {
+        e = hipEventCreateWithFlags(copied, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(*copied, dst->stream);
+    }
+    return e;
+}
+
+// dsts[i] <- src for every i, all copies in flight together: ONE "source is complete" event on the source stream, a
+// copy on every destination's stream behind it, then the source stream waits for all of them -- whatever it is given
+// next (the following block's ingest overwriting src) runs after the copies have read the buffer.  (Waiting per copy
+// would chain them: the second destination's "complete" event would sit behind the wait for the first copy.)
+int32_t peer_fanout(gat_ctx *err_ctx, gat_ctx *src, const void *src_dev, size_t n, gat_ctx *const *dsts, void *const *dst_devs,
+                    size_t bytes)
+{
+    hipEvent_t filled = nullptr;
+    std::vector<hipEvent_t> copied(n, nullptr);
+    GAT_HIP(err_ctx, hipSetDevice(src->device));
+    GAT_HIP(err_ctx, hipEventCreateWithFlags(&filled, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(filled, src->stream);
+    src->wait_seq = 0;
+    for (size_t i = 0; i < n && e == hipSuccess; ++i) {
+        dsts[i]->wait_seq = 0;
+        e = peer_copy_after(dsts[i], dst_devs[i], src, src_dev, bytes, filled, &copied[i]);
+    }
+    if (e == hipSuccess) e = hipSetDevice(src->device);
+    for (size_t i = 0; i < n; ++i) {
+        if (!copied[i]) continue;
+        if (e == hipSuccess) e = hipStreamWaitEvent(src->stream, copied[i], 0);
+        (void)hipEventDestroy(copied[i]); // released once the recorded work has completed
+    }
+    (void)hipEventDestroy(filled);
+    if (e != hipSuccess) return hipfail(err_ctx, e, "peer copy");
+    return GAT_OK;
+}
+} // namespace
+
 GAT_API int32_t gat_memcpy_peer(gat_ctx *dst_ctx, void *dst_dev, gat_ctx *src_ctx, const void *src_dev, size_t bytes)
 {
     if (!dst_ctx || !src_ctx || !dst_dev || !src_dev) return fail(dst_ctx, GAT_ERR_ARG, "null argument");
     if (bytes == 0) return GAT_OK;
-    dst_ctx->wait_seq = 0;
-    src_ctx->wait_seq = 0;
     // Order, both ways: everything enqueued so far on the SOURCE stream (the upload / generator that fills src) completes
     // before the copy, which runs on the DESTINATION stream (its correlator launches follow in stream order); and whatever
     // the source stream is given AFTER this call (the next block's ingest overwriting src) waits for the copy to have read
     // it -- a streaming receiver refills its ingest buffer every millisecond without a group-wide sync in between.
-    hipEvent_t filled = nullptr, copied = nullptr;
-    GAT_HIP(dst_ctx, hipSetDevice(src_ctx->device));
-    GAT_HIP(dst_ctx, hipEventCreateWithFlags(&filled, hipEventDisableTiming));
-    hipError_t e = hipEventRecord(filled, src_ctx->stream);
-    if (e == hipSuccess) e = hipSetDevice(dst_ctx->device);
-    if (e == hipSuccess) e = hipStreamWaitEvent(dst_ctx->stream, filled, 0);
-    if (e == hipSuccess) {
-        if (dst_ctx->device == src_ctx->device)
-            e = hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, dst_ctx->stream);
-        else
-            e = hipMemcpyPeerAsync(dst_dev, dst_ctx->device, src_dev, src_ctx->device, bytes, dst_ctx->stream);
-    }
-    if (e == hipSuccess && dst_ctx->stream != src_ctx->stream) {
-        e = hipEventCreateWithFlags(&copied, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventRecord(copied, dst_ctx->stream);
-        if (e == hipSuccess) e = hipSetDevice(src_ctx->device);
-        if (e == hipSuccess) e = hipStreamWaitEvent(src_ctx->stream, copied, 0);
-    }
-    (void)hipEventDestroy(filled); // released once the recorded work has completed
-    if (copied) (void)hipEventDestroy(copied);
-    if (e != hipSuccess) return hipfail(dst_ctx, e, "gat_memcpy_peer");
-    return GAT_OK;
+    return peer_fanout(dst_ctx, src_ctx, src_dev, 1, &dst_ctx, &dst_dev, bytes);
 }
 
 GAT_API int32_t gat_group_create(int32_t num_members, const int32_t *devices, gat_group **out)
@@ -1496,13 +1514,18 @@ GAT_API int32_t gat_group_set_codes(gat_group *g, const int8_t *codes_host, int3
 GAT_API int32_t gat_group_replicate(gat_group *g, int32_t src_rank, void *const *bufs_dev, size_t bytes)
 {
     if (!g || !bufs_dev || src_rank < 0 || src_rank >= (int32_t)g->ctx.size()) return gfail(g, GAT_ERR_ARG, "bad argument");
+    std::vector<gat_ctx *> dsts;
+    std::vector<void *> ptrs;
     for (size_t r = 0; r < g->ctx.size(); ++r) {
         if (!bufs_dev[r]) return gfail(g, GAT_ERR_ARG, "null buffer");
         if ((int32_t)r == src_rank || bufs_dev[r] == bufs_dev[src_rank]) continue;
-        const int32_t rc = gat_memcpy_peer(g->ctx[r], bufs_dev[r], g->ctx[(size_t)src_rank], bufs_dev[src_rank], bytes);
-        if (rc != GAT_OK) return rc;
+        dsts.push_back(g->ctx[r]);
+        ptrs.push_back(bufs_dev[r]);
     }
-    return GAT_OK;
+    if (dsts.empty() || bytes == 0) return GAT_OK;
+    gat_ctx *src = g->ctx[(size_t)src_rank];
+    // all peers at once (one link per peer on an xGMI node), the source stream ordered behind all of them
+    return peer_fanout(src, src, bufs_dev[src_rank], dsts.size(), dsts.data(), ptrs.data(), bytes);
 }
 
 GAT_API int32_t gat_group_correlate(gat_group *g, const gat_signal_desc *signals, const gat_channel_params *params_host,

@@ -9,6 +9,7 @@
 //                            short-cycled after 8190 chips, both restarted every 10230 chips.
 // Chip mapping logic 0 -> +1, logic 1 -> -1.  Output column-major [code_length x num_prns].
 #include <cstdint>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -90,5 +91,17 @@ extern "C" GAT_API int32_t gat_gen_codes(const char *system, int32_t num_prns, i
     if (!out) return GAT_OK;
     if (num_prns < 1 || num_prns > 37) return GAT_ERR_RANGE;
     for (int p = 1; p <= num_prns; ++p) gen(p, out + (size_t)(p - 1) * (size_t)lc);
+    return GAT_OK;
+}
+
+// get_correlator_sample_shifts(system, correlator, fs, spacing) (src/benchmarks.jl:105-107; the implementation lives in the
+// un-vendored Tracking.jl fork): s = max(1, round(spacing * fs / fc)), taps (l - L / 2) * s.  Host-only like the generators
+// above, so that this translation unit can be built and run under the CPU sanitizers (oracle/Makefile, target sanitize).
+extern "C" GAT_API int32_t gat_sample_shifts(int32_t L, double fs, double fc, double spacing, int32_t *shifts)
+{
+    if (!shifts || L < 1 || L > GAT_MAX_TAPS || !(fs > 0.0) || !(fc > 0.0) || !(spacing == spacing)) return GAT_ERR_ARG;
+    const double x = std::nearbyint(spacing * fs / fc); // round-half-even like Julia round(Int, x)
+    long long s = x >= 1.0 ? (x < 1.0e9 ? (long long)x : 1000000000ll) : 1;
+    for (int l = 0; l < L; ++l) shifts[l] = (int32_t)((l - L / 2) * s);
     return GAT_OK;
 }

@@ -19,6 +19,10 @@ def _env():
     return env
 
 
+FAKE_CHECK = (f"{sys.executable} -c \"print('members 2 ...'); "
+              "print('{\\\"devices\\\": 2, \\\"members\\\": 2, \\\"bit_identical\\\": true, \\\"peer_copy_GBps\\\": 48.5}')\"")
+
+
 def _one_line(stdout: str) -> dict:
     lines = [ln for ln in stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, stdout
@@ -26,20 +30,47 @@ def _one_line(stdout: str) -> dict:
 
 
 def test_self_launch_two_ranks():
-    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"], env=_env(),
-                       capture_output=True, text=True, timeout=300)
+    """The parent (which never touches the GPU) takes rank 0's line, runs the device-group self-check in a further child
+    process AFTER every rank has exited, and prints ONE line carrying it."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=dict(_env(), GAT_BENCH_GROUP_CHECK_CMD=FAKE_CHECK), capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     rec = _one_line(p.stdout)
     assert rec["n_gpus"] == 2 and rec["ranks_seen"] == [0, 1]
+    gc = rec["group_check"]
+    assert gc["devices"] == 2 and gc["bit_identical"] is True and gc["peer_copy_GBps"] == 48.5 and gc["rc"] == 0
 
 
 def test_external_launcher_two_ranks():
+    """The driver's form: rank 0 runs the self-check itself (fresh child process) once the process group is gone."""
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29653", BENCH, "--gpus", "2", "--steps", "2",
-                        "--warmup", "1"], env=_env(), capture_output=True, text=True, timeout=300)
+                        "--warmup", "1"], env=dict(_env(), GAT_BENCH_GROUP_CHECK_CMD=FAKE_CHECK), capture_output=True, text=True,
+                       timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     rec = _one_line(p.stdout)
     assert rec["n_gpus"] == 2 and rec["ranks_seen"] == [0, 1]
+    assert rec["group_check"]["members"] == 2 and rec["group_check"]["bit_identical"] is True
+
+
+def test_group_check_failure_is_recorded_not_fatal():
+    """A self-check that cannot run (no binary, no JSON) leaves an error record in the line; the measurement stands."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=dict(_env(), GAT_BENCH_GROUP_CHECK_CMD="/nonexistent/gat_multi_gpu"), capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "error" in _one_line(p.stdout)["group_check"]
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-group-check"],
+                       env=dict(_env(), GAT_BENCH_GROUP_CHECK_CMD=FAKE_CHECK), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "group_check" not in _one_line(p.stdout)
+
+
+def test_shard_leg_runs_the_headline_protocol():
+    """N > 1: the configs[3] shard is measured with the same settle / warm-up / steps as the headline (a shortened
+    protocol reads the device while it leaves idle: 0.70 instead of 0.58 ms per launch)."""
+    src = open(BENCH).read()
+    assert "measure(args, g, torch, dist, world, rank, kw3, steps3, args.warmup, args.settle, False)" in src
+    assert "steps3 = args.steps" in src and "min(args.settle" not in src and "min(args.warmup" not in src
 
 
 def test_self_launch_ends_soon_when_one_rank_dies():
