@@ -96,7 +96,7 @@ extern "C" GAT_API int32_t gat_gen_codes(const char *system, int32_t num_prns, i
 
 // get_correlator_sample_shifts(system, correlator, fs, spacing) (src/benchmarks.jl:105-107; the implementation lives in the
 // un-vendored Tracking.jl fork): s = max(1, round(spacing * fs / fc)), taps (l - L / 2) * s.  Host-only like the generators
-// above, so that this translation unit can be built and run under the CPU sanitizers (oracle/Makefile, target sanitize).
+// above, so that this translation unit can be built and run under the CPU sanitizers (tests/test_host_sanitizers.py).
 extern "C" GAT_API int32_t gat_sample_shifts(int32_t L, double fs, double fc, double spacing, int32_t *shifts)
 {
     if (!shifts || L < 1 || L > GAT_MAX_TAPS || !(fs > 0.0) || !(fc > 0.0) || !(spacing == spacing)) return GAT_ERR_ARG;
