@@ -223,10 +223,12 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     const int spv = dc_group_samples(4, fmt);
     const long long plane_bytes = fmt == GAT_LAYOUT_PLANAR ? 4 : fmt == GAT_LAYOUT_INTERLEAVED ? 8 : fmt == GAT_LAYOUT_INTERLEAVED_I16 ? 4 : 2;
     int vec = 1;
-    // ... and whole groups only (the block's ragged end is then served by the buffer range check), in a block that a
-    // 32-bit descriptor length can describe
-    if (aligned16(sig->re) && (!planar || aligned16(sig->im)) && sig->ant_stride % spv == 0 &&
-        sig->block_stride % spv == 0 && sig->chan_stride % spv == 0 && sig->num_samples % spv == 0 &&
+    // ... in a block that a 32-bit descriptor length can describe.  The block LENGTH may be anything (the reference
+    // bounds each thread by num_samples, src/algorithms.jl:170): lanes beyond the last whole group read zeros through
+    // the buffer range check and the N % spv samples behind it are taken one per lane after the step loop.
+    // (a stride that is never applied -- one antenna, one block -- does not matter)
+    if (aligned16(sig->re) && (!planar || aligned16(sig->im)) && (sig->num_ants == 1 || sig->ant_stride % spv == 0) &&
+        (B == 1 || sig->block_stride % spv == 0) && sig->chan_stride % spv == 0 &&
         sig->num_samples * plane_bytes < (1ll << 31))
         vec = 4;
 
@@ -250,7 +252,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         std::stable_sort(order, order + L, [&](int x, int y) { return shifts[x] < shifts[y]; });
         const long long span = (long long)shifts[order[L - 1]] - shifts[order[0]];
         const int CT = L <= kMfmaMaxTaps ? 16 / L : 0;
-        const bool shape_any = c->mc_mode != 0 && vec == 4 && M % 16 == 0 && sig->chan_stride == 0 && CT >= 1 &&
+        const bool shape_any = c->mc_mode != 0 && vec == 4 && N % spv == 0 /* whole load groups */ && M % 16 == 0 && sig->chan_stride == 0 && CT >= 1 &&
                               span <= kMfmaMaxSpan && 2 * std::min(K, CT) * L >= 12 /* >= 3/8 of the columns */;
         const bool shape_ok = shape_any && planar; // the f32-MFMA kernel reads planar f32 only
         const int nct_total = shape_ok ? (K + CT - 1) / CT : 1;
@@ -528,6 +530,10 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     a.Ltot = L;
     a.flags = flags;
     a.keep_l2 = KG > 1 && sig->chan_stride == 0;
+    a.n_vec = (int)(vec == 4 ? N - N % spv : N);
+    // a block length that is no multiple of the load group: the N % spv samples behind the last whole group are added
+    // by dc_tail_kernel, one more (tiny) launch behind the vector kernel and its second stage
+    const bool tail = vec == 4 && N % spv != 0;
     a.max_abs_shift = (int)max_shift;
 
     DcLaunch cfg{};
@@ -590,8 +596,8 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             a.tap_off[l] = (d & 1) ? a.rep_copy_stride + d - 1 : d;
         }
         // completion flag: carried by the call's last launch -- the last tap group's kernel, or the second stage behind it
-        const bool fin_follows = !atomic && splits > 1;
-        if (flagged && !fin_follows && t1 >= L) {
+        const bool later_follows = (!atomic && splits > 1) || tail;
+        if (flagged && !later_follows && t1 >= L) {
             a.done_counter = c->d_done;
             a.host_flag = c->d_flag;
             a.flag_seq = next_seq();
@@ -601,8 +607,30 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     }
     const bool fin = !atomic && splits > 1;
     if (fin) {
+        const bool carry = flagged && !tail;
         GAT_HIP(c, launch_finalize(c->d_partial, out_re, out_im, (int)splits, L * M * 2, (long long)B * K, c->stream,
-                                   flagged ? c->d_done : nullptr, c->d_flag, flagged ? next_seq() : 0u));
+                                   carry ? c->d_done : nullptr, c->d_flag, carry ? next_seq() : 0u));
+    }
+    if (tail) {
+        DcTailArgs t{};
+        t.re = sig->re;
+        t.im = sig->im;
+        t.params = params_dev;
+        if (!params_dev) std::memcpy(t.inl, params_inline, (size_t)B * K * sizeof(gat_channel_params));
+        t.codes = c->d_codes;
+        t.out_re = out_re;
+        t.out_im = out_im;
+        if (flagged) {
+            t.done_counter = c->d_done;
+            t.host_flag = c->d_flag;
+            t.flag_seq = next_seq();
+        }
+        t.N = N; t.ant_stride = sig->ant_stride; t.block_stride = sig->block_stride; t.chan_stride = sig->chan_stride;
+        t.fs = fs;
+        t.M = M; t.K = K; t.B = B; t.L = L; t.Lc = c->Lc; t.num_prns = c->P; t.code_row_stride = c->code_row_stride;
+        t.format = fmt; t.n_vec = a.n_vec; t.max_abs_shift = (int)max_shift;
+        for (int l = 0; l < L; ++l) t.shifts[l] = shifts[l];
+        GAT_HIP(c, launch_dc_tail(t, c->stream));
     }
     if (flagged) c->wait_seq = c->flag_seq;
 

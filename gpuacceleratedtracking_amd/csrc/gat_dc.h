@@ -330,8 +330,9 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
 
     const int c_begin = split * a.chunks_per_split;
     const int c_end = min(c_begin + a.chunks_per_split, a.total_chunks);
-    // VEC == 4 (16-byte aligned input, N a multiple of the group size): EVERY chunk takes the vector path -- the lanes
-    // of the ragged last chunk that lie beyond the block read zeros (buffer range check, no memory traffic).
+    // VEC == 4 (16-byte aligned block starts): EVERY chunk takes the vector path -- the lanes of the last chunk that lie
+    // beyond the block's last whole group read zeros (buffer range check, no memory traffic); the N % S samples behind
+    // that group are added by dc_tail_kernel, a second launch that exists for such block lengths only.
     // VEC == 1 (unaligned input): everything takes the per-sample path.
     const int c_full = VEC == 4 ? c_end : c_begin;
     // D register sets of samples: set d holds the steps d, d + D, ... of a block; while a step is consumed the following
@@ -370,7 +371,13 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
         const char *const p_im = static_cast<const char *>(FMT == GAT_LAYOUT_PLANAR ? a.im : a.re) + base * EB;
         const size_t ant_bytes = (size_t)a.ant_stride * EB;
         const size_t blk_bytes = (size_t)a.block_stride * EB;
-        const int blk_len = N * EB; // bytes of one antenna's block
+        // whole 16-byte groups only: of a block length that is no multiple of the group size S the vector path covers the
+        // first n_vec = N - N % S samples (lanes beyond read zeros through the range check); the N % S < 8 samples behind
+        // them are added by dc_tail_kernel (gat_kernels.hip), launched behind this kernel for such lengths only.  Inside
+        // this kernel a per-sample path costs every instance registers whether it runs or not -- measured twice: behind
+        // the step loop its scalar state stays live across the loop (+ 4 registers everywhere, the one-wave three-tap
+        // instance 6 -> 5 waves per SIMD), ahead of the loop the accumulators become live on two paths (+ 6-18).
+        const int blk_len = (VEC == 4 ? a.n_vec : N) * EB; // bytes of one antenna's block that this kernel covers
         const unsigned tile_len = (unsigned)((MT - 1) * ant_bytes) + (unsigned)blk_len; // the descriptors' num_records (host: < 2^31)
         constexpr unsigned kNoRecord = 0x80000000u;
         auto plane_rsrc = [&](const char *p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p), 0, (int)tile_len, 0x00020000); };

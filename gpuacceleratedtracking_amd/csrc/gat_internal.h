@@ -68,6 +68,7 @@ struct DcArgs {
     int rep_copy_stride;   // floats between the replica and its copy shifted by one entry (taps at odd offsets), 0: one copy
     int rep_chan_floats;   // one-wave workgroups: floats of LDS per channel replica (sized for this launch's taps)
     int keep_l2;           // 1: plain loads (several channel groups share the tile through L2), 0: non-temporal
+    int n_vec;             // samples of a block the vector path covers: N - N % (samples per 16-byte load); N for scalar loads
     unsigned flags;
     int shifts[kMaxTapsPerLaunch];    // ascending
     int tap_off[kMaxTapsPerLaunch];   // float offset of tap l's chips from the lane's group base: even (8-byte aligned reads)
@@ -76,6 +77,23 @@ struct DcArgs {
     // kernel_algorithm with scalar arguments): no 40-byte upload in front of the launch (3.3 us of a 15 us call)
     gat_channel_params inl[kInlineParams];
 };
+
+// Arguments of dc_tail_kernel (gat_kernels.hip): the N % S samples at the end of every block that the vector path of
+// dc_kernel leaves out when the block length is no multiple of the samples S one 16-byte load holds.
+struct DcTailArgs {
+    const void *re, *im;
+    const gat_channel_params *params; // dev [B*K], or null: the records are in `inl`
+    const int8_t *codes;
+    float *out_re, *out_im;           // [B][K][L][M]: the tail's sums are ADDED to what dc_kernel (+ second stage) wrote
+    unsigned *done_counter, *host_flag;
+    unsigned flag_seq;
+    long long N, ant_stride, block_stride, chan_stride;
+    double fs;
+    int M, K, B, L, Lc, num_prns, code_row_stride, format, n_vec, max_abs_shift;
+    int shifts[GAT_MAX_TAPS];         // in the caller's order
+    gat_channel_params inl[kInlineParams];
+};
+hipError_t launch_dc_tail(const DcTailArgs &a, hipStream_t s);
 
 struct DcLaunch {
     int ant_tile; // MT: antennas per wave

@@ -86,6 +86,71 @@ finalize_few_kernel(const float *__restrict__ partial, float *__restrict__ out_r
     completion_flag(done_counter, host_flag, flag_seq, gridDim.x);
 }
 
+// The ragged end of every block: dc_kernel's vector path covers whole 16-byte load groups (n_vec = N - N % S samples of
+// each block, S = 4 / 2 / 4 / 8 by sample format); for a block length that is no multiple of S -- N = 2046 at
+// fs = 2 x 1.023 MHz, the reference's N = 2500 fixture as int8 pairs -- this kernel adds the remaining N % S < 8 samples
+// to the results, stream-ordered behind dc_kernel and its second stage (one writer per output element: deterministic).
+// The reference bounds every thread by num_samples instead (src/algorithms.jl:170).  One thread per (block, channel,
+// antenna): the reference's expressions evaluated directly (double-precision code phase, unfused; carrier phase in
+// double, float sincos on the reduced argument), chips straight from the global table.  A few hundred threads of a
+// few dozen instructions; launched for such block lengths only.
+__global__ void __launch_bounds__(kThreads) dc_tail_kernel(const DcTailArgs a)
+{
+    const long long t = (long long)blockIdx.x * kThreads + threadIdx.x;
+    const long long total = (long long)a.B * a.K * a.M;
+    if (t < total) {
+        const int m = (int)(t % a.M);
+        const long long bk = t / a.M;
+        const int k = (int)(bk % a.K);
+        const long long b = bk / a.K;
+        const gat_channel_params P = a.params ? a.params[bk] : a.inl[bk];
+        const double ratio = P.code_freq_hz / a.fs, tau = P.code_phase_chips; // src/algorithms.jl:179
+        const double step = P.carrier_freq_hz / a.fs, phi = P.carrier_phase_cycles;
+        const int N = (int)a.N;
+        // the same predicate as dc_kernel: such a channel's outputs are NaN already, nothing to add (and nothing indexed)
+        const bool bad = P.prn < 0 || P.prn >= a.num_prns || code_span_bad(ratio, tau, (double)(N + a.max_abs_shift), a.Lc) ||
+                         !(step == step) || !(phi == phi) || !(__builtin_fabs(step) < 1.0e15) || !(__builtin_fabs(phi) < 1.0e15);
+        if (!bad) {
+            const int r = N - a.n_vec; // 1 .. 7
+            const size_t base = (size_t)b * a.block_stride + (size_t)k * a.chan_stride + (size_t)m * a.ant_stride + a.n_vec;
+            float dr[8], di[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                dr[j] = di[j] = 0.f;
+                if (j < r) {
+                    float xr, xi, cr, ci;
+                    switch (a.format) {
+                    case GAT_LAYOUT_PLANAR: SampleIO<GAT_LAYOUT_PLANAR>::load1(a.re, a.im, base + j, xr, xi); break;
+                    case GAT_LAYOUT_INTERLEAVED: SampleIO<GAT_LAYOUT_INTERLEAVED>::load1(a.re, a.im, base + j, xr, xi); break;
+                    case GAT_LAYOUT_INTERLEAVED_I16: SampleIO<GAT_LAYOUT_INTERLEAVED_I16>::load1(a.re, a.im, base + j, xr, xi); break;
+                    default: SampleIO<GAT_LAYOUT_INTERLEAVED_I8>::load1(a.re, a.im, base + j, xr, xi); break;
+                    }
+                    const double th = __builtin_fma((double)(a.n_vec + j), step, phi); // src/algorithms.jl:172
+                    sincos_cycles(th - __builtin_rint(th), cr, ci);
+                    dr[j] = __builtin_fmaf(xr, cr, xi * ci); // conjugate wipe-off, src/algorithms.jl:175-176
+                    di[j] = __builtin_fmaf(xi, cr, -(xr * ci));
+                }
+            }
+            const int8_t *code = a.codes + (size_t)P.prn * a.code_row_stride;
+            const float inv_lc = 1.0f / (float)a.Lc;
+            for (int l = 0; l < a.L; ++l) {
+                float sr = 0.f, si = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < r) {
+                        const float c = (float)code[chip_index(ratio, tau, a.n_vec + j + a.shifts[l], a.Lc, inv_lc)];
+                        sr = __builtin_fmaf(c, dr[j], sr);
+                        si = __builtin_fmaf(c, di[j], si);
+                    }
+                const size_t o = ((size_t)bk * a.L + l) * a.M + m;
+                a.out_re[o] += sr;
+                a.out_im[o] += si;
+            }
+        }
+    }
+    completion_flag(a.done_counter, a.host_flag, a.flag_seq, gridDim.x);
+}
+
 // ------------------------------------------------------------------------------------------
 // stand-alone operators
 // ------------------------------------------------------------------------------------------
@@ -408,6 +473,13 @@ hipError_t launch_finalize(const float *partial, float *out_re, float *out_im, i
     const unsigned grid = (unsigned)((waves + kFinElems - 1) / kFinElems);
     hipLaunchKernelGGL(finalize_kernel, dim3(grid), dim3(kThreads), 0, s, partial, out_re, out_im,
                        splits, elems, waves, done_counter, host_flag, flag_seq);
+    return hipGetLastError();
+}
+
+hipError_t launch_dc_tail(const DcTailArgs &a, hipStream_t s)
+{
+    const long long total = (long long)a.B * a.K * a.M;
+    hipLaunchKernelGGL(dc_tail_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)), dim3(kThreads), 0, s, a);
     return hipGetLastError();
 }
 

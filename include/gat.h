@@ -82,10 +82,10 @@ typedef struct gat_channel_params {
  *   n + m*ant_stride + b*block_stride + k*chan_stride          (in samples). */
 /* Fast path requirements (checked per call; a signal that misses them is still correlated, by the scalar-load kernel --
  * one antenna per wave, a double-precision sincos per sample, typically 5-10x slower; gat_launch_info.vec tells which ran):
- * plane base pointers 16-byte aligned, and ant_stride, block_stride, chan_stride AND num_samples multiples of the samples
- * one 16-byte load holds -- 4 (planar float), 2 (ComplexF32 pairs), 4 (int16 pairs), 8 (int8 pairs).  A receiver whose
- * block length is not such a multiple (e.g. N = 2046) pads its blocks: block_stride up to the next multiple, num_samples
- * down to the previous one plus a short second call, or simply N + pad zeros. */
+ * plane base pointers 16-byte aligned, and ant_stride, block_stride and chan_stride multiples of the samples one 16-byte
+ * load holds -- 4 (planar float), 2 (ComplexF32 pairs), 4 (int16 pairs), 8 (int8 pairs) --, i.e. every block of every
+ * antenna STARTS on a 16-byte boundary.  num_samples itself may be anything (N = 2046 at fs = 2 x 1.023 MHz, N = 2500 as
+ * int8 pairs ...): a receiver with such a block length pads block_stride to the next multiple, nothing else. */
 typedef struct gat_signal_desc {
     const void *re;       /* dev; planar: float real plane. interleaved formats: base pointer */
     const void *im;       /* dev; planar: float imaginary plane. interleaved formats: NULL    */

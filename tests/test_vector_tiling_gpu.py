@@ -193,6 +193,8 @@ def test_one_wave_workgroups_match_the_oracle(gat, shape, layout):
             case["im"] = np.rint(case["im"] * s).astype(np.float32)
         got, info = run_case(gat, ctx, case, layout=layout)
         group = {0: 4, 1: 2, 2: 4, 3: 8}[layout]
+        # (blocks are stored N apart here: a length that is no multiple of the load group also misaligns every later
+        # block's start, which is what sends the case to the scalar-load kernel and its four-wave geometry)
         assert info["threads"] == (64 if N % group == 0 else 256), info
         check_close(got, oracle_result(case), what=f"{shape} {info}")
         # and the four-wave geometry on the same inputs: same chip edges, same sums up to summation order
@@ -300,14 +302,19 @@ def test_two_sample_sets_match_the_oracle_and_one_set(gat, shape, layout):
         check_close(outs[0], oracle_result(small), what=f"{shape} layout {layout}")
 
 
-@pytest.mark.parametrize("N,M,layout", [(4002, 4, "planar"), (2501, 2, "planar"), (4004, 1, "i8")])
-def test_ragged_block_length_takes_the_scalar_kernel_and_padding_restores_the_vector_kernel(gat, N, M, layout):
-    """the 16-byte vector path needs num_samples to be a multiple of the samples one load holds (include/gat.h,
-    gat_signal_desc).  A block length that is not (aligned strides otherwise) is served by the scalar-load kernel -- still
-    equal to the oracle, and launch_info.vec says so; the documented remedy, zero padding up to the next multiple, gives
-    the same result from the vector kernel (zeros add nothing) and is several times faster."""
-    import time
+RAGGED = [(2046, 4, "planar"), (2500, 4, "i8"), (4099, 4, "planar"), (2501, 2, "interleaved"), (4002, 1, "i16"), (4004, 1, "i8"),
+          (5, 2, "i8"), (3, 4, "planar")]
 
+
+@pytest.mark.parametrize("N,M,layout", RAGGED, ids=[f"N{n}-M{m}-{l}" for n, m, l in RAGGED])
+def test_ragged_block_length_runs_the_vector_kernel(gat, N, M, layout):
+    """The reference bounds every thread by num_samples (src/algorithms.jl:170): any block length works.  Here the 16-byte
+    vector path needs every block of every antenna to START on a 16-byte boundary (strides padded to the load group), but
+    the length itself may be anything -- N = 2046 (fs = 2 x 1.023 MHz), the reference's N = 2500 fixture as int8 pairs
+    (2500 % 8 = 4), N = 4099: lanes behind the last whole group read zeros through the buffer range check and
+    dc_tail_kernel adds the N % S samples behind it.  Same result as the oracle and as the zero-padded length; vec == 4;
+    and no cliff: at most 1.3 x the time of the padded length on a stream of >= 128 MB (the tail is one more dependent
+    launch, ~ 6 us of device time whatever the size; round 3 sent such lengths to the scalar-load kernel, 5-10 x slower)."""
     import torch
     g = gat
     case = make_case(321 + N, N=N, M=M, K=2, B=4, L=3)
@@ -316,40 +323,76 @@ def test_ragged_block_length_takes_the_scalar_kernel_and_padding_restores_the_ve
     prm = g.make_params(case["prm"]["prn0"], case["prm"]["code_freq_hz"], case["prm"]["carrier_freq_hz"],
                         case["prm"]["code_phase_chips"], case["prm"]["carrier_phase_cycles"])
     B = case["B"]
-    spv = 8 if layout == "i8" else 4
+    spv = {"planar": 4, "interleaved": 2, "i16": 4, "i8": 8}[layout]
+    lay = {"planar": g.GAT_LAYOUT_PLANAR, "interleaved": g.GAT_LAYOUT_INTERLEAVED, "i16": g.GAT_LAYOUT_INTERLEAVED_I16,
+           "i8": g.GAT_LAYOUT_INTERLEAVED_I8}[layout]
     Np = (N + spv - 1) // spv * spv
-    # blocks stored Np apart (aligned strides); the operator is told N (ragged) or Np (padded with zeros)
-    re = torch.zeros((M, B * Np), device=dev)
-    im = torch.zeros((M, B * Np), device=dev)
-    for b in range(B):
-        re[:, b * Np:b * Np + N] = torch.from_numpy(case["re"][:, b * N:(b + 1) * N]).to(dev)
-        im[:, b * Np:b * Np + N] = torch.from_numpy(case["im"][:, b * N:(b + 1) * N]).to(dev)
-    if layout == "i8":
-        scale = 20.0
-        x = torch.stack([torch.clamp(torch.round(re * scale), -128, 127), torch.clamp(torch.round(im * scale), -128, 127)],
-                        dim=-1).to(torch.int8).contiguous()
-        ref_case = dict(case)
-        ref_case["re"] = np.concatenate([x[:, b * Np:b * Np + N, 0].cpu().numpy().astype(np.float32) for b in range(B)], axis=1)
-        ref_case["im"] = np.concatenate([x[:, b * Np:b * Np + N, 1].cpu().numpy().astype(np.float32) for b in range(B)], axis=1)
-        ref = oracle_result(ref_case)
-    else:
-        ref = oracle_result(case)
-    out, vec, times = {}, {}, {}
+    assert Np != N
+
+    def stream(nblk, src_re, src_im):
+        """blocks stored Np apart (aligned strides), zeros in the padding"""
+        re = torch.zeros((M, nblk * Np), device=dev)
+        im = torch.zeros((M, nblk * Np), device=dev)
+        re.view(M, nblk, Np)[:, :, :N] = src_re
+        im.view(M, nblk, Np)[:, :, :N] = src_im
+        if layout == "planar":
+            return (re, im), re, im
+        if layout == "interleaved":
+            x = torch.stack([re, im], dim=-1).contiguous()
+            return (x,), re, im
+        scale, lim, dt = (100.0, 32767, torch.int16) if layout == "i16" else (20.0, 127, torch.int8)
+        x = torch.stack([torch.clamp(torch.round(re * scale), -lim - 1, lim), torch.clamp(torch.round(im * scale), -lim - 1, lim)],
+                        dim=-1).to(dt).contiguous()
+        return (x,), x[..., 0].float(), x[..., 1].float()
+
+    keep, q_re, q_im = stream(B, torch.from_numpy(case["re"]).to(dev).view(M, B, N), torch.from_numpy(case["im"]).to(dev).view(M, B, N))
+    ref_case = dict(case)  # what the kernel is given, block after block without the padding
+    ref_case["re"] = q_re.view(M, B, Np)[:, :, :N].reshape(M, B * N).cpu().numpy()
+    ref_case["im"] = q_im.view(M, B, Np)[:, :, :N].reshape(M, B * N).cpu().numpy()
+    ref = oracle_result(ref_case)
+
+    def desc_for(bufs, n, nblk):
+        return g._lib.SignalDesc(bufs[0].data_ptr(), bufs[1].data_ptr() if layout == "planar" else None, lay, M, n, nblk * Np, Np, 0)
+
+    out, info = {}, {}
     for name, n in (("ragged", N), ("padded", Np)):
-        op = g.StreamCorrelator(sysobj, n, M, B, 2, case["shifts"], case["fs"])
-        op.set_params(prm)
-        desc = g._lib.SignalDesc(x.data_ptr() if layout == "i8" else re.data_ptr(), None if layout == "i8" else im.data_ptr(),
-                                 g.GAT_LAYOUT_INTERLEAVED_I8 if layout == "i8" else g.GAT_LAYOUT_PLANAR, M, n, B * Np, Np, 0)
-        op.launch(desc)
-        out[name] = op.result()
-        vec[name] = op.ctx.last_launch_info()["vec"]
-        op.ctx.sync()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            op.launch(desc)
-        op.ctx.sync()
-        times[name] = (time.perf_counter() - t0) / 20
-    assert vec == {"ragged": 1, "padded": 4}, vec
-    check_close(out["ragged"], ref, what="ragged N through the scalar kernel")
-    check_close(out["padded"], ref, what="zero-padded N through the vector kernel")
-    print(f"N={N} {layout}: scalar kernel {times['ragged'] * 1e6:.1f} us, padded vector kernel {times['padded'] * 1e6:.1f} us per launch")
+        for flags in (0, g.GAT_FLAG_ATOMIC):
+            op = g.StreamCorrelator(sysobj, n, M, B, 2, case["shifts"], case["fs"], flags=flags)
+            op.set_params(prm)
+            op.launch(desc_for(keep, n, B))
+            out[name, flags] = op.result()
+            info[name, flags] = op.ctx.last_launch_info()
+    for key, i in info.items():
+        assert i["vec"] == 4, (key, i)
+    for key, got in out.items():
+        check_close(got, ref, what=f"N={N} {layout} {key}")
+    # B = 1, M = 1: strides that are never applied do not matter (a single-block call with any N takes the vector path)
+    op = g.StreamCorrelator(sysobj, N, 1, 1, 2, case["shifts"], case["fs"])
+    op.set_params(prm[:1])
+    d1 = desc_for(keep, N, B)
+    d1.num_ants, d1.ant_stride, d1.block_stride = 1, N, N
+    op.launch(d1)
+    assert op.ctx.last_launch_info()["vec"] == 4
+    check_close(op.result(), ref[:1, :, :, :1], what=f"N={N} {layout} single block, one antenna")
+
+    # ---- no cliff: a long stream of ragged blocks against the same stream told the padded length
+    if N < 1000:
+        return
+    sample_bytes = {"planar": 8, "interleaved": 8, "i16": 4, "i8": 2}[layout]
+    big = max(2048, -(-(128 << 20) // (Np * M * sample_bytes)) // B * B)
+    rng = torch.Generator(device=dev).manual_seed(N)
+    bufs, _, _ = stream(big, torch.randn((M, big, N), device=dev, generator=rng), torch.randn((M, big, N), device=dev, generator=rng))
+    prm_big = np.tile(prm, (big // B, 1))
+    times = {}
+    for name, n in (("ragged", N), ("padded", Np)):
+        op = g.StreamCorrelator(sysobj, n, M, big, 2, case["shifts"], case["fs"])
+        op.set_params(prm_big)
+        d = desc_for(bufs, n, big)
+        for _ in range(30):
+            op.launch(d)
+        op.ctx.timer_start()
+        for _ in range(40):
+            op.launch(d)
+        times[name] = op.ctx.timer_stop() / 40
+    print(f"N={N} {layout} x {big} blocks: ragged {times['ragged'] * 1e3:.1f} us, padded {times['padded'] * 1e3:.1f} us per launch")
+    assert times["ragged"] <= 1.3 * times["padded"], times
