@@ -68,6 +68,7 @@ struct gat_ctx {
     long long one_wave_min = -1;              // option dc_one_wave_min: fewest (block, channel, tile) groups for them (default 32 per CU)
     int one_wave_seg = kOneWaveSegSteps;      // option dc_ow_seg: steps per replica segment of a one-wave workgroup
     int max_depth = 2;                        // option dc_depth: cap of the sample prefetch depth (register sets per wave)
+    int keep_l2 = -1;                         // option dc_keep_l2: cache policy of the sample loads (-1: by rule)
     int mc_mode = 1; // GAT_MC_* kernel selection (gat_set_matrix_core)
     std::string err;
     gat_launch_info last{};
@@ -529,7 +530,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     a.num_tiles = (int)tiles;
     a.Ltot = L;
     a.flags = flags;
-    a.keep_l2 = KG > 1 && sig->chan_stride == 0;
+    a.keep_l2 = c->keep_l2 >= 0 ? c->keep_l2 : (KG > 1 && sig->chan_stride == 0);
     a.n_vec = (int)(vec == 4 ? N - N % spv : N);
     // a block length that is no multiple of the load group: the N % spv samples behind the last whole group are added
     // by dc_tail_kernel, one more (tiny) launch behind the vector kernel and its second stage
@@ -545,7 +546,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     // only -- every byte read once (one channel group), a workgroup owns whole blocks (no split), >= 2 steps per block.
     // (float samples: with int16 / int8 pairs the conversions make the step vector-bound and the third wave per SIMD that
     // the second set costs is worth more: 0.206 -> 0.209 ms, 0.169 -> 0.170 ms)
-    const bool deep_ok = c->max_depth >= 2 && vec == 4 && splits == 1 && KG == 1 && sig->chan_stride == 0 && chunks >= 2 &&
+    const bool deep_ok = c->max_depth >= 2 && vec == 4 && splits == 1 && KG == 1 && c->keep_l2 != 1 && sig->chan_stride == 0 && chunks >= 2 &&
                          (fmt == GAT_LAYOUT_PLANAR || fmt == GAT_LAYOUT_INTERLEAVED);
     cfg.vec = vec;
     cfg.format = fmt;
@@ -737,7 +738,7 @@ int32_t graph_replay_or_record(gat_ctx *c, MakeKey make_key, Enqueue enqueue)
 void key_put_ctx(std::vector<unsigned char> &key, const gat_ctx *c)
 {
     key_put(key, c->mc_mode); key_put(key, c->max_aw); key_put(key, c->max_kt); key_put(key, c->max_bpw); key_put(key, c->force_bpw);
-    key_put(key, c->wgs_per_cu); key_put(key, c->max_depth); key_put(key, c->one_wave);
+    key_put(key, c->wgs_per_cu); key_put(key, c->max_depth); key_put(key, c->one_wave); key_put(key, c->keep_l2);
     key_put(key, c->d_codes); key_put(key, c->d_code_bits); key_put(key, c->Lc); key_put(key, c->P);
     key_put(key, c->d_partial); key_put(key, c->partial_bytes);
 }
@@ -762,8 +763,9 @@ constexpr OptionDesc kOptions[] = {
     {"dc_wgs_per_cu", 0, 1024},      // workgroups per CU the split planner aims for (0: by instance)
     {"dc_one_wave", 0, 1},           // one-wave workgroups allowed
     {"dc_one_wave_min", -1, 1ll << 40}, // fewest (block, channel, tile) groups for them (-1: 32 per CU)
-    {"dc_ow_seg", 1, 64},            // steps per replica segment of a one-wave workgroup
+    {"dc_ow_seg", 1, kUcarSteps},    // steps per replica segment of a one-wave workgroup
     {"dc_depth", 1, 2},              // cap of the sample prefetch depth (register sets per wave)
+    {"dc_keep_l2", -1, 1},           // sample loads: -1 by rule (plain when channel groups share a tile through L2), 0 non-temporal, 1 plain
 };
 
 int32_t set_option(gat_ctx *c, const char *name, long long v)
@@ -785,6 +787,7 @@ int32_t set_option(gat_ctx *c, const char *name, long long v)
     else if (n == "dc_one_wave_min") c->one_wave_min = v;
     else if (n == "dc_ow_seg") c->one_wave_seg = (int)v;
     else if (n == "dc_depth") c->max_depth = (int)v;
+    else if (n == "dc_keep_l2") c->keep_l2 = (int)v;
     return GAT_OK;
 }
 

@@ -243,7 +243,16 @@ __device__ __forceinline__ void completion_flag(unsigned *done_counter, unsigned
 #ifndef GAT_DC_MINW
 #define GAT_DC_MINW 3
 #endif
-constexpr int dc_min_waves(int mt, int l, int kt, int d = 1) { return 2 * mt * l * kt <= 40 ? (d == 1 && 2 * mt * l * kt >= 40 ? GAT_DC_MINW : 3) : 1; }
+#ifndef GAT_DC_MINW_BIG
+#define GAT_DC_MINW_BIG 2
+#endif
+#ifndef GAT_DC_MINW_SMALL
+#define GAT_DC_MINW_SMALL 4
+#endif
+constexpr int dc_min_waves(int mt, int l, int kt, int d = 1)
+{
+    return 2 * mt * l * kt <= 40 ? (d == 1 && 2 * mt * l * kt >= 40 ? GAT_DC_MINW : (d == 1 && 2 * mt * l * kt <= 24 ? GAT_DC_MINW_SMALL : 3)) : GAT_DC_MINW_BIG;
+}
 
 // Diagnostic builds (-DGAT_DC_LAT_CUT=n, scripts/r03_latency_cuts.sh): the kernel ends at cut point n -- 1 entry, 2 block
 // set-up + chip tables, 3 first replica segment + carrier anchors, 4 step loop -- so that the single-block latency can be
@@ -290,7 +299,8 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
     struct ChanConst { double ratio, tau, step, phi; }; // per channel slot: read at segment starts and on ragged ends
     ChanConst *s_const = reinterpret_cast<ChanConst *>(smem);                          // [KT]
     float *s_part = reinterpret_cast<float *>(smem + KT * sizeof(ChanConst));          // [KT][NW][64]
-    float *s_rep = s_part + KT * NW * 64;                                              // [KT][RCH]
+    float *s_ucar = s_part + KT * NW * 64;                                             // [KT][kUcarSteps][G * S][re, im]
+    float *s_rep = s_ucar + KT * kUcarFloats;                                          // [KT][RCH]
     const int SEG = a.seg_steps;        // steps whose replica is produced at once (<= dc_segment_steps(CHUNK, KT, MT))
     // floats per channel: the replica (+ its shifted copy); one-wave workgroups: sized by the host for this launch
     const int RCH = NW == 1 ? a.rep_chan_floats : dc_rep_chan_floats(CHUNK, KT, MT);
@@ -418,7 +428,10 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
         // The double-precision ones (code rate, code phase, carrier step, carrier phase) are needed at segment starts
         // and on ragged ends only: they live in LDS.  In registers (wave-uniform -> scalar): the one-sample and
         // one-step carrier rotations.  (The previous block's last reads of s_const precede its reduction barrier.)
-        float wr_k[KT], wi_k[KT], cwr_k[KT], cwi_k[KT];
+        // Carrier = U x Q: U[step][sample of a lane's groups] = exp(j 2 pi f/fs (step * CHUNK + g * GSTRIDE + j)) is the same
+        // for every lane and wave -- one table per segment in LDS (below) --, Q = exp(j 2 pi (f/fs * rel0 + phi)) is this
+        // lane's constant for the whole block: the step loop wipes off with U (no per-lane phasor arithmetic at all) and
+        // the block's accumulators are rotated by conj(Q) once, ahead of the reduction.
         unsigned valid_mask = 0, bad_mask = 0;
         bool restage = false;
         int prn_k[KT];
@@ -458,14 +471,6 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
             prn_k[kk] = (P.prn < 0 || P.prn >= a.num_prns) ? 0 : P.prn;
             restage |= valid && prn_k[kk] != staged_prn[kk];
             if (tid == 0) s_const[kk] = ChanConst{ratio, tau, step, phi};
-            float c_, s_;
-            sincos_cycles(step - __builtin_rint(step), c_, s_); // one-sample rotation exp(+j*2*pi*step)
-            wr_k[kk] = uni(c_);
-            wi_k[kk] = uni(s_);
-            const double cs = step * (double)CHUNK;             // one-step rotation of a carried phasor
-            sincos_cycles(cs - __builtin_rint(cs), c_, s_);
-            cwr_k[kk] = uni(c_);
-            cwi_k[kk] = uni(s_);
         }
         valid_mask = uni(valid_mask);
         bad_mask = uni(bad_mask);
@@ -499,7 +504,6 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
             w_exact = uni(wc.exact_only) != 0;
         }
 
-        float car_r[KT][G], car_i[KT][G]; // phasors of this lane's groups, carried from step to step
 
         f32x2 acc[KT][MT][L]; // (re, im)
 #pragma unroll
@@ -571,8 +575,10 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
         // multiply-adds -- every instruction then has its operands ready when it issues (written sample by sample the
         // compiler forms the products right in front of their first use; configs[2] 1.36 -> 1.30 ms).  Not for the
         // channel-looping instances: six more live registers there (configs[3] shard 0.70 -> 0.725 ms).
+        // (`between` runs after the wipe-off products are formed and ahead of the tap multiply-adds: the last antenna of a
+        // pass re-reads the phasor registers for the next pass there)
         auto accumulate_sub = [&](f32x2 (&ac)[L], const i32x4 (&rw)[IO::NV], int j0, const float (&pr)[SB], const float (&pi)[SB],
-                                  const float (&chip)[SB][L]) {
+                                  const float (&chip)[SB][L], auto between) {
             float xr[SB], xi[SB], tr[SB], ti[SB], dr[SB], di[SB];
 #pragma unroll
             for (int j = 0; j < SB; ++j) {
@@ -585,6 +591,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
                 dr[j] = __builtin_fmaf(xr[j], pr[j], tr[j]);
                 di[j] = __builtin_fmaf(xi[j], pr[j], ti[j]);
             }
+            between();
 #pragma unroll
             for (int j = 0; j < SB; ++j)
 #pragma unroll
@@ -593,14 +600,20 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
                     ac[l][1] = __builtin_fmaf(chip[j][l], di[j], ac[l][1]);
                 }
         };
-        // the S phasors of one group: carried phasor + S-1 rotations
-        auto group_phasors = [&](float (&pr)[S], float (&pi)[S], int kk, int g) {
-            pr[0] = car_r[kk][g];
-            pi[0] = car_i[kk][g];
+        // SB phasors of the step at segment position st: entries [e0, e0 + SB) of the step's row of the table U (every lane
+        // reads the same address: broadcast reads, 16 bytes = two phasors each)
+        auto table_phasors = [&](auto cnt_c, float *pr, float *pi, int kk, int st, int e0) {
+            constexpr int CNT = decltype(cnt_c)::value;
+            const float *u = s_ucar + (kk * kUcarSteps + st) * (2 * G * S) + 2 * e0;
+            if constexpr (CNT % 2 == 0) {
 #pragma unroll
-            for (int j = 1; j < S; ++j) {
-                pr[j] = __builtin_fmaf(pr[j - 1], wr_k[kk], -(pi[j - 1] * wi_k[kk]));
-                pi[j] = __builtin_fmaf(pr[j - 1], wi_k[kk], pi[j - 1] * wr_k[kk]);
+                for (int j = 0; j < CNT; j += 2) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(u + 2 * j);
+                    pr[j] = v[0]; pi[j] = v[1]; pr[j + 1] = v[2]; pi[j + 1] = v[3];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CNT; ++j) pr[j] = u[2 * j], pi[j] = u[2 * j + 1];
             }
         };
         // samples [n_lo, n_hi) one at a time with scalar loads (ragged block end, unaligned input)
@@ -700,14 +713,23 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
             if (c0 > c_begin) __syncthreads(); // everybody has finished reading the previous segment's replica
 #endif
             fill_segment(c0, (c1 - c0) * CHUNK + a.rep_span);
-            // exact carrier anchors of this lane's groups at the segment start (src/algorithms.jl:172)
-#pragma unroll
-            for (int kk = 0; kk < KT; ++kk)
-#pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const double th = __builtin_fma((double)(c0 * CHUNK + g * GSTRIDE + rel0), s_const[kk].step, s_const[kk].phi);
-                    sincos_cycles(th - __builtin_rint(th), car_r[kk][g], car_i[kk][g]);
+            // the segment's carrier table U: one exact evaluation (src/algorithms.jl:172: double-precision phase, reduced,
+            // float sincos) per (channel, step, sample of a lane's groups) -- KT * steps * G * S <= 256 entries, one thread each
+            static_assert(KT * kUcarSteps * G * S <= T, "one table entry per thread");
+            {
+                // (the thread id goes through an opaque copy: everything derived from it is otherwise hoisted out of the
+                // segment loop and kept in registers across the step loop -- twelve of them, a wave per SIMD in some instances)
+                int t_ = tid;
+                asm volatile("" : "+v"(t_));
+                const int e = t_ % (G * S), st = (t_ / (G * S)) % kUcarSteps, kk = t_ / ((G * S) * kUcarSteps);
+                if (kk < KT && st < c1 - c0) {
+                const int n = (c0 + st) * CHUNK + (e / S) * GSTRIDE + (e % S); // sample of lane 0 (rel0 = 0)
+                const double th = (double)n * s_const[kk].step;
+                float cr, ci;
+                sincos_cycles(th - __builtin_rint(th), cr, ci);
+                *reinterpret_cast<f32x2 *>(s_ucar + ((kk * kUcarSteps + st) * (G * S) + e) * 2) = f32x2{cr, ci};
                 }
+            }
 #if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 8))
             __syncthreads();
 #endif
@@ -718,6 +740,9 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
             // register set).  The prefetch is unconditional -- a conditional one makes the compiler copy the whole
             // register array around the branch; after the last whole chunk every lane re-loads the block's first bytes.
             const int cf = VEC == 4 ? c1 : c_begin; // c1 <= c_stop: a multiple of D steps from c0 (SEG is one: host)
+            // one channel per workgroup: the phasors of a pass live in these registers from the end of the previous pass
+            float pr[SB], pi[SB];
+            if constexpr (KT == 1 && VEC == 4 && MT >= 2) table_phasors(std::integral_constant<int, SB>{}, pr, pi, 0, 0, 0);
             // one step: the samples of chunk c sit in register set DI, which is refilled with chunk c + D
             auto step = [&](auto di, int c) {
                 constexpr int DI = decltype(di)::value;
@@ -743,29 +768,30 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
                         // SB samples at a time (NH = 2 passes over the eight-sample groups of int8 pairs: chips, phasors and
                         // wipe-off products of four samples live at once instead of eight -- 153 -> fewer registers, a
                         // fourth wave per SIMD); an antenna's registers are refilled when its last samples are consumed
-                        float run_r = car_r[0][g], run_i = car_i[0][g];
 #pragma unroll
                         for (int h = 0; h < NH; ++h) {
-                            float pr[SB], pi[SB], chip[SB][L];
+                            float chip[SB][L];
                             // the chips' LDS reads go out first: left alone the scheduler issues them behind the first
                             // antenna's wipe-off (and its wait for the samples), right in front of their first use
                             // (configs[2] 1.178 -> 1.169 ms, the other shapes unchanged: profiles/r03/r03x_ab_chips_first.txt)
                             get_chips_sub(chip, rel + h * SB, s_rep);
                             __builtin_amdgcn_sched_barrier(0);
-                            pr[0] = run_r;
-                            pi[0] = run_i;
-#pragma unroll
-                            for (int j = 1; j < SB; ++j) {
-                                pr[j] = __builtin_fmaf(pr[j - 1], wr_k[0], -(pi[j - 1] * wi_k[0]));
-                                pi[j] = __builtin_fmaf(pr[j - 1], wi_k[0], pi[j - 1] * wr_k[0]);
-                            }
-                            if (h + 1 < NH) { // the next batch's first phasor
-                                run_r = __builtin_fmaf(pr[SB - 1], wr_k[0], -(pi[SB - 1] * wi_k[0]));
-                                run_i = __builtin_fmaf(pr[SB - 1], wi_k[0], pi[SB - 1] * wr_k[0]);
-                            }
+                            // the pass's phasors were read at the end of the previous pass; the NEXT pass's are read while
+                            // the last antenna's tap multiply-adds run (same registers: no wait for LDS at a pass's start)
+                            // (one-antenna tiles read them at the pass's start: there is no other antenna's arithmetic to
+                            // read behind, and the early read costs the one-wave instances four registers = a wave per SIMD)
+                            constexpr bool PF = MT >= 2;
+                            if constexpr (!PF) table_phasors(std::integral_constant<int, SB>{}, pr, pi, 0, c - c0, g * S + h * SB);
+                            const bool last_pass = h + 1 == NH && g + 1 == G;
+                            const int st_n = (c - c0) + (last_pass ? 1 : 0);
+                            const int e_n = last_pass ? 0 : (h + 1 == NH ? (g + 1) * S : g * S + (h + 1) * SB);
 #pragma unroll
                             for (int m = 0; m < MT; ++m) {
-                                accumulate_sub(acc[0][m], raw[DI][g][m], h * SB, pr, pi, chip);
+                                if (PF && m + 1 == MT)
+                                    accumulate_sub(acc[0][m], raw[DI][g][m], h * SB, pr, pi, chip,
+                                                   [&]() { table_phasors(std::integral_constant<int, SB>{}, pr, pi, 0, st_n, e_n); });
+                                else
+                                    accumulate_sub(acc[0][m], raw[DI][g][m], h * SB, pr, pi, chip, []() {});
                                 if (h + 1 == NH) {
 #if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 16))
                                     load_ant(raw[DI][g][m], m, n_rr, n_ri, n_off[g]);
@@ -778,10 +804,6 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
 #endif
                             }
                         }
-                        // carry the group's phasor to the next step
-                        const float t = __builtin_fmaf(car_r[0][g], cwr_k[0], -(car_i[0][g] * cwi_k[0]));
-                        car_i[0][g] = __builtin_fmaf(car_r[0][g], cwi_k[0], car_i[0][g] * cwr_k[0]);
-                        car_r[0][g] = t;
                     }
                 } else {
                     // Several channels on register-resident samples: the chips and phasors of ALL channels of the step are
@@ -797,7 +819,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
                         float pr[KT][S], pi[KT][S], chip[KT][S][L];
 #pragma unroll
                         for (int kk = 0; kk < KT; ++kk) {
-                            group_phasors(pr[kk], pi[kk], kk, g);
+                            table_phasors(std::integral_constant<int, S>{}, pr[kk], pi[kk], kk, c - c0, g * S);
                             get_chips_group(chip[kk], rel, s_rep + kk * RCH);
                         }
 #pragma unroll
@@ -817,12 +839,6 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
 #if !(defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 32))
                             __builtin_amdgcn_sched_barrier(0);
 #endif
-                        }
-#pragma unroll
-                        for (int kk = 0; kk < KT; ++kk) { // carry the group's phasors to the next step
-                            const float t = __builtin_fmaf(car_r[kk][g], cwr_k[kk], -(car_i[kk][g] * cwi_k[kk]));
-                            car_i[kk][g] = __builtin_fmaf(car_r[kk][g], cwi_k[kk], car_i[kk][g] * cwr_k[kk]);
-                            car_r[kk][g] = t;
                         }
                     }
                 }
@@ -852,12 +868,23 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
 #pragma unroll
         for (int kk = 0; kk < KT; ++kk) {
             float v[NV];
+            float q_r = 1.f, q_i = 0.f;
+            if constexpr (VEC == 4) { // Q of this lane (computed here, not at the block's start: nothing of it lives across the step loop)
+                const double thq = __builtin_fma((double)rel0, s_const[kk].step, s_const[kk].phi); // src/algorithms.jl:172 at the lane's first sample
+                sincos_cycles(thq - __builtin_rint(thq), q_r, q_i);
+            }
 #pragma unroll
             for (int l = 0; l < L; ++l)
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    v[(l * MT + m) * 2 + 0] = acc[kk][m][l][0];
-                    v[(l * MT + m) * 2 + 1] = acc[kk][m][l][1];
+                    const float ar = acc[kk][m][l][0], ai = acc[kk][m][l][1];
+                    if constexpr (VEC == 4) { // this lane's share of the carrier: acc * conj(Q)
+                        v[(l * MT + m) * 2 + 0] = __builtin_fmaf(ar, q_r, ai * q_i);
+                        v[(l * MT + m) * 2 + 1] = __builtin_fmaf(ai, q_r, -(ar * q_i));
+                    } else { // scalar-load path: every sample was wiped off with its own exact phasor
+                        v[(l * MT + m) * 2 + 0] = ar;
+                        v[(l * MT + m) * 2 + 1] = ai;
+                    }
                 }
             Butterfly<NV, 32>::run(v, lane);
             // lanes sharing an index hold bit-identical sums

@@ -107,6 +107,9 @@ struct DcLaunch {
     unsigned grid;
     unsigned lds_bytes;
 };
+// carrier table of one segment: [steps <= kUcarSteps][samples of a lane's groups, G * S <= 8][re, im] floats per channel
+constexpr int kUcarSteps = 8;
+constexpr int kUcarFloats = kUcarSteps * 8 * 2;
 #ifndef GAT_DC_SEG_ENTRIES
 #define GAT_DC_SEG_ENTRIES 8192
 #endif
@@ -118,7 +121,7 @@ struct DcLaunch {
 constexpr int dc_segment_steps(int chunk, int kt, int mt)
 {
     const int s = (kt == 1 ? (mt >= 3 ? GAT_DC_SEG_ENTRIES : 4096) : 8192 / kt) / chunk;
-    return s < 2 ? 2 : (s > 8 ? 8 : s);
+    return s < 2 ? 2 : (s > kUcarSteps ? kUcarSteps : s);
 }
 // Floats of LDS per channel for one segment's replica: entry i <-> sample (segment start) + shifts[0] + i, linear, so
 // that the chips of a lane's S consecutive samples are ONE 8-byte-aligned vector read per tap (ds_read2_b64).  Taps at
@@ -132,11 +135,12 @@ constexpr int dc_rep_chan_floats(int chunk, int kt, int mt)
     const int two = 2 * dc_rep_copy_floats(1, chunk, kMaxReplicaSpan);
     return ((one > two ? one : two) + 7) & ~7;
 }
-// dynamic LDS of one dc_kernel workgroup: per-channel constants, reduction scratch, one segment's replica, chip tables
+// dynamic LDS of one dc_kernel workgroup: per-channel constants, reduction scratch, carrier table, one segment's replica,
+// chip tables
 constexpr size_t dc_lds_bytes(int kt, int mt, int code_row_stride, int chunk)
 {
-    return (size_t)kt * 32 + (size_t)kt * 4 * 64 * sizeof(float) + (size_t)kt * dc_rep_chan_floats(chunk, kt, mt) * sizeof(float) +
-           (size_t)kt * code_row_stride;
+    return (size_t)kt * 32 + (size_t)kt * 4 * 64 * sizeof(float) + (size_t)kt * kUcarFloats * sizeof(float) +
+           (size_t)kt * dc_rep_chan_floats(chunk, kt, mt) * sizeof(float) + (size_t)kt * code_row_stride;
 }
 // does an instance of dc_kernel exist for this combination (gat_dc.h: dc_instance)
 bool dc_has_instance(int ant_tile, int taps, int vec, int aw, int kt, int nw = 4, int depth = 1);
@@ -148,7 +152,7 @@ constexpr int kOneWaveSegSteps = 4;
 constexpr int dc_depth_max(int mt, int l, int aw, int kt, int nw) { return nw == 4 && aw == 1 && kt == 1 && mt == 4 && l <= 3 ? 2 : 1; }
 constexpr size_t dc_lds_bytes_one_wave(int rep_chan_floats, int code_row_stride)
 {
-    return 32 + 64 * sizeof(float) + (size_t)rep_chan_floats * sizeof(float) + (size_t)code_row_stride;
+    return 32 + 64 * sizeof(float) + kUcarFloats * sizeof(float) + (size_t)rep_chan_floats * sizeof(float) + (size_t)code_row_stride;
 }
 
 // Arguments of the matrix-core kernel (gat_mfma.hip): 16-antenna tiles, planar f32 input.

@@ -19,11 +19,13 @@ __device__ __forceinline__ void sincos_cycles(double theta, float &c, float &s)
     const double r = __builtin_fma(q, -0.25, theta); // exact: |r| <= 0.125 cycles
     const float a = (float)r * 6.283185307179586f;
     const float a2 = a * a;
-    float sp = __builtin_fmaf(a2, 2.7557319e-6f, -1.9841270e-4f);
+    // (the leading term as multiply + add: an fma with TWO constants keeps one of them in a register, and the compiler
+    // holds that register across every loop of a kernel that calls this function per segment)
+    float sp = a2 * 2.7557319e-6f + -1.9841270e-4f;
     sp = __builtin_fmaf(a2, sp, 8.3333333e-3f);
     sp = __builtin_fmaf(a2, sp, -1.6666667e-1f);
     sp = __builtin_fmaf(a2 * a, sp, a);
-    float cp = __builtin_fmaf(a2, 2.4801587e-5f, -1.3888889e-3f);
+    float cp = a2 * 2.4801587e-5f + -1.3888889e-3f;
     cp = __builtin_fmaf(a2, cp, 4.1666667e-2f);
     cp = __builtin_fmaf(a2, cp, -0.5f);
     cp = __builtin_fmaf(a2, cp, 1.0f);
