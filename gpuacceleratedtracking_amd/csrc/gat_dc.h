@@ -243,15 +243,18 @@ __device__ __forceinline__ void completion_flag(unsigned *done_counter, unsigned
 #ifndef GAT_DC_MINW
 #define GAT_DC_MINW 3
 #endif
-#ifndef GAT_DC_MINW_BIG
-#define GAT_DC_MINW_BIG 2
-#endif
-#ifndef GAT_DC_MINW_SMALL
-#define GAT_DC_MINW_SMALL 4
-#endif
-constexpr int dc_min_waves(int mt, int l, int kt, int d = 1)
+// Round 4: the carrier table took the per-lane phasor state out of the step loop and the opaque producer index three more
+// registers out of every instance; the small instances (<= 24 accumulator registers, one sample set) now fit four waves
+// per SIMD and the channel-looping ones two (<= 256 registers, no AGPRs) without spills, so they are asked to.  Not the
+// int8 instances: eight samples per group put their channel-looping forms 13-92 registers over 256 (they keep the AGPR
+// copies and one wave per SIMD; by default int8 samples of such shapes run on the split-bf16 matrix kernel anyway).
+constexpr int dc_min_waves(int mt, int l, int kt, int d, int fmt)
 {
-    return 2 * mt * l * kt <= 40 ? (d == 1 && 2 * mt * l * kt >= 40 ? GAT_DC_MINW : (d == 1 && 2 * mt * l * kt <= 24 ? GAT_DC_MINW_SMALL : 3)) : GAT_DC_MINW_BIG;
+    const int accs = 2 * mt * l * kt;
+    const bool i8 = fmt == GAT_LAYOUT_INTERLEAVED_I8;
+    if (accs > 40) return i8 ? 1 : 2;
+    if (d == 1 && accs >= 40) return GAT_DC_MINW;
+    return d == 1 && accs <= 24 && !i8 ? 4 : 3;
 }
 
 // Diagnostic builds (-DGAT_DC_LAT_CUT=n, scripts/r03_latency_cuts.sh): the kernel ends at cut point n -- 1 entry, 2 block
@@ -271,7 +274,7 @@ constexpr int dc_min_waves(int mt, int l, int kt, int d = 1)
 #endif
 
 template <int MT, int L, int VEC, int FMT, int AW, int KT, bool KEEP, int NW, int D>
-__global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel(const DcArgs a)
+__global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D, FMT)) dc_kernel(const DcArgs a)
 {
     // NW = 4 waves per workgroup, or 1: short blocks in a long stream (a few steps per block) spend their time in the
     // per-block set-up, which all four waves of a workgroup repeat, and at its three barriers; a one-wave workgroup
@@ -336,7 +339,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
     // replica producer role of this thread: channel slot gk (wave-uniform), entries gr, gr + RPC, gr + 2 RPC, ... of
     // every segment (consecutive lanes store consecutive floats); entry i <-> sample (segment start) + shift0 + i
     const int gk = KT == 1 ? 0 : uni(tid / RPC);
-    const int gr = tid % RPC;
+    const int gr_t = tid % RPC;
 
     const int c_begin = split * a.chunks_per_split;
     const int c_end = min(c_begin + a.chunks_per_split, a.total_chunks);
@@ -489,21 +492,22 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
 
         // ---- replica producer: walk constants of this thread's channel ----------------------------------------
         // one producer step advances RPC samples (the thread's next entry)
-        unsigned w_rate_lo, w_rate_hi, w_margin;
-        bool w_exact;
+        // (four wave-uniform words live across the step loop; everything else the producers need is derived from them at
+        // each segment start, behind an opaque copy -- the compiler otherwise hoists the derived constants out of the
+        // segment loop and holds them, spilled into vector-register lanes, across the step loop)
+        unsigned w_r1lo, w_r1hi, w_margin, w_flags; // 32.32 chips per sample; margin; bit 0: exact only
         const bool g_valid = (valid_mask >> gk) & 1u;
         {
             const ChanConst cc = s_const[gk];
             const double span = __builtin_fabs(cc.tau) + cc.ratio * (double)(N + a.max_abs_shift) + 1.0;
             // a producer walks RPC samples per step, at most one segment (+ overshoot) away from its anchor
             const ChipWalkConst wc = chip_walk_setup(cc.ratio, span, SEG * CHUNK + a.rep_span + 5 * RPC, RPC, Lc);
-            const unsigned long long r4 = uni(wc.rate) * (unsigned long long)RPC;
-            w_rate_lo = (unsigned)r4;
-            w_rate_hi = (unsigned)(r4 >> 32);
+            const unsigned long long r1 = uni(wc.rate);
+            w_r1lo = (unsigned)r1;
+            w_r1hi = (unsigned)(r1 >> 32);
             w_margin = uni(wc.margin);
-            w_exact = uni(wc.exact_only) != 0;
+            w_flags = uni(wc.exact_only) != 0 ? 1u : 0u;
         }
-
 
         f32x2 acc[KT][MT][L]; // (re, im)
 #pragma unroll
@@ -640,10 +644,21 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D)) dc_kernel
         // one base register + immediate offsets, and only the last, partial batch of a run checks its bound)
         auto fill_impl = [&](auto two_c, int c0, int seg_cnt) {
             constexpr bool TWO = decltype(two_c)::value;
+            // (opaque copy of the thread's producer index: addresses and sample indices derived from it are loop-invariant,
+            // and hoisted out of the segment loop they sat in registers across the step loop -- three in every instance,
+            // a wave per SIMD in 24 of the 141 planar instances)
+            int gr = gr_t;
+            asm volatile("" : "+v"(gr));
             float *rep = s_rep + gk * RCH + gr;
             float *rep1 = rep + a.rep_copy_stride - 1;            // copy[i] = entry i + 1
             const int8_t *tab = s_code + (size_t)gk * a.code_row_stride;
             const int run = (seg_cnt + RPC - 1) / RPC;            // entries per producer thread (wave-uniform)
+            unsigned r1lo = w_r1lo, r1hi = w_r1hi, flags = w_flags;
+            asm volatile("" : "+v"(r1lo), "+v"(r1hi), "+v"(flags));
+            r1lo = uni(r1lo), r1hi = uni(r1hi), flags = uni(flags);
+            const unsigned long long rp = ((unsigned long long)r1hi << 32 | r1lo) * (unsigned long long)RPC; // one producer step
+            const unsigned w_rate_lo = (unsigned)rp, w_rate_hi = (unsigned)(rp >> 32);
+            const bool w_exact = (flags & 1u) != 0;
             const int x0 = c0 * CHUNK + shift0 + gr;
             const double ratio = s_const[gk].ratio, tau = s_const[gk].tau;
             // exact anchor (src/algorithms.jl:179-182)
