@@ -1,8 +1,9 @@
 /* gat_latency.c -- single-block latency from native code over the reference's sweep grid.
  *
  * The reference times ONE 1 ms block per call: @benchmark CUDA.@sync kernel_algorithm(...) (src/benchmarks.jl:120-146),
- * grid scripts/run_benchmarks_gpsl1.jl:5-18 (GPS L1: N = 2^11 .. 2^18, M in {1, 4}, L in {3, 7}; prn 1, 1500 Hz,
- * phases 0, half-chip spacing; BenchmarkTools "Minimum").  This is what a Julia harness calling the shim would see,
+ * grids scripts/run_benchmarks_gpsl1.jl:5-18 (GPS L1: N = 2^11 .. 2^18, M in {1, 4}, L in {3, 7}) and
+ * scripts/run_benchmarks_gpsl5.jl:5-18 (GPS L5: N = 2^15 .. 2^18, M in {1, 4}, L = 3); prn 1, 1500 Hz, phases 0,
+ * half-chip spacing; BenchmarkTools "Minimum".  This is what a Julia harness calling the shim would see,
  * without a Python / ctypes layer in between:
  *   host   : gat_downconvert_and_correlate (host parameters: validation + 40-byte upload + launch) + gat_sync
  *   dev    : gat_downconvert_and_correlate_dev (parameters already on the device) + gat_sync
@@ -41,19 +42,22 @@ int main(int argc, char **argv)
     gat_ctx *ctx = NULL;
     const int reps = argc > 1 ? atoi(argv[1]) : 2000;
     CHECK(gat_create(0, GAT_OWN_STREAM, &ctx));
-    int32_t lc = 0;
-    double fc = 0.0;
-    CHECK(gat_gen_codes("GPSL1", 0, NULL, &lc, &fc));
-    int8_t *codes = malloc((size_t)lc * 32);
-    CHECK(gat_gen_codes("GPSL1", 32, codes, &lc, &fc));
-    CHECK(gat_set_codes(ctx, codes, lc, 32));
     double *t = malloc(sizeof(double) * (size_t)reps), *tc = malloc(sizeof(double) * (size_t)reps);
     const int Ms[2] = {1, 4}, Ls[2] = {3, 7};
-    printf("# GPSL1, one 1 ms block per call, prn 1, 1500 Hz (src/benchmarks.jl:96-99); %d calls per point; microseconds\n", reps);
-    printf("# %8s %2s %2s | %-15s | %-15s | %-15s | %s | %s\n", "N", "M", "L", "host min/med", "dev min/med", "graph min/med", "enqueue-only per call", "call med");
-    for (int e = 11; e <= 18; ++e)
+    /* the two committed grids of the reference */
+    const struct { const char *system; int e0, e1, nl; } grids[2] = {{"GPSL1", 11, 18, 2}, {"GPSL5", 15, 18, 1}};
+    printf("# one 1 ms block per call, prn 1, 1500 Hz (src/benchmarks.jl:96-99); %d calls per point; microseconds; %s\n", reps, gat_version());
+    printf("# %-5s %8s %2s %2s | %-15s | %-15s | %-15s | %s | %s\n", "GNSS", "N", "M", "L", "host min/med", "dev min/med", "graph min/med", "enqueue-only per call", "call med");
+    for (int gi = 0; gi < 2; ++gi) {
+    int32_t lc = 0;
+    double fc = 0.0;
+    CHECK(gat_gen_codes(grids[gi].system, 0, NULL, &lc, &fc));
+    int8_t *codes = malloc((size_t)lc * 32);
+    CHECK(gat_gen_codes(grids[gi].system, 32, codes, &lc, &fc));
+    CHECK(gat_set_codes(ctx, codes, lc, 32));
+    for (int e = grids[gi].e0; e <= grids[gi].e1; ++e)
         for (int mi = 0; mi < 2; ++mi)
-            for (int li = 0; li < 2; ++li) {
+            for (int li = 0; li < grids[gi].nl; ++li) {
                 const int N = 1 << e, M = Ms[mi], L = Ls[li];
                 const double fs = N / 1e-3;
                 int32_t shifts[7];
@@ -94,14 +98,15 @@ int main(int argc, char **argv)
                 CHECK(gat_sync(ctx));
                 const double per = (now_us() - t0) / reps;
                 CHECK(gat_memcpy_d2h(ctx, h, o_re, sizeof(float) * M * L));
-                printf("  %8d %2d %2d | %6.2f / %6.2f | %6.2f / %6.2f | %6.2f / %6.2f | %6.2f | %5.2f   (prompt %.0f)\n", N, M, L, res[0][0], res[0][1],
+                printf("  %-5s %8d %2d %2d | %6.2f / %6.2f | %6.2f / %6.2f | %6.2f / %6.2f | %6.2f | %5.2f   (prompt %.0f)\n", grids[gi].system, N, M, L, res[0][0], res[0][1],
                        res[1][0], res[1][1], res[2][0], res[2][1], per, call_med, h[(L / 2) * M]);
                 fflush(stdout);
                 gat_free(ctx, re); gat_free(ctx, im); gat_free(ctx, prm_dev); gat_free(ctx, o_re); gat_free(ctx, o_im);
             }
+    free(codes);
+    }
     free(t);
     free(tc);
-    free(codes);
     gat_destroy(ctx);
     return 0;
 }

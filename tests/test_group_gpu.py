@@ -198,9 +198,10 @@ def test_native_latency_example_and_completion_flag(gat):
     r = subprocess.run([exe, "60"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     rows = [ln for ln in r.stdout.splitlines() if ln.strip() and not ln.startswith("#")]
-    assert len(rows) == 8 * 2 * 2, r.stdout
+    assert len(rows) == 8 * 2 * 2 + 4 * 2 * 1, r.stdout  # the reference's GPS L1 grid and its GPS L5 grid
+    assert sum(ln.split()[0] == "GPSL5" for ln in rows) == 8
     for ln in rows:
-        n = int(ln.split()[0])
+        n = int(ln.split()[1])
         m = re.search(r"\(prompt (\d+)\)", ln)
         assert m and int(m.group(1)) == n, ln
         dev_min = float(ln.split("|")[2].split("/")[0])
