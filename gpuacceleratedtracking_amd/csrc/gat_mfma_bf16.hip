@@ -188,6 +188,9 @@ __device__ __forceinline__ void mfma_slice(f32x16 (&acc)[RT == 1 ? 2 : RT], Frag
 template <int J, int RT, bool X1>
 __device__ __forceinline__ void mfma_apply(f32x16 (&acc)[RT == 1 ? 2 : RT], FragSet<RT, X1> &cur)
 {
+#if defined(GAT_ABLATE) && (GAT_ABLATE & 128) // diagnostic (results wrong): the arithmetic of two k-slices out of three -- what a
+    if constexpr (!X1 && J % 3 == 2) return;   // 2-term split of the SAMPLE operand (5 products, 3 samples per MFMA) would issue
+#endif
     u32x4 w = cur.w;
 #if defined(GAT_ABLATE) && (GAT_ABLATE & 64)
     if constexpr (!X1) w = u32x4{cur.wl[0], cur.wl[1], cur.wl[0], cur.wl[1]};
@@ -474,8 +477,14 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
                     const unsigned fb = __float_as_uint(v);
                     xb[plane * XS + rel] = u32x2{GAT_PERM(fb, fb, 0x03020302u), fb >> 16};
                 } else {
+#if defined(GAT_ABLATE) && (GAT_ABLATE & 128) // diagnostic: the producers' share of a 2-term sample split (no lo term)
+                    const unsigned fb = __float_as_uint(v);
+                    const float r = v - __uint_as_float(fb & 0xffff0000u);
+                    xb[plane * XS + rel] = u32x2{GAT_PERM(__float_as_uint(r), fb, 0x07060302u), 0u};
+#else
                     const Split3 sp = split3(v);
                     xb[plane * XS + rel] = u32x2{GAT_PERM(sp.r, sp.v, 0x07060302u), GAT_PERM(sp.r2, sp.r2, 0x03020302u)};
+#endif
                 }
             };
             if constexpr (PLANAR) {
