@@ -69,6 +69,7 @@ struct gat_ctx {
     int one_wave_seg = kOneWaveSegSteps;      // option dc_ow_seg: steps per replica segment of a one-wave workgroup
     int max_depth = 2;                        // option dc_depth: cap of the sample prefetch depth (register sets per wave)
     int keep_l2 = -1;                         // option dc_keep_l2: cache policy of the sample loads (-1: by rule)
+    int align_head = 1;                       // option dc_align: line-aligned virtual block starts where blocks start off a line
     int mc_mode = 1; // GAT_MC_* kernel selection (gat_set_matrix_core)
     std::string err;
     gat_launch_info last{};
@@ -454,27 +455,39 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         dc_has_instance(MT, max_taps, vec, 1, 1, 1))
         nw = 1;
     const long long chunk = dc_chunk(vec, fmt, aw, nw);
-    const long long chunks = (N + chunk - 1) / chunk;
     // Workgroups per CU the split aims for: 8 -- except for the channel-looping instances (KT >= 2: 170-250 registers,
     // two workgroups resident per CU), where a finer split only adds partial sums, a second launch and workgroup starts
     // (configs[3] shard, 512 tiles: 2 / 4 / 8 per CU = 0.667 / 0.675 / 0.687 ms, profiles/r03/r03a_c4_split.txt).
     const int per_cu = c->wgs_per_cu > 0 ? c->wgs_per_cu : (kt >= 2 ? 2 : 8);
     const long long target = (long long)per_cu * c->num_cus * (nw == 1 ? 4 : 1);
-    long long splits = std::max<long long>(1, (target + groups - 1) / groups);
-    splits = std::min(splits, chunks);
-    // tiny blocks (latency regime): a second launch costs more than a few serial steps
-    if (chunks <= 4 && !(flags & GAT_FLAG_ATOMIC)) splits = 1;
-    const long long cps = (chunks + splits - 1) / splits;
-    splits = (chunks + cps - 1) / cps;
+    long long chunks = 0, splits = 1, cps = 1, bpw = 1;
+    auto plan = [&](long long slack) { // slack: virtual samples in front of a block (line alignment, below)
+        chunks = (N + slack + chunk - 1) / chunk;
+        splits = std::max<long long>(1, (target + groups - 1) / groups);
+        splits = std::min(splits, chunks);
+        // tiny blocks (latency regime): a second launch costs more than a few serial steps
+        if (chunks <= 4 && !(flags & GAT_FLAG_ATOMIC)) splits = 1;
+        cps = (chunks + splits - 1) / splits;
+        splits = (chunks + cps - 1) / cps;
+    };
+    plan(0);
     // short blocks in a long stream: one workgroup loops over several consecutive blocks (chip table, channel set-up
     // and the workgroup launch are paid once) while the chip stays filled 16 workgroups deep per CU
-    long long bpw = 1;
     if (splits == 1 && c->max_bpw > 1) {
         const long long by_fill = std::max<long long>(1, groups / (16ll * c->num_cus * (nw == 1 ? 4 : 1)));
         const long long by_len = std::max<long long>(1, (nw == 1 ? 64 : 16) / chunks);
         bpw = std::min<long long>(std::min(by_fill, by_len), c->max_bpw);
         if (c->force_bpw > 0) bpw = std::min<long long>(c->force_bpw, B); // A/B runs: option dc_bpw_force
     }
+    // Line alignment (gat_dc.h): where a block of some antenna may start off a 128-byte line -- the base pointer or a stride
+    // that is applied is no multiple of 128 bytes (N = 50 000 floats: every other block) -- workgroups walk each block from
+    // the line its first sample lies in: up to 112 bytes of virtual samples in front of the block, hence the slack in the
+    // chunk count.  Four-wave workgroups that own one block each (several short blocks per workgroup keep their walk across
+    // block boundaries instead); option dc_align = 0 turns it off for A/B runs.
+    const bool align_head = c->align_head && vec == 4 && nw == 4 && bpw == 1 &&
+                            ((reinterpret_cast<uintptr_t>(sig->re) & 127u) != 0 || (B > 1 && (sig->block_stride * plane_bytes) % 128 != 0) ||
+                             (M > MT && (sig->ant_stride * plane_bytes * MT) % 128 != 0) || (sig->chan_stride * plane_bytes) % 128 != 0);
+    if (align_head) plan(112 / plane_bytes);
     const long long BG = (B + bpw - 1) / bpw;
     const long long tiles = BG * AG * splits;
     const long long grid_wgs = ((tiles + 7) / 8) * 8 * KG;
@@ -532,6 +545,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     a.flags = flags;
     a.keep_l2 = c->keep_l2 >= 0 ? c->keep_l2 : (KG > 1 && sig->chan_stride == 0);
     a.n_vec = (int)(vec == 4 ? N - N % spv : N);
+    a.align_head = align_head ? 1 : 0;
     // a block length that is no multiple of the load group: the N % spv samples behind the last whole group are added
     // by dc_tail_kernel, one more (tiny) launch behind the vector kernel and its second stage
     const bool tail = vec == 4 && N % spv != 0;
@@ -738,7 +752,7 @@ int32_t graph_replay_or_record(gat_ctx *c, MakeKey make_key, Enqueue enqueue)
 void key_put_ctx(std::vector<unsigned char> &key, const gat_ctx *c)
 {
     key_put(key, c->mc_mode); key_put(key, c->max_aw); key_put(key, c->max_kt); key_put(key, c->max_bpw); key_put(key, c->force_bpw);
-    key_put(key, c->wgs_per_cu); key_put(key, c->max_depth); key_put(key, c->one_wave); key_put(key, c->keep_l2);
+    key_put(key, c->wgs_per_cu); key_put(key, c->max_depth); key_put(key, c->one_wave); key_put(key, c->keep_l2); key_put(key, c->align_head);
     key_put(key, c->d_codes); key_put(key, c->d_code_bits); key_put(key, c->Lc); key_put(key, c->P);
     key_put(key, c->d_partial); key_put(key, c->partial_bytes);
 }
@@ -766,6 +780,7 @@ constexpr OptionDesc kOptions[] = {
     {"dc_ow_seg", 1, kUcarSteps},    // steps per replica segment of a one-wave workgroup
     {"dc_depth", 1, 2},              // cap of the sample prefetch depth (register sets per wave)
     {"dc_keep_l2", -1, 1},           // sample loads: -1 by rule (plain when channel groups share a tile through L2), 0 non-temporal, 1 plain
+    {"dc_align", 0, 1},              // blocks walked from the 128-byte line their first sample lies in (1) or from the sample itself (0)
 };
 
 int32_t set_option(gat_ctx *c, const char *name, long long v)
@@ -788,6 +803,7 @@ int32_t set_option(gat_ctx *c, const char *name, long long v)
     else if (n == "dc_ow_seg") c->one_wave_seg = (int)v;
     else if (n == "dc_depth") c->max_depth = (int)v;
     else if (n == "dc_keep_l2") c->keep_l2 = (int)v;
+    else if (n == "dc_align") c->align_head = (int)v;
     return GAT_OK;
 }
 

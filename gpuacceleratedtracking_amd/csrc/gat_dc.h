@@ -380,8 +380,24 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D, FMT)) dc_k
         // breaks the step into many basic blocks (+ 50 registers).
         const size_t base = (size_t)b * a.block_stride + (size_t)kg * a.chan_stride /* != 0 only with KT == 1 */ +
                             (size_t)((ag * AW + at_w) * MT) * a.ant_stride;
-        const char *const p_re = static_cast<const char *>(a.re) + base * EB;
-        const char *const p_im = static_cast<const char *>(FMT == GAT_LAYOUT_PLANAR ? a.im : a.re) + base * EB;
+        // Line alignment: a wave-instruction fetches 1 KiB of contiguous memory per plane; when the block does not start on a
+        // 128-byte line (N = 50 000 floats: every other block starts 64 bytes into one) it straddles nine lines instead of
+        // eight and the line it shares with its neighbour in time is fetched twice (configs[3] shard: traffic 1.05 x the
+        // algorithmic bytes, 2 % of the time: profiles/r04/r04a_block_alignment_probe.txt).  The workgroup therefore walks
+        // the block from a VIRTUAL start `head_b` bytes ahead of it, on the line's boundary: lane offsets, replica entries
+        // and the carrier table are all in virtual samples, lanes in front of the real start read zeros (range check).
+        // head_b is a multiple of 16 (whole groups); launch-uniform switch (the host turns it on where a stride or the base
+        // is not a multiple of 128 bytes, and then gives every block one chunk of slack and one block per workgroup).
+        unsigned head_b = 0;
+        if constexpr (VEC == 4) {
+            if (a.align_head) {
+                const size_t base0 = (size_t)b * a.block_stride + (size_t)kg * a.chan_stride + (size_t)(ag * AW * MT) * a.ant_stride;
+                head_b = uni((unsigned)(reinterpret_cast<size_t>(a.re) + base0 * EB) & 127u); // the tile's first antenna
+            }
+        }
+        const int head_s = (int)(head_b / (unsigned)EB); // virtual sample v <-> sample v - head_s of the block
+        const char *const p_re = static_cast<const char *>(a.re) + base * EB - head_b;
+        const char *const p_im = static_cast<const char *>(FMT == GAT_LAYOUT_PLANAR ? a.im : a.re) + base * EB - head_b;
         const size_t ant_bytes = (size_t)a.ant_stride * EB;
         const size_t blk_bytes = (size_t)a.block_stride * EB;
         // whole 16-byte groups only: of a block length that is no multiple of the group size S the vector path covers the
@@ -391,10 +407,12 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D, FMT)) dc_k
         // the step loop its scalar state stays live across the loop (+ 4 registers everywhere, the one-wave three-tap
         // instance 6 -> 5 waves per SIMD), ahead of the loop the accumulators become live on two paths (+ 6-18).
         const int blk_len = (VEC == 4 ? a.n_vec : N) * EB; // bytes of one antenna's block that this kernel covers
-        const unsigned tile_len = (unsigned)((MT - 1) * ant_bytes) + (unsigned)blk_len; // the descriptors' num_records (host: < 2^31)
+        const unsigned v_end = (unsigned)blk_len + head_b; // virtual byte offset of the block's end
+        const unsigned tile_len = (unsigned)((MT - 1) * ant_bytes) + v_end; // the descriptors' num_records (host: < 2^31)
         constexpr unsigned kNoRecord = 0x80000000u;
         auto plane_rsrc = [&](const char *p) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p), 0, (int)tile_len, 0x00020000); };
-        auto lane_offset = [&](unsigned off) { return off < (unsigned)blk_len ? off : kNoRecord; };
+        // (one unsigned compare covers both ends: offsets in front of the real start wrap to huge values)
+        auto lane_offset = [&](unsigned off) { return off - head_b < (unsigned)blk_len ? off : kNoRecord; };
 
         // 16-byte loads of antenna m's group at byte offset `off` of the block that starts at (bre, bim) (KEEP: plain
         // loads that stay in L2 for the other channel groups, otherwise non-temporal: aux bit 1)
@@ -659,7 +677,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D, FMT)) dc_k
             const unsigned long long rp = ((unsigned long long)r1hi << 32 | r1lo) * (unsigned long long)RPC; // one producer step
             const unsigned w_rate_lo = (unsigned)rp, w_rate_hi = (unsigned)(rp >> 32);
             const bool w_exact = (flags & 1u) != 0;
-            const int x0 = c0 * CHUNK + shift0 + gr;
+            const int x0 = c0 * CHUNK - head_s + shift0 + gr;
             const double ratio = s_const[gk].ratio, tau = s_const[gk].tau;
             // exact anchor (src/algorithms.jl:179-182)
             const double p0 = code_phase(ratio, tau, x0);
@@ -738,7 +756,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D, FMT)) dc_k
                 asm volatile("" : "+v"(t_));
                 const int e = t_ % (G * S), st = (t_ / (G * S)) % kUcarSteps, kk = t_ / ((G * S) * kUcarSteps);
                 if (kk < KT && st < c1 - c0) {
-                const int n = (c0 + st) * CHUNK + (e / S) * GSTRIDE + (e % S); // sample of lane 0 (rel0 = 0)
+                const int n = (c0 + st) * CHUNK - head_s + (e / S) * GSTRIDE + (e % S); // sample of lane 0 (rel0 = 0)
                 const double th = (double)n * s_const[kk].step;
                 float cr, ci;
                 sincos_cycles(th - __builtin_rint(th), cr, ci);
@@ -768,7 +786,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D, FMT)) dc_k
                 const bool hop = !more && next_block; // wave-uniform
                 const char *const n_re = hop ? p_re + blk_bytes : p_re, *const n_im = hop ? p_im + blk_bytes : p_im;
                 const unsigned next_off = more ? (unsigned)((c + D) * CHUNK + rel0) * EB
-                                          : (hop ? (unsigned)((c_begin + DI) * CHUNK + rel0) * EB : (unsigned)blk_len);
+                                          : (hop ? (unsigned)((c_begin + DI) * CHUNK + rel0) * EB : v_end);
                 const unsigned next_g = more || hop ? (unsigned)(GSTRIDE * EB) : 0u;
                 const __amdgpu_buffer_rsrc_t n_rr = plane_rsrc(n_re), n_ri = plane_rsrc(n_im);
                 unsigned n_off[G];

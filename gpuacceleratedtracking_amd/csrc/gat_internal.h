@@ -69,6 +69,7 @@ struct DcArgs {
     int rep_chan_floats;   // one-wave workgroups: floats of LDS per channel replica (sized for this launch's taps)
     int keep_l2;           // 1: plain loads (several channel groups share the tile through L2), 0: non-temporal
     int n_vec;             // samples of a block the vector path covers: N - N % (samples per 16-byte load); N for scalar loads
+    int align_head;        // 1: workgroups walk a block from the 128-byte line its first sample lies in (gat_dc.h)
     unsigned flags;
     int shifts[kMaxTapsPerLaunch];    // ascending
     int tap_off[kMaxTapsPerLaunch];   // float offset of tap l's chips from the lane's group base: even (8-byte aligned reads)

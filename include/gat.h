@@ -341,7 +341,7 @@ GAT_API int32_t gat_set_vector_tiling(gat_ctx *ctx, int32_t max_antenna_tiles, i
  * result beyond summation order.  The library reads NO environment variable that selects kernels or geometry (development
  * builds, -DGAT_DEV, map GAT_<NAME> onto these).  Names: "sync_flag_wgs" (largest launch in workgroups that carries the
  * completion flag; 0: never), "max_ant_tile", "dc_aw", "dc_kt", "dc_bpw" (the caps of gat_set_vector_tiling),
- * "dc_bpw_force", "dc_wgs_per_cu", "dc_one_wave", "dc_one_wave_min", "dc_ow_seg", "dc_depth", "dc_keep_l2".
+ * "dc_bpw_force", "dc_wgs_per_cu", "dc_one_wave", "dc_one_wave_min", "dc_ow_seg", "dc_depth", "dc_keep_l2", "dc_align".
  * GAT_ERR_ARG: unknown name; GAT_ERR_RANGE: value outside the option's range. */
 GAT_API int32_t gat_set_option(gat_ctx *ctx, const char *name, int64_t value);
 

@@ -396,3 +396,74 @@ def test_ragged_block_length_runs_the_vector_kernel(gat, N, M, layout):
         times[name] = op.ctx.timer_stop() / 40
     print(f"N={N} {layout} x {big} blocks: ragged {times['ragged'] * 1e3:.1f} us, padded {times['padded'] * 1e3:.1f} us per launch")
     assert times["ragged"] <= 1.3 * times["padded"], times
+
+
+ALIGN_SHAPES = [
+    # system, N, M, L, K, B -- block lengths whose byte size is no multiple of 128: blocks start 16 .. 112 bytes into a line
+    ("GPSL1", 5004, 4, 3, 1, 9),     # planar: 20 016 B per block -> the start walks through all eight 16-byte offsets
+    ("GPSL1", 5000, 16, 3, 4, 3),    # configs[3] shard shape (shortened): AW = 4, KT = 4, every other block 64 B off
+    ("GPSL5", 6020, 4, 5, 3, 5),     # configs[2] family, three channel groups sharing a tile
+    ("GPSL1", 2052, 4, 3, 1, 40),    # two steps per block, 40 blocks
+    ("GPSL1", 24580, 4, 3, 1, 1),    # one block, split over workgroups: the base pointer itself is moved off the line
+]
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2, 3], ids=["planar", "interleaved", "i16", "i8"])
+@pytest.mark.parametrize("shape", ALIGN_SHAPES, ids=[f"{s[0]}-N{s[1]}-M{s[2]}-K{s[4]}-B{s[5]}" for s in ALIGN_SHAPES])
+def test_blocks_that_start_off_a_cache_line(gat, shape, layout):
+    """Where a block may start off a 128-byte line the workgroups walk it from the line's boundary (gat_dc.h: virtual block
+    start, lanes in front of the real start read zeros): against the oracle, for every 16-byte offset of a block start within
+    a line, with the walk from the sample itself (option dc_align = 0) beside it -- same chips, same samples, only the
+    lane a sample lands in differs, so the two agree to summation order."""
+    import torch
+    g = gat
+    system, N, M, L, K, B = shape
+    group = {0: 4, 1: 2, 2: 4, 3: 8}[layout]
+    if N % group:
+        N -= N % group
+    case = make_case(zlib.crc32(repr(shape).encode()) + layout, system=system, N=N, M=M, L=L, K=K, B=B)
+    if layout >= 2:
+        s = 100.0 if layout == 2 else 20.0
+        case["re"] = np.rint(case["re"] * s).astype(np.float32)
+        case["im"] = np.rint(case["im"] * s).astype(np.float32)
+    ref = oracle_result(case)
+    sysobj = g.GNSSDICT[system](use_gpu=True)
+    prm = g.make_params(case["prm"]["prn0"], case["prm"]["code_freq_hz"], case["prm"]["carrier_freq_hz"],
+                        case["prm"]["code_phase_chips"], case["prm"]["carrier_phase_cycles"])
+    dev = torch.device("cuda", torch.cuda.current_device())
+    lay = [g.GAT_LAYOUT_PLANAR, g.GAT_LAYOUT_INTERLEAVED, g.GAT_LAYOUT_INTERLEAVED_I16, g.GAT_LAYOUT_INTERLEAVED_I8][layout]
+    sample_bytes = [4, 8, 4, 2][layout]
+    outs = {}
+    for lead in (0, 16 // sample_bytes * 3):  # the stream itself starts on a line / 48 bytes into one
+        re = torch.zeros((M, lead + B * N), device=dev)
+        im = torch.zeros((M, lead + B * N), device=dev)
+        re[:, lead:] = torch.from_numpy(case["re"]).to(dev)
+        im[:, lead:] = torch.from_numpy(case["im"]).to(dev)
+        if layout == 0:
+            bufs = (re, im)
+            ptrs = (re.data_ptr() + lead * 4, im.data_ptr() + lead * 4)
+        else:
+            x = torch.stack([re, im], dim=-1)
+            x = (x if layout == 1 else x.to(torch.int16 if layout == 2 else torch.int8)).contiguous()
+            bufs = (x,)
+            ptrs = (x.data_ptr() + lead * sample_bytes, None)
+        desc = g._lib.SignalDesc(ptrs[0], ptrs[1], lay, M, N, lead + B * N, N, 0)
+        for align in (1, 0):
+            ctx = g.Context(torch.cuda.current_device())
+            try:
+                ctx.set_matrix_core(g.GAT_MC_VECTOR)
+                ctx.set_option("dc_align", align)
+                op = g.StreamCorrelator(sysobj, N, M, B, K, case["shifts"], case["fs"], ctx=ctx)
+                op.set_params(prm)
+                op.launch(desc)
+                got = op.result()
+                info = ctx.last_launch_info()
+                assert info["vec"] == 4, info
+                check_close(got, ref, what=f"{shape} layout {layout} lead {lead} align {align} {info}")
+                outs[lead, align] = got
+            finally:
+                ctx.close()
+        del bufs
+    scale = np.abs(ref).max(axis=(2, 3), keepdims=True)
+    for key, got in outs.items():
+        assert np.max(np.abs(got - outs[0, 1]) / scale) < 2e-6, key
