@@ -43,11 +43,11 @@ def main(path):
         entries.append({"workload_key": key, "kernel": kernel.strip(), "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
                         "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "ratio": round(hbm / alg, 4)})
     out = {"how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python bench.py --steps 6 --warmup 40 "
-                  "--settle 64 [shape flags]` (scripts/r03_pmc.sh, driven by scripts/r03_profile_configs.sh -> "
+                  "--settle 64 [shape flags]` (scripts/r0N_pmc.sh, driven by scripts/r0N_profile_configs.sh of the round -> "
                   + os.path.basename(path) + "); per-dispatch counter values of the correlator kernel named in `kernel`, mean of the "
                   "last four dispatches; FETCH_SIZE (KB) doubled as MI355X_MICROARCH.md prescribes for gfx950 16-B/lane streaming "
                   "reads, WRITE_SIZE (KB) as reported (scripts/make_pmc_traffic.py)",
-           "source": "profiles/r03/" + os.path.basename(path),
+           "source": os.path.relpath(os.path.abspath(path), os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")),
            "entries": entries}
     json.dump(out, open(os.path.join(os.path.dirname(__file__), "..", "profiles", "pmc_traffic.json"), "w"), indent=1)
     for e in entries:
