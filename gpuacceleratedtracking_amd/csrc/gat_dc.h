@@ -194,7 +194,7 @@ struct SampleIO {
 // The compiler sinks every kernel-argument load to its first use, so a kernel with several hundred bytes of arguments
 // pays one scalar-cache miss per 64-byte line, one after the other, each a full trip to the runtime's argument buffer
 // (set-up, replica, steps, tail: in a single-block call these serial trips were a third of the kernel's time,
-// scripts/r03_latency_cuts.sh; HIP_FORCE_DEV_KERNARG=1 changes nothing).  Touching every line at the kernel's first
+// scripts/history/r03/r03_latency_cuts.sh; HIP_FORCE_DEV_KERNARG=1 changes nothing).  Touching every line at the kernel's first
 // instruction overlaps them into one.
 template <int BYTES>
 __device__ __forceinline__ void kernarg_prefetch()
@@ -209,7 +209,7 @@ __device__ __forceinline__ void kernarg_prefetch()
 
 // Completion flag (latency regime): the last workgroup of a launch to get here stores the call's sequence number into
 // pinned host memory, where gat_sync spins on it -- a kernel's end reaches the host ~5 us sooner that way than through
-// hipStreamSynchronize (scripts/sync_probe.hip: 7.0 vs 11.7 us for an empty kernel).  Called by every thread of every
+// hipStreamSynchronize (scripts/probes/sync_probe.hip: 7.0 vs 11.7 us for an empty kernel).  Called by every thread of every
 // workgroup that did work, after its result stores.
 __device__ __forceinline__ void completion_flag(unsigned *done_counter, unsigned *host_flag, unsigned seq, unsigned total_wgs)
 {
@@ -257,7 +257,7 @@ constexpr int dc_min_waves(int mt, int l, int kt, int d, int fmt)
     return d == 1 && accs <= 24 && !i8 ? 4 : 3;
 }
 
-// Diagnostic builds (-DGAT_DC_LAT_CUT=n, scripts/r03_latency_cuts.sh): the kernel ends at cut point n -- 1 entry, 2 block
+// Diagnostic builds (-DGAT_DC_LAT_CUT=n, scripts/history/r03/r03_latency_cuts.sh): the kernel ends at cut point n -- 1 entry, 2 block
 // set-up + chip tables, 3 first replica segment + carrier anchors, 4 step loop -- so that the single-block latency can be
 // attributed to its phases (5: + reduction up to its barrier, 6: everything but the result stores).  Results are wrong by
 // construction; never part of the product build.
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D, FMT)) dc_k
         };
         // ---- the block's first samples: requested before anything else (they depend on the launch geometry only), so
         // that their trip from HBM overlaps the parameter fetch, the chip-table staging and the first replica segment --
-        // in a single-block call that trip is a fifth of the kernel's time (scripts/r03_latency_cuts.sh)
+        // in a single-block call that trip is a fifth of the kernel's time (scripts/history/r03/r03_latency_cuts.sh)
         if (c_begin < c_full && !preloaded) {
             const __amdgpu_buffer_rsrc_t rr = plane_rsrc(p_re), ri = plane_rsrc(p_im);
 #pragma unroll

@@ -12,7 +12,7 @@
 // ALU only builds B (one carrier rotation + one chip fetch per lane and MFMA) -- in the vector
 // kernel the same work costs 4 + 2L FMAs per antenna, channel and sample plus per-4-antenna-tile
 // carrier / replica overhead, and that kernel is VALU-bound for these shapes.
-// Measured limit (scripts/mfma_probe.hip, MI355X): a dependent chain of this instruction issues
+// Measured limit (scripts/probes/mfma_probe.hip, MI355X): a dependent chain of this instruction issues
 // every 64.0 cycles bare, 94 with one carrier rotation + product (5 VALU) per MFMA, 132 with two
 // LDS fetches more -- the f32 MFMA runs at the FP32 vector rate and vector work does NOT hide
 // behind it as it does behind the bf16 matrix pipe, so this kernel gains what it saves in

@@ -232,7 +232,7 @@ __device__ __forceinline__ void mfma_apply(f32x16 (&acc)[RT == 1 ? 2 : RT], Frag
             const unsigned a0 = aa[t][0], a1 = aa[t][1], a2 = cur.xa[t][0], b3 = cur.xa[t][1];
             const u32x4 af = u32x4{a0, a1, a2, b3};
             // (one row tile: two accumulators take the slices in turn -- a dependent chain of this MFMA issues
-            // every 52 cycles, independent ones every 32: scripts/mfma_bf16_probe.hip)
+            // every 52 cycles, independent ones every 32: scripts/probes/mfma_bf16_probe.hip)
             acc[RT == 1 ? (J & 1) : t] =
                 __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), bw, acc[RT == 1 ? (J & 1) : t], 0, 0, 0);
         }
@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         if (!have_item) return;
         if (!c.valid) return;
         const bool anchor = first || ((st - s_begin) % kReanchor) == 0; // wave-uniform
-#if defined(GAT_ABLATE) && (GAT_ABLATE & 1) // diagnostic builds (scripts/ablate_mfma_bf16.sh; results wrong on purpose): no replica
+#if defined(GAT_ABLATE) && (GAT_ABLATE & 1) // diagnostic builds (scripts/history/r01/ablate_mfma_bf16.sh; results wrong on purpose): no replica
         if (first)
 #endif
         gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, nb, span + item_s0, OS, span + T,

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B bench of several libgat builds in one gpurun call: scripts/ab.sh "<bench args>" lib1 lib2 ...
+# A/B bench of several libgat builds in one gpurun call: scripts/history/r01/ab.sh "<bench args>" lib1 lib2 ...
 ARGS=$1; shift
 for rep in 1 2; do
 for lib in "$@"; do

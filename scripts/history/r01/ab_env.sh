@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B bench with environment variants in one gpurun call: scripts/ab_env.sh "<bench args>" "ENV1=.." "ENV2=.." ...
+# A/B bench with environment variants in one gpurun call: scripts/history/r01/ab_env.sh "<bench args>" "ENV1=.." "ENV2=.." ...
 ARGS=$1; shift
 for rep in 1 2; do
 for ev in "$@"; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of two builds of libgat.so on the one-GPU BASELINE shapes: scripts/ab_lib.sh <other .so>
+# A/B of two builds of libgat.so on the one-GPU BASELINE shapes: scripts/history/r01/ab_lib.sh <other .so>
 run() { for lib in "" "$OTHER"; do GAT_LIBRARY=$lib timeout 180 python bench.py --no-cpu-baseline --steps 10 --warmup 2 "$@" 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); r=d['roofline']; c=d['config']

@@ -1,5 +1,5 @@
 #!/bin/bash
-# one PMC pass with a caller-chosen counter list: scripts/pmc_generic.sh <tag> "<counters>" <bench args...>
+# one PMC pass with a caller-chosen counter list: scripts/history/r01/pmc_generic.sh <tag> "<counters>" <bench args...>
 set -u
 TAG=$1; CNT=$2; shift; shift
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counter passes for one bench configuration:  scripts/pmc_r.sh <tag> <bench args...>
+# SQ counter passes for one bench configuration:  scripts/history/r01/pmc_r.sh <tag> <bench args...>
 set -u
 TAG=$1; shift
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library builds in ONE call (same box): scripts/r02_ab.sh tag libA libB ...  (lib = "main" or a build/libgat_<name>.so variant)
+# A/B of library builds in ONE call (same box): scripts/history/r02/r02_ab.sh tag libA libB ...  (lib = "main" or a build/libgat_<name>.so variant)
 tag=$1; shift
 libs=("$@")
 mkdir -p gpurun_out/r02h

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counter passes of a development build on one bench shape: scripts/r02_pmc.sh <lib> <tag> [ENV=..]... -- <bench args>
+# SQ counter passes of a development build on one bench shape: scripts/history/r02/r02_pmc.sh <lib> <tag> [ENV=..]... -- <bench args>
 set -u
 LIB=$1; TAG=$2; shift; shift
 envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift

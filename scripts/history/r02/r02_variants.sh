@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of development builds of libgat (build/libgat_<name>.so) on the BASELINE shapes: scripts/r02_variants.sh name...
+# A/B of development builds of libgat (build/libgat_<name>.so) on the BASELINE shapes: scripts/history/r02/r02_variants.sh name...
 set -o pipefail
 out=gpurun_out/r02v; mkdir -p $out
 run() { # lib, name, env..., -- args

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3: A/B of library builds on ONE box.  scripts/r03_ab.sh tag "shapes" libA libB ...
+# Round 3: A/B of library builds on ONE box.  scripts/history/r03/r03_ab.sh tag "shapes" libA libB ...
 #   lib = "main" (gpuacceleratedtracking_amd/libgat.so) or the NAME of build/libgat_NAME.so
 #   shapes = space-separated subset of: c2 c2_i16 c2_i8 c1shape c3 c4 c5
 # Every line is the default bench protocol (64 settle + 50 warm-up + 200 timed launches); two rounds, alternating.

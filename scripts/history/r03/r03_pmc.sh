@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 3: PMC passes of one bench shape (separate rocprofv3 --pmc runs, --kernel-trace only beside them):
-#   scripts/r03_pmc.sh tag [sets] -- bench-args...      sets: any of "fetch write sq1 sq2 clk lds" (default: all but lds)
+#   scripts/history/r03/r03_pmc.sh tag [sets] -- bench-args...      sets: any of "fetch write sq1 sq2 clk lds" (default: all but lds)
 # GAT_LIBRARY=... selects a variant build.  Output: gpurun_out/r03/pmc_<tag>.txt (one dict per pass, averaged over the
 # last launches of the dominant kernel) + the raw csv under gpurun_out/r03/pmc_<tag>_<set>/
 set -o pipefail

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 3 evidence: rocprofv3 --kernel-trace --stats of `python bench.py [...]` for the default line and every BASELINE shape
-# (default protocol: 64 settle + 50 warm-up + 200 timed launches), then the PMC passes of scripts/r03_pmc.sh (FETCH_SIZE /
+# (default protocol: 64 settle + 50 warm-up + 200 timed launches), then the PMC passes of scripts/history/r03/r03_pmc.sh (FETCH_SIZE /
 # WRITE_SIZE in separate runs; SQ sets; clock) per shape.  Output: gpurun_out/r03p/  (copied to profiles/r03/ by hand)
 set -o pipefail
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -34,7 +34,7 @@ cd $REPO
 for spec in "c2:" "c1shape:--num-samples 4000 --num-ants 1 --blocks 16384" "c3:--baseline-config 2" "c4:--baseline-config 3" "c5:--baseline-config 4" "c2_i16:--layout i16" "c2_i8:--layout i8"; do
   tag=${spec%%:*}; args=${spec#*:}
   : > gpurun_out/r03/pmc_$tag.txt
-  bash scripts/r03_pmc.sh $tag "fetch write sq1 sq2 clk" -- $args > /dev/null 2>&1
+  bash scripts/history/r03/r03_pmc.sh $tag "fetch write sq1 sq2 clk" -- $args > /dev/null 2>&1
   cat gpurun_out/r03/pmc_$tag.txt >> $OUT/summary.txt
 done
 cat $OUT/summary.txt

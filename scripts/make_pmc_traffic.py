@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""profiles/pmc_traffic.json from the summary of scripts/r03_profile_configs.sh (lines `<tag> fetch <kernel> {...}` /
-`<tag> write <kernel> {...}` written by scripts/r03_pmc.sh): HBM bytes per launch = 2 * FETCH_SIZE KB (gfx950 correction of
+"""profiles/pmc_traffic.json from the summary of the round's scripts/r0N_profile_configs.sh (lines `<tag> fetch <kernel> {...}` /
+`<tag> write <kernel> {...}` written by scripts/r0N_pmc.sh): HBM bytes per launch = 2 * FETCH_SIZE KB (gfx950 correction of
 MI355X_MICROARCH.md for 16-B/lane streaming reads) + WRITE_SIZE KB, against bench.py's algorithmic bytes of the same
 workload.  The kernel label is the full instance name rocprofv3 reports (all template arguments).
 usage: scripts/make_pmc_traffic.py profiles/r03/r03p_summary.txt"""

@@ -1,6 +1,6 @@
 // bw_probe.hip -- HBM read-ceiling probe for MI355X: what can a pure streaming-read kernel reach
 // on a 2.6 GB buffer?  (cdna_hip_programming.md rule 10: a ceiling needs a known-good reference
-// measured on the same hardware.)  Build: hipcc -O3 --offload-arch=gfx950 scripts/bw_probe.hip -o build/bw_probe
+// measured on the same hardware.)  Build: hipcc -O3 --offload-arch=gfx950 scripts/probes/bw_probe.hip -o build/bw_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -1,7 +1,7 @@
 // fma_mix_probe.hip -- does v_fma_mix_f32 (f16 multiplicand taken from one half of a register, f32 multiplier and
 // accumulator) issue at the rate of v_fma_f32 on gfx950?  (round 3: code chips kept as f16 pairs would halve the chip
 // registers and the LDS replica of the fused correlator if the mixed instruction costs nothing extra.)
-// Independent chains in registers, no memory.  Build: hipcc -O3 --offload-arch=gfx950 scripts/fma_mix_probe.hip -o build/fmp
+// Independent chains in registers, no memory.  Build: hipcc -O3 --offload-arch=gfx950 scripts/probes/fma_mix_probe.hip -o build/fmp
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)

@@ -1,6 +1,6 @@
 // lds_unaligned_probe.hip -- does ds_read_b128 work at 4-byte-aligned (not 16-byte-aligned) LDS addresses on gfx950, and at what
 // cost?  (round 2: the correlator reads the chips of 4 consecutive samples for a tap offset o; entry = 4*lane + o.)
-// Build: hipcc -O3 --offload-arch=gfx950 scripts/lds_unaligned_probe.hip -o build/lup
+// Build: hipcc -O3 --offload-arch=gfx950 scripts/probes/lds_unaligned_probe.hip -o build/lup
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f4 __attribute__((ext_vector_type(4)));

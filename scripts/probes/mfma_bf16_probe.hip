@@ -1,5 +1,5 @@
 // Issue-rate probe for v_mfma_f32_32x32x16_bf16 on the whole chip: waves/SIMD x accumulators, wall clock and
-// s_memtime.  hipcc --offload-arch=gfx950 -O3 scripts/mfma_bf16_probe.hip -o build/mfma_bf16_probe && ./build/mfma_bf16_probe
+// s_memtime.  hipcc --offload-arch=gfx950 -O3 scripts/probes/mfma_bf16_probe.hip -o build/mfma_bf16_probe && ./build/mfma_bf16_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));

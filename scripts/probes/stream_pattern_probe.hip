@@ -2,7 +2,7 @@
 //   (a) "4 antennas per workgroup":   a workgroup streams 8 planes, 4 KB contiguous per plane and step (4 waves side by side)
 //   (b) "16 antennas per workgroup":  a workgroup streams 32 planes, 1 KB contiguous per plane and step (every wave its own 8 planes)
 // same total bytes, same loads per lane (8 x 16 B in flight per step), non-temporal loads, 256-thread workgroups.
-// Build: hipcc -O3 --offload-arch=gfx950 scripts/stream_pattern_probe.hip -o /tmp/spp
+// Build: hipcc -O3 --offload-arch=gfx950 scripts/probes/stream_pattern_probe.hip -o /tmp/spp
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -5,7 +5,7 @@
 //   C  the kernel's last thread writes a flag in pinned host memory, the host spins on it
 //   D  hipStreamWriteValue32 behind the kernel into pinned host memory, the host spins on it
 // each with the device's default scheduling flags and with hipDeviceScheduleSpin.
-// Build: hipcc -O2 --offload-arch=gfx950 scripts/sync_probe.hip -o build/sync_probe
+// Build: hipcc -O2 --offload-arch=gfx950 scripts/probes/sync_probe.hip -o build/sync_probe
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>

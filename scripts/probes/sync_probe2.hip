@@ -1,5 +1,5 @@
 // sync_probe2.hip -- round 3: the single-block correlate call + gat_sync is 11.5-12 us even when the vector kernel ends at its
-// first instruction (scripts/r03_latency_cuts.sh), while sync_probe.hip's empty kernel + flag is 7.0 us.  Which difference
+// first instruction (scripts/history/r03/r03_latency_cuts.sh), while sync_probe.hip's empty kernel + flag is 7.0 us.  Which difference
 // between the two launches costs the 4.5 us?  Every variant: one launch + host spin on a pinned flag, minimum / median,
 // plus the host time inside the launch call itself and the per-launch time of 2000 launches with ONE wait at the end.
 //   0  sync_probe's mode C: 1 workgroup x 64 threads, system fence + flag store
@@ -9,7 +9,7 @@
 //   4  3 + the library's completion protocol: barrier, agent-scope release fence, arrival counter, system-scope release store
 //   5  3 + completion protocol WITHOUT the arrival counter (single-workgroup launches need none)
 //   6  4 with hipExtLaunchKernelGGL-free plain hipModule-style launch through hipLaunchKernel (args array)
-// Build: hipcc -O2 --offload-arch=gfx950 scripts/sync_probe2.hip -o build/sync_probe2
+// Build: hipcc -O2 --offload-arch=gfx950 scripts/probes/sync_probe2.hip -o build/sync_probe2
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>

@@ -6,7 +6,7 @@
 //   MODE 3: MODE 2 at the size of the 4-channel x 4-antenna x 4-sample step of the real kernel: 96 accumulators, 48 chips and
 //           32 phasor values live, ~700 straight-line vector instructions per iteration (register count and code size)
 //   MODE 2: the correlator's inner pattern: dr = xr*cr + xi*ci; di = xi*cr - xr*ci; acc[l] += chip[l]*{dr,di}  (L = 3, 4 antennas)
-// Build: hipcc -O3 -fno-slp-vectorize -ffp-contract=off --offload-arch=gfx950 scripts/valu_issue_probe.hip -o build/vip
+// Build: hipcc -O3 -fno-slp-vectorize -ffp-contract=off --offload-arch=gfx950 scripts/probes/valu_issue_probe.hip -o build/vip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
