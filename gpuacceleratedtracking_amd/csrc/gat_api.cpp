@@ -595,7 +595,15 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             a.rep_chan_floats = ((odd ? 2 : 1) * one + 7) & ~7;
             cfg.lds_bytes = (unsigned)dc_lds_bytes_one_wave(a.rep_chan_floats, c->code_row_stride);
         } else {
-            const int chan_floats = dc_rep_chan_floats((int)chunk, kt, MT);
+            // An instance that holds four waves per SIMD (dc_min_waves) needs four workgroups per CU to get them: with
+            // 10 KB chip tables (GPS L5) the full eight-step segment makes a workgroup 47 KB -- three per CU.  Such launches
+            // take a segment short enough for 40 KB (configs[2]: six steps; 1.151 -> 1.106 ms together with the two-sample
+            // passes that bring the five-tap instance to 128 registers, profiles/r04/r04g_c2_four_waves.txt).
+            if (dc_min_waves(MT, cfg.taps, kt, 1, fmt) >= 4)
+                while (seg > 2 && dc_lds_bytes_floats(kt, c->code_row_stride, dc_rep_chan_floats_steps(seg, (int)chunk)) > 40 * 1024) --seg;
+            const int chan_floats = dc_rep_chan_floats_steps(seg, (int)chunk);
+            a.rep_chan_floats = chan_floats;
+            cfg.lds_bytes = (unsigned)dc_lds_bytes_floats(kt, c->code_row_stride, chan_floats);
             if (odd)
                 while (seg > 1 && 2 * dc_rep_copy_floats(seg, (int)chunk, a.rep_span) > chan_floats) --seg;
             cfg.depth = 1;

@@ -233,30 +233,6 @@ __device__ __forceinline__ void completion_flag(unsigned *done_counter, unsigned
     }
 }
 
-// Occupancy hint: instances with up to 40 accumulator registers come out at 125-165 registers; asking for three waves
-// per SIMD (<= 168) costs them nothing, while the four-antenna five-tap instance otherwise lands ONE register over
-// that step.  No bound for the larger instances, and never a tighter one: the allocator then spills into the step loop
-// (measured in both rounds: 1.2-3x slower).
-#ifndef GAT_DC_SB_EXPR
-#define GAT_DC_SB_EXPR (S > 4 ? 4 : S)
-#endif
-#ifndef GAT_DC_MINW
-#define GAT_DC_MINW 3
-#endif
-// Round 4: the carrier table took the per-lane phasor state out of the step loop and the opaque producer index three more
-// registers out of every instance; the small instances (<= 24 accumulator registers, one sample set) now fit four waves
-// per SIMD and the channel-looping ones two (<= 256 registers, no AGPRs) without spills, so they are asked to.  Not the
-// int8 instances: eight samples per group put their channel-looping forms 13-92 registers over 256 (they keep the AGPR
-// copies and one wave per SIMD; by default int8 samples of such shapes run on the split-bf16 matrix kernel anyway).
-constexpr int dc_min_waves(int mt, int l, int kt, int d, int fmt)
-{
-    const int accs = 2 * mt * l * kt;
-    const bool i8 = fmt == GAT_LAYOUT_INTERLEAVED_I8;
-    if (accs > 40) return i8 ? 1 : 2;
-    if (d == 1 && accs >= 40) return GAT_DC_MINW;
-    return d == 1 && accs <= 24 && !i8 ? 4 : 3;
-}
-
 // Diagnostic builds (-DGAT_DC_LAT_CUT=n, scripts/history/r03/r03_latency_cuts.sh): the kernel ends at cut point n -- 1 entry, 2 block
 // set-up + chip tables, 3 first replica segment + carrier anchors, 4 step loop -- so that the single-block latency can be
 // attributed to its phases (5: + reduction up to its barrier, 6: everything but the result stores).  Results are wrong by
@@ -306,7 +282,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D, FMT)) dc_k
     float *s_rep = s_ucar + KT * kUcarFloats;                                          // [KT][RCH]
     const int SEG = a.seg_steps;        // steps whose replica is produced at once (<= dc_segment_steps(CHUNK, KT, MT))
     // floats per channel: the replica (+ its shifted copy); one-wave workgroups: sized by the host for this launch
-    const int RCH = NW == 1 ? a.rep_chan_floats : dc_rep_chan_floats(CHUNK, KT, MT);
+    const int RCH = a.rep_chan_floats;
     int8_t *s_code = reinterpret_cast<int8_t *>(s_rep + KT * RCH);                     // [KT][code_row_stride]
 
     const int tid = threadIdx.x;
@@ -544,7 +520,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D, FMT)) dc_k
         // L taps: one 8-byte-aligned vector read per tap and 4 samples -- tap_off[l] is the tap's distance from the first
         // when that is even, else (distance - 1) into the copy stored one entry further (host: gat_api.cpp).
         // SB = samples handled at once: the whole group, or half of the eight-sample groups of int8 pairs (see the step)
-        constexpr int SB = GAT_DC_SB_EXPR;
+        constexpr int SB = dc_sub_batch(S, MT, L, KT);
         constexpr int NH = S / SB;
         auto get_chips_sub = [&](float (&chip)[SB][L], int rel, const float *rep) {
 #if defined(GAT_DC_ABLATE) && (GAT_DC_ABLATE & 2)

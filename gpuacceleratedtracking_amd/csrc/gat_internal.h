@@ -66,7 +66,8 @@ struct DcArgs {
     int rep_span;          // shifts[last] - shifts[0] of THIS launch's taps (replica halo)
     int seg_steps;         // steps per segment (replica produced at once), <= dc_segment_steps()
     int rep_copy_stride;   // floats between the replica and its copy shifted by one entry (taps at odd offsets), 0: one copy
-    int rep_chan_floats;   // one-wave workgroups: floats of LDS per channel replica (sized for this launch's taps)
+    int rep_chan_floats;   // floats of LDS per channel replica (one-wave workgroups: sized for this launch's taps; four-wave
+                           // ones: for the segment the host chose, <= dc_rep_chan_floats())
     int keep_l2;           // 1: plain loads (several channel groups share the tile through L2), 0: non-temporal
     int n_vec;             // samples of a block the vector path covers: N - N % (samples per 16-byte load); N for scalar loads
     int align_head;        // 1: workgroups walk a block from the 128-byte line its first sample lies in (gat_dc.h)
@@ -130,18 +131,46 @@ constexpr int dc_segment_steps(int chunk, int kt, int mt)
 // then halves the segment so that both fit here.  Room: segment samples + kMaxReplicaSpan taps + one entry per
 // producer thread of overshoot; at least one step with two copies.
 constexpr int dc_rep_copy_floats(int steps, int chunk, int span, int threads = kThreads) { return (steps * chunk + span + threads + 2 + 1) & ~1; }
-constexpr int dc_rep_chan_floats(int chunk, int kt, int mt)
+constexpr int dc_rep_chan_floats_steps(int steps, int chunk)
 {
-    const int one = dc_rep_copy_floats(dc_segment_steps(chunk, kt, mt), chunk, kMaxReplicaSpan);
+    const int one = dc_rep_copy_floats(steps, chunk, kMaxReplicaSpan);
     const int two = 2 * dc_rep_copy_floats(1, chunk, kMaxReplicaSpan);
     return ((one > two ? one : two) + 7) & ~7;
 }
-// dynamic LDS of one dc_kernel workgroup: per-channel constants, reduction scratch, carrier table, one segment's replica,
-// chip tables
-constexpr size_t dc_lds_bytes(int kt, int mt, int code_row_stride, int chunk)
+constexpr int dc_rep_chan_floats(int chunk, int kt, int mt) { return dc_rep_chan_floats_steps(dc_segment_steps(chunk, kt, mt), chunk); }
+// dynamic LDS of one four-wave dc_kernel workgroup: per-channel constants, reduction scratch, carrier table, one segment's
+// replica (chan_floats per channel: the host may size it for fewer steps than dc_segment_steps), chip tables
+constexpr size_t dc_lds_bytes_floats(int kt, int code_row_stride, int chan_floats)
 {
     return (size_t)kt * 32 + (size_t)kt * 4 * 64 * sizeof(float) + (size_t)kt * kUcarFloats * sizeof(float) +
-           (size_t)kt * dc_rep_chan_floats(chunk, kt, mt) * sizeof(float) + (size_t)kt * code_row_stride;
+           (size_t)kt * chan_floats * sizeof(float) + (size_t)kt * code_row_stride;
+}
+constexpr size_t dc_lds_bytes(int kt, int mt, int code_row_stride, int chunk)
+{
+    return dc_lds_bytes_floats(kt, code_row_stride, dc_rep_chan_floats(chunk, kt, mt));
+}
+// Samples of a group handled at once in the one-channel step (chips, phasors and wipe-off products of SB samples live
+// together): the whole group, half of the eight-sample groups of int8 pairs (a fourth wave per SIMD, round 3), and two of
+// four for the tiles with 25-40 accumulator registers (four antennas x five taps: 145 -> 128 registers, round 4).
+constexpr int dc_sub_batch(int s, int mt, int l, int kt) { return s > 4 ? 4 : (s == 4 && kt == 1 && 2 * mt * l > 24 && 2 * mt * l <= 40 ? 2 : s); }
+// Occupancy hints (__launch_bounds__ of dc_kernel; the host sizes the LDS segment for the same number of workgroups per
+// CU).  scripts/kernel_resources.sh prints what every instance needs; a bound tighter than that spills into the step loop
+// (1.2-3x slower, rounds 1-2).  Round 4 took the per-lane phasor state and three hoisted fill addresses out of every
+// instance: see the rule below; the channel-looping instances with more than 40 accumulator registers -> two waves
+// (<= 256 registers, no AGPR copies), without spills for float and int16 samples.  The int8 forms (eight samples per
+// group) keep round 3's bounds: 13-92 registers over 256 in their channel-looping instances (AGPR copies, one wave per
+// SIMD; by default such shapes run on the split-bf16 matrix kernel).
+constexpr int dc_min_waves(int mt, int l, int kt, int d, int fmt)
+{
+    const int accs = 2 * mt * l * kt;
+    const bool i8 = fmt == GAT_LAYOUT_INTERLEAVED_I8;
+    if (accs > 40) return i8 ? 1 : (accs <= 48 && kt == 2 ? 3 : 2); // (four antennas x three taps x two channels: 167 registers)
+    if (d != 1 || i8 || kt != 1) return 3;
+    // one channel, one sample set: four waves where the step fits 128 registers -- up to 24 accumulator registers in every
+    // format, up to 40 where the step runs in two-sample passes (dc_sub_batch: four-sample groups, i.e. planar float and
+    // int16 samples; the four-antenna five-tap planar instance spills two registers outside its step loop for it)
+    const int s = dc_group_samples(4, fmt);
+    return accs <= 24 || dc_sub_batch(s, mt, l, kt) < s ? 4 : 3;
 }
 // does an instance of dc_kernel exist for this combination (gat_dc.h: dc_instance)
 bool dc_has_instance(int ant_tile, int taps, int vec, int aw, int kt, int nw = 4, int depth = 1);
