@@ -397,7 +397,7 @@ def measure(args, g, torch, dist, world, rank, shape_kw, steps, warmup, settle, 
     elapsed = time.perf_counter() - t0
     per_rank = [elapsed * 1e3 / steps]
     props = torch.cuda.get_device_properties(torch.cuda.current_device())
-    ident = {"rank": rank, "device": torch.cuda.current_device(), "name": props.name,
+    ident = {"rank": rank, "device": torch.cuda.current_device(), "name": ctx.device_info()["name"],  # name + gfx arch
              "pci_bus_id": "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
                                                  getattr(props, "pci_device_id", 0)),
              "uuid": str(getattr(props, "uuid", ""))}
