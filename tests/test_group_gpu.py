@@ -250,14 +250,15 @@ def test_sync_after_flagged_launch_sees_results_and_later_work_falls_back(gat):
     assert lib.gat_destroy(h) == 0
 
 
-@pytest.mark.parametrize("N,M", [(2500, 4), (65536, 4), (20000, 1)])
+@pytest.mark.parametrize("N,M", [(2500, 4), (65536, 4), (20000, 1), (2046, 1), (65538, 1)])
 def test_completion_flag_results_are_out_when_the_flag_is(gat, N, M):
     """The completion flag must not reach the host before the results are in memory.  The copies in the test above are
     stream-ordered behind the kernel and would pass either way; here the outputs are read by PyTorch's stream, which is NOT
     ordered with the context's own stream -- the read is correct only if gat_sync returned after the results were written
     back.  The carrier phase changes from call to call (a rotation of every accumulator), so a stale or half-written result
     shows as the previous call's rotation; one-workgroup launches (N = 2500: no arrival counter), a split block with the
-    second stage carrying the flag (N = 65536), and host-parameter records inside the kernel arguments."""
+    second stage carrying the flag (N = 65536), ragged lengths whose tail launch carries it (N = 2046, 65538), and
+    host-parameter records inside the kernel arguments."""
     import torch
     from gpuacceleratedtracking_amd import _lib
     from gpuacceleratedtracking_amd.context import Context
@@ -283,7 +284,10 @@ def test_completion_flag_results_are_out_when_the_flag_is(gat, N, M):
 
     base = call(0.0)
     assert abs(base.reshape(L, M)[1, 0] - N) < 1e-3 * N
-    assert ctx.last_launch_info()["finalize_launched"] == (0 if N == 2500 else 1)
+    # (N = 2046 / 65538: ragged block lengths -- the flag is carried by dc_tail_kernel, the call's last launch; a single
+    # antenna, so that the unpadded antenna stride does not matter)
+    assert ctx.last_launch_info()["finalize_launched"] == (0 if N in (2500, 2046) else 1)
+    assert ctx.last_launch_info()["vec"] == 4
     bad = 0
     for i in range(1, 1500):
         phase = (i * 0.0371) % 1.0
