@@ -14,7 +14,7 @@ from .algorithms import (ALGODICT, ALGODICTINV, MEMDICT, REDDICT, KernelAlgorith
                          ReplicaAlgorithm, cpu_reduce_partial_sum, cuda_reduce_partial_sum, kernel_algorithm)
 from .benchmarks import (add_metadata, add_results, algorithmic_bytes, build_stream,  # noqa: F401
                          run_kernel_benchmark, run_reduction_benchmark, run_replica_benchmark, stream_scenario)
-from .context import Context, get_context  # noqa: F401
+from .context import Context, ResidentCorrelator, get_context  # noqa: F401
 from .correlator import (EarlyPromptLateCorrelator, NumAccumulators, NumAnts, get_accumulators,  # noqa: F401
                          get_correlator_sample_shifts, get_num_accumulators, get_num_ants)
 from .gen_signal import StructSignal, gen_blank_signal, gen_signal, gen_signal_stream, make_params  # noqa: F401

@@ -36,6 +36,8 @@ EXPORTS = [
     "gat_device_count", "gat_memcpy_peer", "gat_group_create", "gat_group_destroy", "gat_group_size", "gat_group_ctx",
     "gat_group_last_error", "gat_group_shard", "gat_group_set_codes", "gat_group_replicate", "gat_group_correlate",
     "gat_group_gather", "gat_group_sync",
+    # resident correlator: single-block calls without a kernel launch
+    "gat_resident_open", "gat_resident_correlate", "gat_resident_info_get", "gat_resident_park", "gat_resident_close",
 ]
 
 
@@ -89,6 +91,19 @@ class LaunchInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("workgroups", "threads", "splits", "ant_tile", "vec",
                                           "lds_bytes", "finalize_launched", "matrix_core", "channels_per_wg",
                                           "blocks_per_wg", "prefetch_depth")]
+
+
+class ResidentConfig(C.Structure):
+    """gat_resident_config (include/gat.h)."""
+
+    _fields_ = [(n, C.c_uint32) for n in ("struct_size", "idle_us", "life_ms", "max_calls", "max_workgroups")]
+
+
+class ResidentInfo(C.Structure):
+    """gat_resident_info (include/gat.h)."""
+
+    _fields_ = [("workgroups", C.c_int32), ("splits", C.c_int32), ("running", C.c_int32), ("last_exit", C.c_int32),
+                ("launches", C.c_uint64), ("calls", C.c_uint64)]
 
 
 _LIB = None
@@ -165,6 +180,11 @@ def load(build_if_missing: bool = True):
         "gat_group_correlate": (i32, [vp, sp, pp, i32, i32, i32, i32p, dbl, C.POINTER(vp), C.POINTER(vp), u32]),
         "gat_group_gather": (i32, [vp, C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, vp, vp]),
         "gat_group_sync": (i32, [vp]),
+        "gat_resident_open": (i32, [vp, sp, i32, i32, i32p, dbl, C.POINTER(ResidentConfig), C.POINTER(vp)]),
+        "gat_resident_correlate": (i32, [vp, pp, i64, vp, vp]),
+        "gat_resident_info_get": (i32, [vp, C.POINTER(ResidentInfo), C.c_size_t]),
+        "gat_resident_park": (i32, [vp]),
+        "gat_resident_close": (i32, [vp]),
     }
     assert sorted(sigs) == sorted(EXPORTS)
     for name, (res, args) in sigs.items():

@@ -13,11 +13,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgat.so")
-SOURCES = ["gat_dc_f0.hip", "gat_dc_f1.hip", "gat_dc_f2.hip", "gat_dc_f3.hip", "gat_kernels.hip", "gat_mfma.hip",
-           "gat_mfma_bf16.hip", "gat_api.cpp", "gat_codes.cpp"]
+SOURCES = ["gat_dc_f0.hip", "gat_dc_f1.hip", "gat_dc_f2.hip", "gat_dc_f3.hip", "gat_resident_f0.hip", "gat_resident_f1.hip",
+           "gat_kernels.hip", "gat_mfma.hip", "gat_mfma_bf16.hip", "gat_api.cpp", "gat_codes.cpp"]
 # gat_version.cpp is not in SOURCES: it is compiled at every link with the build's identity (git commit, flags)
 HEADERS = [os.path.join(CSRC, "gat_internal.h"), os.path.join(CSRC, "gat_phase.h"), os.path.join(CSRC, "gat_dc.h"),
-           os.path.join(ROOT, "include", "gat.h")]
+           os.path.join(CSRC, "gat_dc_body.inc"), os.path.join(CSRC, "gat_resident.h"), os.path.join(ROOT, "include", "gat.h")]
 
 
 def hipcc_path() -> str:
@@ -110,7 +110,8 @@ def build_libgat(force: bool = False, verbose: bool = False, extra_flags: tuple[
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
         # flags that only touch the fused vector kernel (-DGAT_DC_*): every other object is shared with the main build
-        shared = dc_only and not src.startswith("gat_dc_f") and src != "gat_api.cpp"  # the planner shares gat_internal.h
+        vector_tu = src.startswith("gat_dc_f") or src.startswith("gat_resident_f")  # both are made of gat_dc_body.inc
+        shared = dc_only and not vector_tu and src != "gat_api.cpp"  # the planner shares gat_internal.h
         obj = os.path.join(base_objdir if shared else objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if shared:
@@ -120,7 +121,7 @@ def build_libgat(force: bool = False, verbose: bool = False, extra_flags: tuple[
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(sp), hdr_t):
             # the fused vector kernel is written with scalar FMAs on purpose (gat_dc.h): keep the SLP vectoriser from
             # re-packing them into v_pk_fma_f32 + operand-pairing moves
-            per_file = ("-fno-slp-vectorize",) if src.startswith("gat_dc_f") else ()
+            per_file = ("-fno-slp-vectorize",) if vector_tu else ()
             jobs.append([hipcc_path(), *_flags(tuple(extra_here) + per_file), "-c", sp, "-o", obj])
 
     def run(cmd):

@@ -242,9 +242,79 @@ class Context:
                                             C.c_void_p(_ptr(out_re)), C.c_void_p(_ptr(out_im)))
         self.check(rc, "gat_reduce_cplx_multi")
 
+    def open_resident(self, desc: _lib.SignalDesc, num_channels: int, shifts, sampling_frequency: float, **config):
+        """A resident correlator for single-block calls (include/gat.h gat_resident_open): see ``ResidentCorrelator``."""
+        return ResidentCorrelator(self, desc, num_channels, shifts, sampling_frequency, **config)
+
     def params_to_device(self, params: np.ndarray) -> torch.Tensor:
         prm = np.ascontiguousarray(params, dtype=_lib.PARAMS_DTYPE)
         return torch.from_numpy(prm.view(np.uint8).reshape(-1).copy()).to(self.device)
+
+
+class ResidentCorrelator:
+    """``gat_resident`` (include/gat.h): ONE bounded-lifetime kernel stays on the device for a fixed call geometry; a call
+    rings it through pinned host memory (no kernel launch, no stream wait) and returns the correlator outputs as host
+    arrays -- the reference's ``@benchmark CUDA.@sync kernel_algorithm(...)`` call (src/benchmarks.jl:120-146) plus the copy
+    of its outputs to the host.  ``config``: idle_us, life_ms, max_calls, max_workgroups (0 / absent: library defaults).
+
+    The caller makes sure the block's samples are in device memory before ``correlate`` (``torch.cuda.synchronize()`` or
+    ``ctx.sync()`` after whatever produced them).  Use as a context manager, or ``close()`` it."""
+
+    def __init__(self, ctx: Context, desc: _lib.SignalDesc, num_channels: int, shifts, sampling_frequency: float, **config):
+        unknown = set(config) - {"idle_us", "life_ms", "max_calls", "max_workgroups"}
+        if unknown:
+            raise TypeError(f"unknown resident option(s): {sorted(unknown)}")
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self._desc = desc  # the buffer it describes must outlive the correlator: the caller keeps the tensors
+        sh = np.ascontiguousarray(shifts, dtype=np.int32)
+        cfg = _lib.ResidentConfig(C.sizeof(_lib.ResidentConfig), *(int(config.get(k, 0)) for k in ("idle_us", "life_ms", "max_calls", "max_workgroups")))
+        self._h = C.c_void_p()
+        rc = self.lib.gat_resident_open(ctx._h, C.byref(desc), int(num_channels), int(sh.size), sh.ctypes.data_as(C.POINTER(C.c_int32)),
+                                        float(sampling_frequency), C.byref(cfg), C.byref(self._h))
+        ctx.check(rc, "gat_resident_open")
+        self.shape = (int(num_channels), int(sh.size), int(desc.num_ants))  # [K, L, M] (C order == the ABI's [M x L x K])
+        self._re = np.empty(self.shape, dtype=np.float32)
+        self._im = np.empty(self.shape, dtype=np.float32)
+        self._fn = self.lib.gat_resident_correlate
+        self._pre, self._pim = C.c_void_p(self._re.ctypes.data), C.c_void_p(self._im.ctypes.data)
+
+    def correlate(self, params, block_offset: int = 0):
+        """params: structured array of ``num_channels`` records (``_lib.PARAMS_DTYPE``).  Returns (re, im): float32 views
+        [K, L, M] that the NEXT call overwrites (copy what has to last)."""
+        prm = params if (isinstance(params, np.ndarray) and params.dtype == _lib.PARAMS_DTYPE and params.flags.c_contiguous) \
+            else np.ascontiguousarray(params, dtype=_lib.PARAMS_DTYPE)
+        if prm.size != self.shape[0]:
+            raise ValueError("params must hold num_channels entries")
+        rc = self._fn(self._h, prm.ctypes.data_as(C.POINTER(_lib.ChannelParams)), int(block_offset), self._pre, self._pim)
+        if rc != 0:
+            self.ctx.check(rc, "gat_resident_correlate")
+        return self._re, self._im
+
+    def info(self) -> dict:
+        i = _lib.ResidentInfo()
+        self.ctx.check(self.lib.gat_resident_info_get(self._h, C.byref(i), C.sizeof(i)), "gat_resident_info_get")
+        return {n: int(getattr(i, n)) for n, _ in i._fields_}
+
+    def park(self):
+        self.ctx.check(self.lib.gat_resident_park(self._h), "gat_resident_park")
+
+    def close(self):
+        if self._h and self.ctx._h:  # (a context that was closed first has taken its correlators with it)
+            self.lib.gat_resident_close(self._h)
+        self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _CONTEXTS: dict = {}

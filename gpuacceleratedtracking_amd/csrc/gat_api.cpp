@@ -26,7 +26,35 @@
 
 using namespace gat;
 
+struct gat_ctx;
+
+// A resident correlator (gat_resident_open): one bounded-lifetime kernel serving single-block calls rung in through
+// pinned host memory (gat_resident.h).  Owned by its context's list until gat_resident_close.
+struct gat_resident {
+    gat_ctx *ctx = nullptr;
+    hipStream_t stream = nullptr;  // its own non-blocking stream: the kernel runs next to the context's work
+    DcArgs a{};
+    DcLaunch cfg{};
+    ResidentArgs r{};
+    unsigned char *h_block = nullptr; // pinned: doorbell lines | flag | state | staging for the device block | results
+    unsigned *h_bell = nullptr, *h_flag = nullptr, *h_state = nullptr, *h_init = nullptr;
+    float *h_out_re = nullptr, *h_out_im = nullptr;
+    unsigned *d_block = nullptr;      // device: forwarded doorbell [64] | done_seq (own line) | arrival counter (own line)
+    float *d_partial = nullptr;
+    unsigned seq = 0;                 // sequence number of the last call
+    bool running = false;             // a kernel was started and has not been seen to end
+    bool stale = false;               // the code table changed: the correlator has to be opened again
+    int K = 0, L = 0, M = 0, spv = 1;
+    long long N = 0, max_shift = 0;
+    double fs = 0.0;
+    uint32_t idle_us = 0, life_ms = 0, max_calls = 0;
+    long long ticks_per_us = 100;
+    unsigned last_exit = 0;
+    uint64_t launches = 0, calls = 0;
+};
+
 struct gat_ctx {
+    std::vector<gat_resident *> residents; // open resident correlators (parked before device-wide waits)
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -186,11 +214,21 @@ int32_t upload_params(gat_ctx *c, const gat_channel_params *params_host, size_t 
     return GAT_OK;
 }
 
+// What the planner hands to gat_resident_open instead of launching: the arguments and geometry of the ONE vector launch
+// that would serve the call (four-wave workgroups, one antenna tile and one channel each: the resident instances).
+struct DcPlan {
+    long long max_wgs = 64; // in: workgroups the block's samples may be split over (times antenna tiles and channels)
+    DcArgs a{};
+    DcLaunch cfg{};
+};
+
 // params_dev: [B*K] records on the device -- or null with params_inline: B*K <= kInlineParams validated HOST records that
 // travel inside the vector kernel's arguments (uploaded after all if a matrix-core kernel takes the call)
+// plan != null: nothing is launched; GAT_ERR_UNSUPPORTED unless the call is exactly one launch of the vector kernel
 int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel_params *params_dev,
                        int32_t B, int32_t K, int32_t L, const int32_t *shifts, double fs,
-                       float *out_re, float *out_im, uint32_t flags, const gat_channel_params *params_inline = nullptr)
+                       float *out_re, float *out_im, uint32_t flags, const gat_channel_params *params_inline = nullptr,
+                       DcPlan *plan_out = nullptr)
 {
     c->wait_seq = 0;
     const TraceRange trace("gat_downconvert_and_correlate");
@@ -254,7 +292,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         std::stable_sort(order, order + L, [&](int x, int y) { return shifts[x] < shifts[y]; });
         const long long span = (long long)shifts[order[L - 1]] - shifts[order[0]];
         const int CT = L <= kMfmaMaxTaps ? 16 / L : 0;
-        const bool shape_any = c->mc_mode != 0 && vec == 4 && N % spv == 0 /* whole load groups */ && M % 16 == 0 && sig->chan_stride == 0 && CT >= 1 &&
+        const bool shape_any = !plan_out && c->mc_mode != 0 && vec == 4 && N % spv == 0 /* whole load groups */ && M % 16 == 0 && sig->chan_stride == 0 && CT >= 1 &&
                               span <= kMfmaMaxSpan && 2 * std::min(K, CT) * L >= 12 /* >= 3/8 of the columns */;
         const bool shape_ok = shape_any && planar; // the f32-MFMA kernel reads planar f32 only
         const int nct_total = shape_ok ? (K + CT - 1) / CT : 1;
@@ -421,6 +459,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     aw = std::min(aw, c->max_aw);
     if (vec == 4 && aw == 4 && sig->chan_stride == 0 && K > 1) kt = K >= 3 ? 4 : 2;
     kt = std::min(kt, c->max_kt);
+    if (plan_out) aw = 1, kt = 1;
     // tap launches: sorted taps cut into groups of <= kMaxTapsPerLaunch whose span fits the LDS replica segment
     int order[GAT_MAX_TAPS];
     for (int l = 0; l < L; ++l) order[l] = l;
@@ -448,7 +487,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     // long enough to fill the chip with single waves.  Per block the set-up (parameters, rotations, walk constants) is
     // then done by one wave instead of four, and no wave waits at a workgroup barrier.
     int nw = 4;
-    if (c->one_wave && vec == 4 && aw == 1 && kt == 1 && MT <= 2 && c->code_row_stride <= 2048 &&
+    if (c->one_wave && !plan_out && vec == 4 && aw == 1 && kt == 1 && MT <= 2 && c->code_row_stride <= 2048 &&
         (N + dc_chunk(vec, fmt, 1) - 1) / dc_chunk(vec, fmt, 1) <= 8 &&
         groups >= (c->one_wave_min >= 0 ? c->one_wave_min : 32ll * c->num_cus) &&
         c->max_aw >= 4 /* the (1, 1, 1) tiling of the A/B tests keeps the four-wave geometry */ &&
@@ -459,7 +498,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     // two workgroups resident per CU), where a finer split only adds partial sums, a second launch and workgroup starts
     // (configs[3] shard, 512 tiles: 2 / 4 / 8 per CU = 0.667 / 0.675 / 0.687 ms, profiles/r03/r03a_c4_split.txt).
     const int per_cu = c->wgs_per_cu > 0 ? c->wgs_per_cu : (kt >= 2 ? 2 : 8);
-    const long long target = (long long)per_cu * c->num_cus * (nw == 1 ? 4 : 1);
+    const long long target = plan_out ? plan_out->max_wgs : (long long)per_cu * c->num_cus * (nw == 1 ? 4 : 1);
     long long chunks = 0, splits = 1, cps = 1, bpw = 1;
     auto plan = [&](long long slack) { // slack: virtual samples in front of a block (line alignment, below)
         chunks = (N + slack + chunk - 1) / chunk;
@@ -484,8 +523,9 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     // the line its first sample lies in: up to 112 bytes of virtual samples in front of the block, hence the slack in the
     // chunk count.  Four-wave workgroups that own one block each (several short blocks per workgroup keep their walk across
     // block boundaries instead); option dc_align = 0 turns it off for A/B runs.
+    // (a resident correlator is told the block's offset with every call: it always walks from the line)
     const bool align_head = c->align_head && vec == 4 && nw == 4 && bpw == 1 &&
-                            ((reinterpret_cast<uintptr_t>(sig->re) & 127u) != 0 || (B > 1 && (sig->block_stride * plane_bytes) % 128 != 0) ||
+                            (plan_out || (reinterpret_cast<uintptr_t>(sig->re) & 127u) != 0 || (B > 1 && (sig->block_stride * plane_bytes) % 128 != 0) ||
                              (M > MT && (sig->ant_stride * plane_bytes * MT) % 128 != 0) || (sig->chan_stride * plane_bytes) % 128 != 0);
     if (align_head) plan(112 / plane_bytes);
     const long long BG = (B + bpw - 1) / bpw;
@@ -498,7 +538,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     if (atomic) {
         GAT_HIP(c, hipMemsetAsync(out_re, 0, out_elems * sizeof(float), c->stream));
         GAT_HIP(c, hipMemsetAsync(out_im, 0, out_elems * sizeof(float), c->stream));
-    } else if (splits > 1) {
+    } else if (splits > 1 && !plan_out) {
         const int32_t rc = ensure_partial(c, (size_t)B * K * splits * L * M * 2 * sizeof(float));
         if (rc != GAT_OK) return rc;
     }
@@ -517,7 +557,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(c->stream, &cap);
     // (library-owned streams only: nobody else can have enqueued newer work on them behind the library's back)
-    const bool flagged = c->own_stream && c->d_flag && c->flag_max_wgs > 0 && tiles * KG <= c->flag_max_wgs && cap == hipStreamCaptureStatusNone;
+    const bool flagged = !plan_out && c->own_stream && c->d_flag && c->flag_max_wgs > 0 && tiles * KG <= c->flag_max_wgs && cap == hipStreamCaptureStatusNone;
     (void)hipGetLastError();
     auto next_seq = [&]() { // sequence numbers of flagged launches: never 0 (0 = "nothing to wait for")
         if (++c->flag_seq == 0) ++c->flag_seq;
@@ -560,7 +600,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     // only -- every byte read once (one channel group), a workgroup owns whole blocks (no split), >= 2 steps per block.
     // (float samples: with int16 / int8 pairs the conversions make the step vector-bound and the third wave per SIMD that
     // the second set costs is worth more: 0.206 -> 0.209 ms, 0.169 -> 0.170 ms)
-    const bool deep_ok = c->max_depth >= 2 && vec == 4 && splits == 1 && KG == 1 && c->keep_l2 != 1 && sig->chan_stride == 0 && chunks >= 2 &&
+    const bool deep_ok = !plan_out && c->max_depth >= 2 && vec == 4 && splits == 1 && KG == 1 && c->keep_l2 != 1 && sig->chan_stride == 0 && chunks >= 2 &&
                          (fmt == GAT_LAYOUT_PLANAR || fmt == GAT_LAYOUT_INTERLEAVED);
     cfg.vec = vec;
     cfg.format = fmt;
@@ -625,6 +665,15 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             a.host_flag = c->d_flag;
             a.flag_seq = next_seq();
         }
+        if (plan_out) {
+            if (t1 < L) return fail(c, GAT_ERR_UNSUPPORTED, "resident correlator: the taps need more than one launch");
+            if (vec != 4 || tail) return fail(c, GAT_ERR_UNSUPPORTED, "resident correlator: block starts must be 16-byte aligned and num_samples a multiple of the load group");
+            if (cfg.depth != 1 || nw != 4) return fail(c, GAT_ERR_UNSUPPORTED, "resident correlator: no instance for this geometry");
+            plan_out->a = a;
+            plan_out->a.keep_l2 = 0; // the resident instances read the signal with non-temporal loads
+            plan_out->cfg = cfg;
+            return GAT_OK;
+        }
         GAT_HIP(c, launch_dc(a, cfg, c->stream));
         t0 = t1;
     }
@@ -668,6 +717,85 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     c->last.blocks_per_wg = (int32_t)bpw;
     c->last.prefetch_depth = cfg.depth;
     return GAT_OK;
+}
+
+} // namespace
+
+namespace {
+
+// ---- resident correlator: host side --------------------------------------------------------------------------------
+constexpr size_t kResBellBytes = kInlineParams * kBellDwords * sizeof(unsigned); // 256
+constexpr size_t kResDevBlockBytes = kResBellBytes + 128;                          // + done_seq line + counter line
+
+double mono_us()
+{
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec * 1e6 + t.tv_nsec * 1e-3;
+}
+
+// host mirror of the kernels' `bad` predicate for host-resident records: what passes here is not poisoned there
+int32_t validate_params(gat_ctx *c, const gat_channel_params *params_host, size_t n, double reach, double fs)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const gat_channel_params &p = params_host[i];
+        if (p.prn < 0 || p.prn >= c->P) return fail(c, GAT_ERR_RANGE, "prn outside the code table");
+        if (!std::isfinite(p.code_freq_hz) || !std::isfinite(p.carrier_freq_hz) ||
+            !std::isfinite(p.code_phase_chips) || !std::isfinite(p.carrier_phase_cycles))
+            return fail(c, GAT_ERR_ARG, "non-finite channel parameter");
+        if (p.code_freq_hz < 0.0) return fail(c, GAT_ERR_RANGE, "negative code frequency");
+        if (std::fabs(p.carrier_freq_hz / fs) >= 1.0e15 || std::fabs(p.carrier_phase_cycles) >= 1.0e15)
+            return fail(c, GAT_ERR_RANGE, "carrier frequency / phase out of range");
+        if (!code_span_ok(p.code_freq_hz / fs, p.code_phase_chips, reach, c->Lc))
+            return fail(c, GAT_ERR_RANGE, "code phase span too large");
+    }
+    return GAT_OK;
+}
+
+// start the kernel: it has served everything up to start_seq; a ring with a newer number is served at once
+int32_t resident_start(gat_resident *res, unsigned start_seq)
+{
+    gat_ctx *c = res->ctx;
+    __atomic_store_n(&res->h_state[0], (unsigned)kResidentRuns, __ATOMIC_RELEASE);
+    res->h_state[1] = 0;
+    std::memset(res->h_init, 0, kResDevBlockBytes);
+    res->h_init[0] = start_seq;                            // forwarded doorbell: nothing newer than start_seq
+    res->h_init[kResBellBytes / sizeof(unsigned)] = start_seq; // done_seq: that call is finished
+    GAT_HIP(c, hipMemcpyAsync(res->d_block, res->h_init, kResDevBlockBytes, hipMemcpyHostToDevice, res->stream));
+    res->r.start_seq = start_seq;
+    res->a.codes = c->d_codes;
+    GAT_HIP(c, launch_dc_resident(res->a, res->cfg, res->r, res->stream));
+    res->running = true;
+    ++res->launches;
+    return GAT_OK;
+}
+
+// ask the kernel to leave and wait until it has (its own limits bound the wait)
+int32_t resident_park(gat_resident *res)
+{
+    if (!res->running) return GAT_OK;
+    gat_ctx *c = res->ctx;
+    if (__atomic_load_n(&res->h_state[0], __ATOMIC_ACQUIRE) == kResidentRuns)
+        __atomic_store_n(&res->h_bell[0], kBellQuit, __ATOMIC_RELEASE);
+    GAT_HIP(c, hipStreamSynchronize(res->stream));
+    __atomic_store_n(&res->h_bell[0], res->seq, __ATOMIC_RELEASE); // line 0 is the last call's again
+    res->last_exit = __atomic_load_n(&res->h_state[0], __ATOMIC_ACQUIRE);
+    res->running = false;
+    return GAT_OK;
+}
+
+void park_residents(gat_ctx *c)
+{
+    for (gat_resident *r : c->residents) (void)resident_park(r);
+}
+
+void resident_free(gat_resident *res)
+{
+    if (res->d_block) (void)hipFree(res->d_block);
+    if (res->d_partial) (void)hipFree(res->d_partial);
+    if (res->h_block) (void)hipHostFree(res->h_block);
+    if (res->stream) (void)hipStreamDestroy(res->stream);
+    delete res;
 }
 
 } // namespace
@@ -877,6 +1005,9 @@ GAT_API int32_t gat_destroy(gat_ctx *c)
 {
     if (!c) return GAT_ERR_ARG;
     (void)hipSetDevice(c->device);
+    park_residents(c);
+    for (gat_resident *r : c->residents) resident_free(r); // handles of correlators that were not closed die with the context
+    c->residents.clear();
     (void)hipStreamSynchronize(c->stream);
     if (c->d_codes) (void)hipFree(c->d_codes);
     if (c->d_code_bits) (void)hipFree(c->d_code_bits);
@@ -965,6 +1096,8 @@ GAT_API int32_t gat_set_codes(gat_ctx *c, const int8_t *codes_host, int32_t code
     // the vector kernel keeps a workgroup's chip table in LDS next to one replica segment (~40 KB): 160 KB - that
     if (code_length > 120000) return fail(c, GAT_ERR_RANGE, "code table does not fit in LDS (max 120000 chips)");
     GAT_HIP(c, hipSetDevice(c->device));
+    park_residents(c); // their kernels hold the old tables (and hipFree waits for the whole device)
+    for (gat_resident *r : c->residents) r->stale = true;
     GAT_HIP(c, hipStreamSynchronize(c->stream));
     drop_loop_graphs(c); // recorded launches point at the old tables
     if (c->d_codes) {
@@ -1042,17 +1175,9 @@ GAT_API int32_t gat_downconvert_and_correlate(gat_ctx *c, const gat_signal_desc 
     const size_t n = (size_t)B * K;
     if (!c->d_codes) return fail(c, GAT_ERR_STATE, "gat_set_codes has not been called");
     if (!(fs > 0.0) || !std::isfinite(fs)) return fail(c, GAT_ERR_ARG, "sampling frequency must be positive");
-    for (size_t i = 0; i < n; ++i) { // mirrors the kernels' `bad` predicate: what passes here is not poisoned there
-        const gat_channel_params &p = params_host[i];
-        if (p.prn < 0 || p.prn >= c->P) return fail(c, GAT_ERR_RANGE, "prn outside the code table");
-        if (!std::isfinite(p.code_freq_hz) || !std::isfinite(p.carrier_freq_hz) ||
-            !std::isfinite(p.code_phase_chips) || !std::isfinite(p.carrier_phase_cycles))
-            return fail(c, GAT_ERR_ARG, "non-finite channel parameter");
-        if (p.code_freq_hz < 0.0) return fail(c, GAT_ERR_RANGE, "negative code frequency");
-        if (std::fabs(p.carrier_freq_hz / fs) >= 1.0e15 || std::fabs(p.carrier_phase_cycles) >= 1.0e15)
-            return fail(c, GAT_ERR_RANGE, "carrier frequency / phase out of range");
-        if (!code_span_ok(p.code_freq_hz / fs, p.code_phase_chips, (double)(sig->num_samples + max_shift), c->Lc))
-            return fail(c, GAT_ERR_RANGE, "code phase span too large");
+    {
+        const int32_t rcv = validate_params(c, params_host, n, (double)(sig->num_samples + max_shift), fs);
+        if (rcv != GAT_OK) return rcv;
     }
     if (n <= (size_t)kInlineParams) // no upload: the records ride in the kernel arguments
         return correlate_impl(c, sig, nullptr, B, K, L, shifts, fs, out_re, out_im, flags, params_host);
@@ -1283,6 +1408,7 @@ GAT_API int32_t gat_free(gat_ctx *c, void *p)
 {
     if (!c) return GAT_ERR_ARG;
     GAT_HIP(c, hipSetDevice(c->device));
+    park_residents(c); // hipFree waits for every kernel on the device: a resident one would hold it until its idle limit
     GAT_HIP(c, hipFree(p));
     return GAT_OK;
 }
@@ -1383,6 +1509,200 @@ GAT_API int32_t gat_last_launch_info(const gat_ctx *c, gat_launch_info *out, siz
     // the struct grows at its end: a caller built against an older header gets the fields it knows
     std::memcpy(out, &c->last, std::min(struct_size, sizeof(gat_launch_info)));
     return GAT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Resident correlator (include/gat.h; kernel: gat_resident.h)
+// ---------------------------------------------------------------------------------------------------------------------
+GAT_API int32_t gat_resident_open(gat_ctx *c, const gat_signal_desc *sig, int32_t K, int32_t L, const int32_t *shifts,
+                                  double fs, const gat_resident_config *config, gat_resident **out)
+{
+    if (!c) return GAT_ERR_ARG;
+    if (!out || !sig || !shifts) return fail(c, GAT_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (K < 1 || K > kInlineParams) return fail(c, K < 1 ? GAT_ERR_ARG : GAT_ERR_UNSUPPORTED, "resident correlator: 1 .. 4 channels");
+    gat_resident_config cf{};
+    if (config) {
+        if (config->struct_size < sizeof(uint32_t)) return fail(c, GAT_ERR_ARG, "gat_resident_config.struct_size not set");
+        std::memcpy(&cf, config, std::min<size_t>(config->struct_size, sizeof cf));
+    }
+    if (cf.max_workgroups > 1024) return fail(c, GAT_ERR_RANGE, "max_workgroups above 1024");
+    GAT_HIP(c, hipSetDevice(c->device));
+    if (sig->layout != GAT_LAYOUT_PLANAR && sig->layout != GAT_LAYOUT_INTERLEAVED)
+        return fail(c, GAT_ERR_UNSUPPORTED, "resident correlator: float samples only (GAT_LAYOUT_PLANAR, GAT_LAYOUT_INTERLEAVED)");
+
+    gat_resident *res = new (std::nothrow) gat_resident();
+    if (!res) return fail(c, GAT_ERR_NOMEM, "out of memory");
+    res->ctx = c;
+    auto bail = [&](int32_t rc) {
+        resident_free(res);
+        return rc;
+    };
+    // geometry: the planner's, restricted to the resident instances
+    DcPlan plan;
+    plan.max_wgs = cf.max_workgroups ? cf.max_workgroups : 64;
+    const gat_channel_params dummy[kInlineParams] = {};
+    float *const nonnull = reinterpret_cast<float *>(uintptr_t(64));
+    int32_t rc = correlate_impl(c, sig, nullptr, 1, K, L, shifts, fs, nonnull, nonnull, 0, dummy, &plan);
+    if (rc != GAT_OK) return bail(rc);
+    if (!dc_has_resident_instance(plan.cfg.ant_tile, plan.cfg.taps, plan.cfg.format))
+        return bail(fail(c, GAT_ERR_UNSUPPORTED, "resident correlator: no kernel instance for this shape"));
+    res->a = plan.a;
+    res->cfg = plan.cfg;
+    res->K = K;
+    res->L = L;
+    res->M = sig->num_ants;
+    res->N = sig->num_samples;
+    res->fs = fs;
+    res->spv = dc_group_samples(4, sig->layout);
+    for (int l = 0; l < L; ++l) res->max_shift = std::max<long long>(res->max_shift, std::llabs((long long)shifts[l]));
+    res->idle_us = cf.idle_us ? cf.idle_us : 5000u;
+    res->life_ms = cf.life_ms ? cf.life_ms : 2000u;
+    res->max_calls = cf.max_calls ? cf.max_calls : 0xfffffff0u;
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0) res->ticks_per_us = std::max(1, khz / 1000);
+    (void)hipGetLastError();
+
+    // pinned host block: doorbell | flag | state | staging | results
+    const size_t out_floats = ((size_t)K * L * res->M + 15) & ~size_t(15);
+    const size_t host_bytes = kResBellBytes + 64 + 64 + kResDevBlockBytes + 2 * out_floats * sizeof(float);
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&res->h_block), host_bytes, hipHostMallocCoherent | hipHostMallocMapped);
+    if (e != hipSuccess) return bail(hipfail(c, e, "hipHostMalloc"));
+    std::memset(res->h_block, 0, host_bytes);
+    unsigned char *d_host = nullptr;
+    if ((e = hipHostGetDevicePointer(reinterpret_cast<void **>(&d_host), res->h_block, 0)) != hipSuccess) return bail(hipfail(c, e, "hipHostGetDevicePointer"));
+    size_t off = 0;
+    auto carve = [&](size_t bytes, unsigned char **host, unsigned char **dev) {
+        *host = res->h_block + off;
+        *dev = d_host + off;
+        off += bytes;
+    };
+    unsigned char *h = nullptr, *d = nullptr;
+    carve(kResBellBytes, &h, &d); res->h_bell = reinterpret_cast<unsigned *>(h); res->r.host_bell = reinterpret_cast<const unsigned *>(d);
+    carve(64, &h, &d); res->h_flag = reinterpret_cast<unsigned *>(h); res->r.host_flag = reinterpret_cast<unsigned *>(d);
+    carve(64, &h, &d); res->h_state = reinterpret_cast<unsigned *>(h); res->r.host_state = reinterpret_cast<unsigned *>(d);
+    carve(kResDevBlockBytes, &h, &d); res->h_init = reinterpret_cast<unsigned *>(h);
+    carve(out_floats * sizeof(float), &h, &d); res->h_out_re = reinterpret_cast<float *>(h); res->r.host_out_re = reinterpret_cast<float *>(d);
+    carve(out_floats * sizeof(float), &h, &d); res->h_out_im = reinterpret_cast<float *>(h); res->r.host_out_im = reinterpret_cast<float *>(d);
+
+    if ((e = hipMalloc(reinterpret_cast<void **>(&res->d_block), kResDevBlockBytes)) != hipSuccess) return bail(hipfail(c, e, "hipMalloc"));
+    res->r.dev_bell = res->d_block;
+    res->r.dev_done_seq = res->d_block + kResBellBytes / sizeof(unsigned);
+    res->r.done_counter = res->d_block + kResBellBytes / sizeof(unsigned) + 16;
+    if (res->a.splits > 1) {
+        const size_t pb = (size_t)K * res->a.splits * L * res->M * 2 * sizeof(float);
+        if ((e = hipMalloc(reinterpret_cast<void **>(&res->d_partial), pb)) != hipSuccess) return bail(hipfail(c, e, "hipMalloc"));
+    }
+    res->a.partial = res->d_partial;
+    res->a.out_re = res->r.host_out_re; // one split: the workgroups store their results straight into host memory
+    res->a.out_im = res->r.host_out_im;
+    res->a.done_counter = nullptr;
+    res->a.host_flag = nullptr;
+    res->r.max_calls = res->max_calls;
+    res->r.idle_ticks = (long long)res->idle_us * res->ticks_per_us;
+    res->r.life_ticks = (long long)res->life_ms * 1000ll * res->ticks_per_us;
+    if ((e = hipStreamCreateWithFlags(&res->stream, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreateWithFlags"));
+    res->seq = 1; // "the last call": nothing is pending when the kernel starts
+    res->h_bell[0] = res->seq;
+    rc = resident_start(res, res->seq);
+    if (rc != GAT_OK) return bail(rc);
+    c->residents.push_back(res);
+    *out = res;
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_resident_correlate(gat_resident *res, const gat_channel_params *params_host, int64_t block_offset,
+                                       float *out_re_host, float *out_im_host)
+{
+    if (!res) return GAT_ERR_ARG;
+    gat_ctx *c = res->ctx;
+    if (!params_host || !out_re_host || !out_im_host) return fail(c, GAT_ERR_ARG, "null argument");
+    if (res->stale) return fail(c, GAT_ERR_STATE, "the code table changed: open the resident correlator again");
+    if (block_offset < 0 || block_offset % res->spv != 0 || block_offset >= (1ll << 40))
+        return fail(c, GAT_ERR_ARG, "block offset must be a non-negative multiple of the samples one 16-byte load holds");
+    int32_t rc = validate_params(c, params_host, (size_t)res->K, (double)(res->N + res->max_shift), res->fs);
+    if (rc != GAT_OK) return rc;
+
+    // ring: one line per channel, line 0 last; inside a line the two sequence words last
+    unsigned prev = res->seq, seq = prev + 1;
+    if (seq == 0u || seq == kBellQuit) seq = 1;
+    if (seq == prev) ++seq;
+    for (int k = res->K - 1; k >= 0; --k) {
+        unsigned w[kBellDwords] = {};
+        w[0] = seq;
+        std::memcpy(&w[2], &params_host[k], sizeof(gat_channel_params));
+        w[3] = 0; // the record's reserved word
+        std::memcpy(&w[12], &block_offset, sizeof(int64_t));
+        unsigned x = 0;
+        for (int i = 0; i < 14; ++i) x ^= w[i];
+        w[14] = x;
+        w[15] = seq;
+        unsigned *line = res->h_bell + (size_t)k * kBellDwords;
+        for (int i = 1; i < 15; ++i) line[i] = w[i];
+        __atomic_store_n(&line[15], seq, __ATOMIC_RELEASE);
+        __atomic_store_n(&line[0], seq, __ATOMIC_RELEASE);
+    }
+    res->seq = seq;
+    if (!res->running || __atomic_load_n(&res->h_state[0], __ATOMIC_ACQUIRE) != kResidentRuns) {
+        if (res->running) res->last_exit = res->h_state[0];
+        GAT_HIP(c, hipSetDevice(c->device));
+        if ((rc = resident_start(res, prev)) != GAT_OK) return rc;
+    }
+    // wait: the kernel stores the call's number after its results (system-scope release)
+    const double t0 = mono_us(), deadline = (double)res->life_ms * 1000.0 + 1.0e6;
+    for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(res->h_flag, __ATOMIC_ACQUIRE) == seq) break;
+        if ((spins & 63u) != 63u) continue;
+        if (__atomic_load_n(&res->h_state[0], __ATOMIC_ACQUIRE) != kResidentRuns) {
+            // the kernel has left (idle, lifetime, call budget) -- with this call served or not
+            if (__atomic_load_n(res->h_flag, __ATOMIC_ACQUIRE) == seq) break;
+            res->last_exit = res->h_state[0];
+            GAT_HIP(c, hipSetDevice(c->device));
+            if ((rc = resident_start(res, prev)) != GAT_OK) return rc;
+        }
+        if (mono_us() - t0 > deadline) {
+            (void)resident_park(res);
+            return fail(c, GAT_ERR_STATE, "resident correlator: no answer from the device");
+        }
+    }
+    const size_t n = (size_t)res->K * res->L * res->M;
+    std::memcpy(out_re_host, res->h_out_re, n * sizeof(float));
+    std::memcpy(out_im_host, res->h_out_im, n * sizeof(float));
+    ++res->calls;
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_resident_info_get(const gat_resident *res, gat_resident_info *out, size_t struct_size)
+{
+    if (!res || !out || struct_size == 0) return GAT_ERR_ARG;
+    gat_resident_info i{};
+    i.workgroups = (int32_t)res->a.total_wgs;
+    i.splits = res->a.splits;
+    const bool ended = res->running && __atomic_load_n(&res->h_state[0], __ATOMIC_ACQUIRE) != kResidentRuns;
+    i.running = res->running && !ended ? 1 : 0;
+    i.last_exit = (int32_t)(ended ? res->h_state[0] : res->last_exit);
+    i.launches = res->launches;
+    i.calls = res->calls;
+    std::memcpy(out, &i, std::min(struct_size, sizeof i));
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_resident_park(gat_resident *res)
+{
+    if (!res) return GAT_ERR_ARG;
+    (void)hipSetDevice(res->ctx->device);
+    return resident_park(res);
+}
+
+GAT_API int32_t gat_resident_close(gat_resident *res)
+{
+    if (!res) return GAT_ERR_ARG;
+    gat_ctx *c = res->ctx;
+    (void)hipSetDevice(c->device);
+    const int32_t rc = resident_park(res);
+    c->residents.erase(std::remove(c->residents.begin(), c->residents.end(), res), c->residents.end());
+    resident_free(res);
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

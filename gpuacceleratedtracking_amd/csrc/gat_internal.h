@@ -109,6 +109,33 @@ struct DcLaunch {
     unsigned grid;
     unsigned lds_bytes;
 };
+// ---- resident correlator (gat_resident.h): calls without a launch ----------------------------------------------------
+// One bounded-lifetime kernel stays on the device and serves single-block calls that the host rings in through a
+// doorbell in pinned host memory; results and the completion flag go back to pinned host memory.
+// Doorbell: one 64-byte line per channel (K <= kInlineParams lines, written by the host in descending order, line 0 last):
+//   dword 0 seq | 1 reserved | 2..11 gat_channel_params | 12..13 block offset in samples (int64) | 14 check | 15 seq
+// check = XOR of dwords 0..13: a poll that catches a line half-written fails the check and is repeated.
+constexpr int kBellDwords = 16;
+constexpr unsigned kBellQuit = 0xffffffffu; // never a call's sequence number
+struct ResidentArgs {
+    const unsigned *host_bell; // pinned host (device address): [K][16]
+    unsigned *dev_bell;        // device: the master workgroup's copy for the other workgroups (total_wgs > 1)
+    unsigned *dev_done_seq;    // device: sequence number of the last call all workgroups have finished
+    unsigned *done_counter;    // device: arrival counter
+    unsigned *host_flag;       // pinned host: sequence number of the last finished call (results are in place)
+    unsigned *host_state;      // pinned host: [0] why the kernel ended (0: it runs), [1] calls it served
+    float *host_out_re;        // pinned host: [K][Ltot][M]
+    float *host_out_im;
+    unsigned start_seq;        // sequence number of the last call served before this launch
+    unsigned max_calls;        // the kernel ends after this many calls ...
+    long long idle_ticks;      // ... or this long without one (100 MHz wall clock) ...
+    long long life_ticks;      // ... or this long after its start, whatever happens
+};
+enum ResidentExit : unsigned { kResidentRuns = 0, kResidentQuit = 1, kResidentIdle = 2, kResidentLife = 3, kResidentCalls = 4 };
+bool dc_has_resident_instance(int ant_tile, int taps, int format);
+hipError_t launch_dc_resident(const DcArgs &a, const DcLaunch &cfg, const ResidentArgs &r, hipStream_t s);
+template <int FMT> hipError_t launch_dc_resident_fmt(const DcArgs &a, const DcLaunch &cfg, const ResidentArgs &r, hipStream_t s);
+
 // carrier table of one segment: [steps <= kUcarSteps][samples of a lane's groups, G * S <= 8][re, im] floats per channel
 constexpr int kUcarSteps = 8;
 constexpr int kUcarFloats = kUcarSteps * 8 * 2;

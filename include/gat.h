@@ -357,6 +357,61 @@ typedef struct gat_launch_info {
  * library copies no more than the caller has room for. */
 GAT_API int32_t gat_last_launch_info(const gat_ctx *ctx, gat_launch_info *out, size_t struct_size);
 
+/* ---- resident correlator: single-block calls without a kernel launch -------------------------------------------
+ * The reference's benchmark is ONE 1 ms block per call, synchronised (`@benchmark CUDA.@sync kernel_algorithm(...)`,
+ * src/benchmarks.jl:120-146), and its receiver loop consumes every block's correlator outputs on the host
+ * (Tracking.jl's discriminators).  Through gat_downconvert_and_correlate + gat_sync such a call costs a kernel launch and
+ * the wait for its end: 7 us on this platform before the kernel has done anything.  A resident correlator keeps ONE
+ * kernel on the device for a fixed call geometry; a call rings a doorbell in pinned host memory (the channel records
+ * and the block's position travel with the ring), the kernel correlates and writes the results and a completion
+ * number into pinned host memory, the host copies them out: no launch, no stream wait, outputs already on the host.
+ *
+ * Lifetime is bounded on the DEVICE side, whatever the host does: the kernel ends by itself after `idle_us` without a
+ * call, after `life_ms` in total, or after `max_calls` calls; the next call starts it again (that call then costs a
+ * launch).  It occupies one workgroup slot per workgroup it uses (info.workgroups, <= max_workgroups) and polls host
+ * memory from one of them while it waits.  Other work of the process runs next to it on other streams; calls that
+ * synchronise the whole device (hipDeviceSynchronize, hipFree) wait until it has ended: gat_free, gat_set_codes and
+ * gat_destroy therefore ask every resident correlator of the context to leave first (gat_set_codes: for good -- the
+ * correlator answers GAT_ERR_STATE afterwards and has to be opened again).
+ *
+ * Geometry (fixed at open): `signal` describes ONE block (num_samples, num_ants, ant_stride, layout; block_stride and
+ * chan_stride as for the correlator) at the START of a device buffer; every call names its block by an offset in
+ * samples from there (a ring buffer of blocks, or always 0).  Supported: what gat_downconvert_and_correlate would run as
+ * ONE launch of the vector kernel -- GAT_LAYOUT_PLANAR or GAT_LAYOUT_INTERLEAVED, block starts 16-byte aligned and
+ * num_samples a multiple of the samples one 16-byte load holds (4 / 2), num_channels <= 4, at most 8 taps within a span
+ * of 512 samples -- else GAT_ERR_UNSUPPORTED (use the ordinary call).  The caller makes sure the block's samples are in
+ * device memory before the call (e.g. gat_sync after the copy that brought them); the kernel reads them past its caches.
+ * Results: host arrays [M x L x K], the ordinary call's layout for one block; same values as the ordinary call up to the
+ * summation order of the per-workgroup partial sums. */
+typedef struct gat_resident gat_resident;
+typedef struct gat_resident_config {
+    uint32_t struct_size;    /* sizeof(gat_resident_config) of the caller's header                               */
+    uint32_t idle_us;        /* the kernel ends after this long without a call          (0: default, 5 000 us)   */
+    uint32_t life_ms;        /* ... and after this long whatever happens                (0: default, 2 000 ms)   */
+    uint32_t max_calls;      /* ... and after this many calls                           (0: no limit)            */
+    uint32_t max_workgroups; /* workgroups one block's samples may be split over        (0: default, 64)         */
+} gat_resident_config;
+typedef struct gat_resident_info {
+    int32_t workgroups;  /* workgroups of the resident kernel (sample splits x antenna tiles x channels)          */
+    int32_t splits;      /* sample splits of one block                                                            */
+    int32_t running;     /* 1: a kernel has been started and has not been seen to end                             */
+    int32_t last_exit;   /* why the last kernel that ended did: 0 none yet, 1 asked to, 2 idle, 3 lifetime, 4 calls */
+    uint64_t launches;   /* kernels started so far (1 + the restarts)                                             */
+    uint64_t calls;      /* calls served                                                                          */
+} gat_resident_info;
+GAT_API int32_t gat_resident_open(gat_ctx *ctx, const gat_signal_desc *signal, int32_t num_channels, int32_t num_taps,
+                                  const int32_t *shifts_host, double sampling_freq_hz, const gat_resident_config *config,
+                                  gat_resident **out_resident);
+/* One call = gat_downconvert_and_correlate(..., num_blocks = 1, ...) + gat_sync + the copy of the outputs to the host.
+ * params_host: num_channels records, validated as by the host entry point.  block_offset_samples: >= 0, a multiple of
+ * the samples one 16-byte load holds.  Blocks until the results are in out_re_host / out_im_host. */
+GAT_API int32_t gat_resident_correlate(gat_resident *resident, const gat_channel_params *params_host,
+                                       int64_t block_offset_samples, float *out_re_host, float *out_im_host);
+GAT_API int32_t gat_resident_info_get(const gat_resident *resident, gat_resident_info *out, size_t struct_size);
+/* asks the kernel to leave and waits until it has (bounded by the kernel's own limits); the next call starts it again */
+GAT_API int32_t gat_resident_park(gat_resident *resident);
+GAT_API int32_t gat_resident_close(gat_resident *resident);
+
 /* ---- several devices from one host thread --------------------------------------------------
  * The reference is single-device (its only device call is CUDA.CuDevice(0) for the GPU's name, src/benchmarks.jl:24;
  * "parallelization over multiple channels can be easily extended", paper/paper.tex:114).  Satellite channels are

@@ -100,6 +100,24 @@ struct LaunchInfo
     prefetch_depth::Int32
 end
 
+# struct gat_resident_config (20 bytes) / gat_resident_info (32 bytes): the resident correlator (single-block calls
+# without a kernel launch, include/gat.h)
+struct ResidentConfig
+    struct_size::UInt32
+    idle_us::UInt32
+    life_ms::UInt32
+    max_calls::UInt32
+    max_workgroups::UInt32
+end
+struct ResidentInfo
+    workgroups::Int32
+    splits::Int32
+    running::Int32
+    last_exit::Int32
+    launches::UInt64
+    calls::UInt64
+end
+
 struct GatError <: Exception
     status::Int32
     msg::String
@@ -522,6 +540,50 @@ end
 function memcpy_peer!(g::DeviceGroup, dst_rank::Integer, dst::Ptr{Cvoid}, src_rank::Integer, src::Ptr{Cvoid}, bytes::Integer)
     gcheck(g, ccall((:gat_memcpy_peer, libgat), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t),
                     member_handle(g, dst_rank), dst, member_handle(g, src_rank), src, bytes))
+end
+
+# ---- resident correlator: what `@benchmark CUDA.@sync kernel_algorithm(...)` (src/benchmarks.jl:120-146) times, without
+#      the launch -- one kernel stays on the device for a fixed call geometry (signal buffer, channels, taps), a call rings
+#      it through pinned host memory and returns the outputs on the host, ComplexF32 [M x L x K].  The kernel ends by itself
+#      (idle / lifetime / call budget, ResidentConfig; zeros = library defaults) and is started again by the next call.
+mutable struct Resident
+    handle::Ptr{Cvoid}
+    ctx::Context
+    re::Array{Float32,3}
+    im::Array{Float32,3}
+    prm::Vector{ChannelParams}
+end
+function Resident(ctx::Context, desc::SignalDesc, num_channels::Integer, shifts::Vector{Int32}, sampling_frequency_hz::Float64;
+                  idle_us = 0, life_ms = 0, max_calls = 0, max_workgroups = 0)
+    cfg = Ref(ResidentConfig(sizeof(ResidentConfig), idle_us, life_ms, max_calls, max_workgroups))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ctx, ccall((:gat_resident_open, libgat), Int32,
+                     (Ptr{Cvoid}, Ref{SignalDesc}, Int32, Int32, Ptr{Int32}, Float64, Ref{ResidentConfig}, Ref{Ptr{Cvoid}}),
+                     ctx.handle, Ref(desc), Int32(num_channels), Int32(length(shifts)), shifts, sampling_frequency_hz, cfg, h))
+    r = Resident(h[], ctx, Array{Float32}(undef, desc.num_ants, length(shifts), num_channels),
+                 Array{Float32}(undef, desc.num_ants, length(shifts), num_channels),
+                 [ChannelParams(0, 0, 0.0, 0.0, 0.0, 0.0) for _ in 1:num_channels])
+    finalizer(x -> x.handle == C_NULL || ccall((:gat_resident_close, libgat), Int32, (Ptr{Cvoid},), x.handle), r)
+    r
+end
+# one call: r.prm holds the channels' records (written in place by the caller), block_offset in samples from the buffer's
+# start; the outputs are in r.re / r.im when it returns
+function correlate!(r::Resident, block_offset::Integer = 0)
+    check(r.ctx, ccall((:gat_resident_correlate, libgat), Int32, (Ptr{Cvoid}, Ptr{ChannelParams}, Int64, Ptr{Cfloat}, Ptr{Cfloat}),
+                       r.handle, r.prm, Int64(block_offset), r.re, r.im))
+    r
+end
+function info(r::Resident)
+    i = Ref(ResidentInfo(0, 0, 0, 0, 0, 0))
+    check(r.ctx, ccall((:gat_resident_info_get, libgat), Int32, (Ptr{Cvoid}, Ref{ResidentInfo}, Csize_t), r.handle, i, sizeof(ResidentInfo)))
+    i[]
+end
+park!(r::Resident) = check(r.ctx, ccall((:gat_resident_park, libgat), Int32, (Ptr{Cvoid},), r.handle))
+function Base.close(r::Resident)
+    r.handle == C_NULL && return nothing
+    rc = ccall((:gat_resident_close, libgat), Int32, (Ptr{Cvoid},), r.handle)
+    r.handle = C_NULL
+    check(r.ctx, rc)
 end
 
 # ---- Tracking.gen_code_replica! (scripts/code_replica_experiment.jl:70)

@@ -175,7 +175,8 @@ def jl_layout(fields: list[tuple[str, str]]) -> tuple[int, list[int]]:
 
 
 STRUCT_PAIRS = {"gat_channel_params": "ChannelParams", "gat_signal_desc": "SignalDesc", "gat_loop_config": "LoopConfig",
-                "gat_loop_state": "LoopState", "gat_launch_info": "LaunchInfo"}
+                "gat_loop_state": "LoopState", "gat_launch_info": "LaunchInfo", "gat_resident_config": "ResidentConfig",
+                "gat_resident_info": "ResidentInfo"}
 
 
 # ------------------------------------------------------------------------------------------------ tests

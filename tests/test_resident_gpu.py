@@ -1,0 +1,285 @@
+"""Resident correlator (include/gat.h gat_resident_*; kernel gat_resident.h): single-block calls rung into a kernel that
+stays on the device -- parity with the FP64 oracle through every path of the doorbell protocol (one workgroup, several
+workgroups with the forwarded doorbell and the in-kernel second stage, several channels, block offsets), visibility of a
+signal rewritten between calls, and the kernel's bounded lifetime (idle exit, call budget, park, restart).  Run with -m gpu."""
+import time
+
+import numpy as np
+import pytest
+
+from tests.helpers import check_close, make_case, oracle_result
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gat():
+    import gpuacceleratedtracking_amd as g
+    g.load_library()
+    return g
+
+
+def _params(g, case, b):
+    p = case["prm"][b]
+    return g.make_params(p["prn0"], p["code_freq_hz"], p["carrier_freq_hz"], p["code_phase_chips"], p["carrier_phase_cycles"])
+
+
+def _open(g, case, layout=0, **config):
+    """The case's B blocks in one device buffer; the correlator is opened on block 0, block b is call offset b * N."""
+    import torch
+    ctx = g.get_context()
+    ctx.set_codes(case["codes"])
+    dev = ctx.device
+    N, M, B = case["N"], case["M"], case["B"]
+    re = torch.from_numpy(case["re"]).to(dev)
+    im = torch.from_numpy(case["im"]).to(dev)
+    if layout == 0:
+        keep = (re, im)
+        desc = g._lib.SignalDesc(re.data_ptr(), im.data_ptr(), g.GAT_LAYOUT_PLANAR, M, N, B * N, N, 0)
+    else:
+        x = torch.stack([re, im], dim=-1).contiguous()
+        keep = (x,)
+        desc = g._lib.SignalDesc(x.data_ptr(), None, g.GAT_LAYOUT_INTERLEAVED, M, N, B * N, N, 0)
+    torch.cuda.synchronize()
+    res = ctx.open_resident(desc, case["K"], case["shifts"], case["fs"], **config)
+    res._keep = keep
+    return ctx, res
+
+
+@pytest.mark.parametrize("N,M,L,K,layout,max_wgs", [
+    (2048, 4, 3, 1, 0, 0),     # one workgroup: the reference grid's smallest point
+    (2048, 1, 7, 1, 0, 0),
+    (4096, 4, 3, 1, 1, 0),     # ComplexF32 pairs
+    (32768, 4, 3, 1, 0, 0),    # sample splits: forwarded doorbell, in-kernel second stage
+    (32768, 1, 3, 1, 1, 8),
+    (16384, 16, 3, 1, 0, 16),  # four antenna tiles x splits
+    (8192, 2, 5, 3, 0, 0),     # three channels: three doorbell lines, channel workgroups
+    (2500 - 2500 % 4, 3, 3, 4, 0, 0),
+    (262144, 4, 3, 1, 0, 0),   # the grid's largest point
+])
+def test_resident_matches_oracle(gat, N, M, L, K, layout, max_wgs):
+    g = gat
+    case = make_case(900 + N % 97 + M + K, N=N, M=M, L=L, K=K, B=3)
+    ref = oracle_result(case)
+    ctx, res = _open(g, case, layout, max_workgroups=max_wgs, idle_us=200000)
+    try:
+        info = res.info()
+        assert info["running"] == 1 and info["launches"] == 1
+        for rep in range(2):  # every block twice: the second round runs on staged chip tables
+            for b in (0, 2, 1):
+                re, im = res.correlate(_params(g, case, b), block_offset=b * N)
+                got = (re + 1j * im)[None]  # [1, K, L, M]
+                assert np.isfinite(got.view(np.float32)).all()
+                check_close(got, ref[b:b + 1], what=f"resident N={N} M={M} K={K} block {b} rep {rep}")
+        assert res.info()["calls"] == 6 and res.info()["launches"] == 1
+    finally:
+        res.close()
+
+
+def test_resident_calls_are_bit_identical_and_agree_with_the_ordinary_call(gat):
+    g = gat
+    import torch
+    case = make_case(77, N=16384, M=4, L=3, K=2, B=1)
+    ctx, res = _open(g, case)
+    try:
+        prm = _params(g, case, 0)
+        first = tuple(a.copy() for a in res.correlate(prm))
+        for _ in range(20):
+            re, im = res.correlate(prm)
+            assert np.array_equal(re, first[0]) and np.array_equal(im, first[1])
+        # the ordinary call on the same buffers (different split plan: summation order only)
+        dev = ctx.device
+        o_re = torch.zeros((1, 2, 3, 4), device=dev)
+        o_im = torch.zeros_like(o_re)
+        desc = res._desc
+        ctx.downconvert_and_correlate(desc, prm, 1, 2, case["shifts"], case["fs"], o_re, o_im)
+        torch.cuda.synchronize()
+        ordinary = (o_re.cpu().numpy() + 1j * o_im.cpu().numpy())
+        check_close((first[0] + 1j * first[1])[None], ordinary, what="resident vs ordinary call")
+    finally:
+        res.close()
+
+
+def test_resident_sees_a_signal_rewritten_between_calls(gat):
+    """The kernel that serves call n+1 is the one that read the buffer for call n: nothing of the old samples may come
+    from its caches (system-scope acquire after every ring)."""
+    g = gat
+    import torch
+    a = make_case(11, N=8192, M=4, L=3, K=1, B=1)
+    b = make_case(12, N=8192, M=4, L=3, K=1, B=1)
+    want = {id(a): oracle_result(a), id(b): oracle_result(b)}
+    ctx, res = _open(g, a, idle_us=500000, life_ms=5000)
+    try:
+        re_t, im_t = res._keep
+        for rnd in range(6):
+            cur = a if rnd % 2 == 0 else b
+            re_t.copy_(torch.from_numpy(cur["re"]))
+            im_t.copy_(torch.from_numpy(cur["im"]))
+            torch.cuda.current_stream().synchronize()  # (a device-wide wait would sit out the kernel's idle limit)
+            re, im = res.correlate(_params(g, cur, 0))
+            check_close((re + 1j * im)[None], want[id(cur)], what=f"round {rnd}")
+        assert res.info()["launches"] == 1  # one kernel served all of them
+    finally:
+        res.close()
+
+
+def test_resident_lifetime_is_bounded_on_the_device(gat):
+    g = gat
+    case = make_case(5, N=4096, M=4, L=3, K=1, B=1)
+    ref = oracle_result(case)
+    ctx, res = _open(g, case, idle_us=3000, life_ms=200, max_calls=7)
+    try:
+        prm = _params(g, case, 0)
+        re, im = res.correlate(prm)
+        check_close((re + 1j * im)[None], ref)
+        # idle: the kernel leaves by itself
+        time.sleep(0.05)
+        i = res.info()
+        assert i["running"] == 0 and i["last_exit"] == 2, i
+        re, im = res.correlate(prm)  # starts it again
+        check_close((re + 1j * im)[None], ref)
+        assert res.info()["launches"] == 2
+        # call budget: 7 calls per kernel
+        for _ in range(20):
+            re, im = res.correlate(prm)
+        check_close((re + 1j * im)[None], ref)
+        i = res.info()
+        assert i["launches"] >= 4 and i["calls"] == 22, i
+        # lifetime: calls every millisecond keep it from idling; it still leaves after life_ms
+        res.park()
+        assert res.info()["running"] == 0 and res.info()["last_exit"] in (1, 2, 4)
+        n0 = res.info()["launches"]
+        t0 = time.time()
+        while time.time() - t0 < 0.5:
+            re, im = res.correlate(prm)
+            time.sleep(0.001)
+        check_close((re + 1j * im)[None], ref)
+        assert res.info()["launches"] >= n0 + 2  # 0.5 s of calls against a 0.2 s lifetime (and the budget of 7)
+    finally:
+        res.close()
+
+
+def test_resident_is_parked_by_free_and_invalidated_by_new_codes(gat):
+    g = gat
+    import ctypes as C
+    case = make_case(6, N=2048, M=1, L=3, K=1, B=1)
+    ctx, res = _open(g, case)
+    try:
+        prm = _params(g, case, 0)
+        res.correlate(prm)
+        p = C.c_void_p()
+        ctx.check(ctx.lib.gat_malloc(ctx._h, 4096, C.byref(p)), "gat_malloc")
+        t0 = time.time()
+        ctx.check(ctx.lib.gat_free(ctx._h, p), "gat_free")  # must not wait for the kernel's idle limit (5 ms default) for long
+        assert time.time() - t0 < 0.5
+        assert res.info()["running"] == 0
+        re, im = res.correlate(prm)
+        check_close((re + 1j * im)[None], oracle_result(case))
+        # a new code table: the correlator answers GAT_ERR_STATE until it is opened again
+        other = case["codes"].copy()
+        other[0, 0] = -other[0, 0]
+        ctx.set_codes(other)
+        with pytest.raises(g._lib.GatError) as e:
+            res.correlate(prm)
+        assert e.value.status == 3
+    finally:
+        res.close()
+    ctx.set_codes(case["codes"])
+
+
+def test_resident_rejects_what_it_cannot_serve(gat):
+    g = gat
+    import torch
+    ctx = g.get_context()
+    case = make_case(8, N=4096, M=2, L=3, K=1, B=1)
+    ctx.set_codes(case["codes"])
+    dev = ctx.device
+    x16 = torch.zeros((2, 4096, 2), dtype=torch.int16, device=dev)
+    re = torch.zeros((2, 4098), device=dev)
+    torch.cuda.synchronize()
+    L = g._lib
+    cases = [
+        (L.SignalDesc(x16.data_ptr(), None, g.GAT_LAYOUT_INTERLEAVED_I16, 2, 4096, 4096, 4096, 0), 1, [-1, 0, 1], 4),   # int16 pairs
+        (L.SignalDesc(re.data_ptr(), re.data_ptr(), g.GAT_LAYOUT_PLANAR, 2, 4096, 4096, 4096, 0), 5, [-1, 0, 1], 4),    # five channels
+        (L.SignalDesc(re.data_ptr(), re.data_ptr(), g.GAT_LAYOUT_PLANAR, 1, 4098, 4098, 4098, 0), 1, [-1, 0, 1], 4),    # ragged block length
+        (L.SignalDesc(re.data_ptr(), re.data_ptr(), g.GAT_LAYOUT_PLANAR, 1, 4096, 4096, 4096, 0), 1, [-2000, 0, 2000], 4),  # taps of two launches
+    ]
+    for desc, K, shifts, want in cases:
+        with pytest.raises(L.GatError) as e:
+            ctx.open_resident(desc, K, shifts, 4.096e6)
+        assert e.value.status == want, (K, shifts, e.value)
+    # bad calls on a good correlator
+    desc = L.SignalDesc(re.data_ptr(), re.data_ptr(), g.GAT_LAYOUT_PLANAR, 1, 4096, 4096, 4096, 0)
+    with ctx.open_resident(desc, 1, [-1, 0, 1], 4.096e6) as res:
+        prm = _params(g, case, 0)
+        for off in (-4, 3):
+            with pytest.raises(L.GatError):
+                res.correlate(prm, block_offset=off)
+        bad = prm.copy()
+        bad["prn"] = 99
+        with pytest.raises(L.GatError) as e:
+            res.correlate(bad)
+        assert e.value.status == 2
+        res.correlate(prm)  # still alive
+
+
+def test_context_close_takes_its_resident_correlators_along(gat):
+    g = gat
+    import torch
+    ctx = g.Context(0, "own")
+    case = make_case(9, N=2048, M=4, L=3, K=1, B=1)
+    ctx.set_codes(case["codes"])
+    re = torch.from_numpy(case["re"]).to(ctx.device)
+    im = torch.from_numpy(case["im"]).to(ctx.device)
+    torch.cuda.synchronize()
+    desc = g._lib.SignalDesc(re.data_ptr(), im.data_ptr(), g.GAT_LAYOUT_PLANAR, 4, 2048, 2048, 2048, 0)
+    res = ctx.open_resident(desc, 1, case["shifts"], case["fs"])
+    r, i = res.correlate(_params(g, case, 0))
+    check_close((r + 1j * i)[None], oracle_result(case))
+    t0 = time.time()
+    ctx.close()  # the kernel is asked to leave; nothing hangs
+    assert time.time() - t0 < 1.0
+    res.close()  # a no-op now
+
+
+def test_resident_call_is_faster_than_launch_and_wait(gat):
+    """What it is for: a call through the doorbell against the ordinary call + sync (completion-flag path, own stream) on
+    the reference grid's small points.  Medians over 300 calls; asserted loosely (the point is the protocol, the numbers
+    are in profiles/ and DESIGN.md)."""
+    g = gat
+    import torch
+    ctx = g.get_context(own_stream=True)
+    rows = []
+    for N, M in ((2048, 4), (16384, 4)):
+        case = make_case(3, N=N, M=M, L=3, K=1, B=1)
+        ctx.set_codes(case["codes"])
+        dev = ctx.device
+        re = torch.from_numpy(case["re"]).to(dev)
+        im = torch.from_numpy(case["im"]).to(dev)
+        o_re = torch.zeros((1, 1, 3, M), device=dev)
+        o_im = torch.zeros_like(o_re)
+        torch.cuda.synchronize()
+        desc = g._lib.SignalDesc(re.data_ptr(), im.data_ptr(), g.GAT_LAYOUT_PLANAR, M, N, N, N, 0)
+        prm = _params(g, case, 0)
+        pdev = ctx.params_to_device(prm)
+        torch.cuda.synchronize()
+        call = ctx.prepared_call(desc, pdev, 1, 1, case["shifts"], case["fs"], o_re, o_im)
+        t_ord = []
+        for r in range(350):
+            t0 = time.perf_counter()
+            call()
+            ctx.sync()
+            t_ord.append(time.perf_counter() - t0)
+        with ctx.open_resident(desc, 1, case["shifts"], case["fs"]) as res:
+            t_res = []
+            for r in range(350):
+                t0 = time.perf_counter()
+                res.correlate(prm)
+                t_res.append(time.perf_counter() - t0)
+            a, b = res.correlate(prm)
+            check_close((a + 1j * b)[None], oracle_result(case))
+        mo, mr = np.median(t_ord[50:]) * 1e6, np.median(t_res[50:]) * 1e6
+        rows.append((N, M, mo, mr))
+        print(f"single block N={N} M={M}: ordinary call + sync {mo:.1f} us, resident call {mr:.1f} us (Python host layer)")
+    for N, M, mo, mr in rows:
+        assert mr < mo, rows
