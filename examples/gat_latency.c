@@ -10,7 +10,9 @@
  *   graph  : the same call with GAT_FLAG_GRAPH (the launch sequence replayed as one instantiated hipGraph) + gat_sync
  *   enqueue: the call alone, many in a row, one sync at the end (what the device needs per call when the host does not wait)
  *   call   : host time inside the `dev` call itself (planning + the launches), median -- the rest of `dev` is waiting
- * Output: one line per grid point, minimum / median in microseconds.   build/gat_latency [reps]
+ *   resident: gat_resident_correlate -- the call rung into a kernel that stays on the device (no launch, no stream wait),
+ *             outputs copied to the host included; "wgs" = workgroups of that kernel
+ * Output: one line per grid point, minimum / median in microseconds.   build/gat_latency [reps [resident max_workgroups [host_pollers]]]
  */
 #include <math.h>
 #include <stdio.h>
@@ -41,13 +43,15 @@ int main(int argc, char **argv)
 {
     gat_ctx *ctx = NULL;
     const int reps = argc > 1 ? atoi(argv[1]) : 2000;
+    const unsigned res_wgs = argc > 2 ? (unsigned)atoi(argv[2]) : 0u; /* resident correlator: max_workgroups (0: library default) */
+    const unsigned res_pollers = argc > 3 ? (unsigned)atoi(argv[3]) : 0u; /* ... host_pollers (0: library default) */
     CHECK(gat_create(0, GAT_OWN_STREAM, &ctx));
     double *t = malloc(sizeof(double) * (size_t)reps), *tc = malloc(sizeof(double) * (size_t)reps);
     const int Ms[2] = {1, 4}, Ls[2] = {3, 7};
     /* the two committed grids of the reference */
     const struct { const char *system; int e0, e1, nl; } grids[2] = {{"GPSL1", 11, 18, 2}, {"GPSL5", 15, 18, 1}};
     printf("# one 1 ms block per call, prn 1, 1500 Hz (src/benchmarks.jl:96-99); %d calls per point; microseconds; %s\n", reps, gat_version());
-    printf("# %-5s %8s %2s %2s | %-15s | %-15s | %-15s | %s | %s\n", "GNSS", "N", "M", "L", "host min/med", "dev min/med", "graph min/med", "enqueue-only per call", "call med");
+    printf("# %-5s %8s %2s %2s | %-15s | %-15s | %-15s | %s | %s | %s\n", "GNSS", "N", "M", "L", "host min/med", "dev min/med", "graph min/med", "enqueue-only per call", "call med", "resident min/med (wgs)");
     for (int gi = 0; gi < 2; ++gi) {
     int32_t lc = 0;
     double fc = 0.0;
@@ -98,8 +102,35 @@ int main(int argc, char **argv)
                 CHECK(gat_sync(ctx));
                 const double per = (now_us() - t0) / reps;
                 CHECK(gat_memcpy_d2h(ctx, h, o_re, sizeof(float) * M * L));
-                printf("  %-5s %8d %2d %2d | %6.2f / %6.2f | %6.2f / %6.2f | %6.2f / %6.2f | %6.2f | %5.2f   (prompt %.0f)\n", grids[gi].system, N, M, L, res[0][0], res[0][1],
-                       res[1][0], res[1][1], res[2][0], res[2][1], per, call_med, h[(L / 2) * M]);
+                /* the same call through a resident correlator */
+                double rmin = 0.0, rmed = 0.0, rprompt = 0.0;
+                int rwgs = 0;
+                {
+                    gat_resident *rs = NULL;
+                    const gat_resident_config rcfg = {sizeof(gat_resident_config), 200000, 60000, 0, res_wgs, res_pollers};
+                    float r_re[4 * 7], r_im[4 * 7];
+                    CHECK(gat_sync(ctx));
+                    const int32_t orc = gat_resident_open(ctx, &sig, 1, L, shifts, fs, &rcfg, &rs);
+                    if (orc == GAT_OK) {
+                        for (int r = -50; r < reps; ++r) {
+                            const double t0 = now_us();
+                            CHECK(gat_resident_correlate(rs, &p, 0, r_re, r_im));
+                            if (r >= 0) t[r] = now_us() - t0;
+                        }
+                        gat_resident_info ri;
+                        CHECK(gat_resident_info_get(rs, &ri, sizeof ri));
+                        rwgs = ri.workgroups;
+                        rprompt = r_re[(L / 2) * M];
+                        CHECK(gat_resident_close(rs));
+                        qsort(t, (size_t)reps, sizeof(double), cmp_d);
+                        rmin = t[0];
+                        rmed = t[reps / 2];
+                    } else if (orc != GAT_ERR_UNSUPPORTED) { /* (taps wider than one launch's replica: the ordinary call only) */
+                        CHECK(orc);
+                    }
+                }
+                printf("  %-5s %8d %2d %2d | %6.2f / %6.2f | %6.2f / %6.2f | %6.2f / %6.2f | %6.2f | %5.2f | %6.2f / %6.2f (%2d)   (prompt %.0f / %.0f)\n", grids[gi].system, N, M, L, res[0][0], res[0][1],
+                       res[1][0], res[1][1], res[2][0], res[2][1], per, call_med, rmin, rmed, rwgs, h[(L / 2) * M], rprompt);
                 fflush(stdout);
                 gat_free(ctx, re); gat_free(ctx, im); gat_free(ctx, prm_dev); gat_free(ctx, o_re); gat_free(ctx, o_im);
             }

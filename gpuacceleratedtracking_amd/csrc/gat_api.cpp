@@ -36,11 +36,10 @@ struct gat_resident {
     DcArgs a{};
     DcLaunch cfg{};
     ResidentArgs r{};
-    unsigned char *h_block = nullptr; // pinned: doorbell lines | flag | state | staging for the device block | results
-    unsigned *h_bell = nullptr, *h_flag = nullptr, *h_state = nullptr, *h_init = nullptr;
-    float *h_out_re = nullptr, *h_out_im = nullptr;
-    unsigned *d_block = nullptr;      // device: forwarded doorbell [64] | done_seq (own line) | arrival counter (own line)
-    float *d_partial = nullptr;
+    unsigned char *h_block = nullptr; // pinned: doorbell lines | state | result lines
+    unsigned *h_bell = nullptr, *h_state = nullptr, *h_lines = nullptr, *h_init = nullptr;
+    unsigned *d_quit = nullptr;       // device: the master's "I am leaving" word | eight forwarded doorbells
+    int wgs = 0, lines_per_wg = 0, nval = 0; // working workgroups, result lines and values of each
     unsigned seq = 0;                 // sequence number of the last call
     bool running = false;             // a kernel was started and has not been seen to end
     bool stale = false;               // the code table changed: the correlator has to be opened again
@@ -505,7 +504,8 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         splits = std::max<long long>(1, (target + groups - 1) / groups);
         splits = std::min(splits, chunks);
         // tiny blocks (latency regime): a second launch costs more than a few serial steps
-        if (chunks <= 4 && !(flags & GAT_FLAG_ATOMIC)) splits = 1;
+        // (a resident correlator has no second launch: its workgroups post their sums to the host, which adds them)
+        if (chunks <= 4 && !(flags & GAT_FLAG_ATOMIC) && !plan_out) splits = 1;
         cps = (chunks + splits - 1) / splits;
         splits = (chunks + cps - 1) / cps;
     };
@@ -725,7 +725,10 @@ namespace {
 
 // ---- resident correlator: host side --------------------------------------------------------------------------------
 constexpr size_t kResBellBytes = kInlineParams * kBellDwords * sizeof(unsigned); // 256
-constexpr size_t kResDevBlockBytes = kResBellBytes + 128;                          // + done_seq line + counter line
+constexpr size_t kResDevBytes = 64 + 8 * kResBellBytes;                          // "leaving" word (own line) | eight forwarded doorbells
+// up to this many workgroups poll the host's doorbell themselves (gat_resident.h; 17 workgroups: 6.0 / 6.4 us polling
+// directly, 5.7 / 7.4 forwarded; 33: 10.5 / 11.7 directly, 6.7 / 7.4 forwarded -- profiles/r04/r04r_*)
+constexpr int kResHostPollers = 20;
 
 double mono_us()
 {
@@ -758,10 +761,10 @@ int32_t resident_start(gat_resident *res, unsigned start_seq)
     gat_ctx *c = res->ctx;
     __atomic_store_n(&res->h_state[0], (unsigned)kResidentRuns, __ATOMIC_RELEASE);
     res->h_state[1] = 0;
-    std::memset(res->h_init, 0, kResDevBlockBytes);
-    res->h_init[0] = start_seq;                            // forwarded doorbell: nothing newer than start_seq
-    res->h_init[kResBellBytes / sizeof(unsigned)] = start_seq; // done_seq: that call is finished
-    GAT_HIP(c, hipMemcpyAsync(res->d_block, res->h_init, kResDevBlockBytes, hipMemcpyHostToDevice, res->stream));
+    // device words: the master's "leaving" word = 0; the eight forwarded doorbells say "nothing newer than start_seq"
+    std::memset(res->h_init, 0, kResDevBytes);
+    for (int c8 = 0; c8 < 8; ++c8) res->h_init[16 + c8 * (kInlineParams * kBellDwords)] = start_seq;
+    GAT_HIP(c, hipMemcpyAsync(res->d_quit, res->h_init, kResDevBytes, hipMemcpyHostToDevice, res->stream));
     res->r.start_seq = start_seq;
     res->a.codes = c->d_codes;
     GAT_HIP(c, launch_dc_resident(res->a, res->cfg, res->r, res->stream));
@@ -791,8 +794,7 @@ void park_residents(gat_ctx *c)
 
 void resident_free(gat_resident *res)
 {
-    if (res->d_block) (void)hipFree(res->d_block);
-    if (res->d_partial) (void)hipFree(res->d_partial);
+    if (res->d_quit) (void)hipFree(res->d_quit);
     if (res->h_block) (void)hipHostFree(res->h_block);
     if (res->stream) (void)hipStreamDestroy(res->stream);
     delete res;
@@ -1563,39 +1565,31 @@ GAT_API int32_t gat_resident_open(gat_ctx *c, const gat_signal_desc *sig, int32_
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0) res->ticks_per_us = std::max(1, khz / 1000);
     (void)hipGetLastError();
 
-    // pinned host block: doorbell | flag | state | staging | results
-    const size_t out_floats = ((size_t)K * L * res->M + 15) & ~size_t(15);
-    const size_t host_bytes = kResBellBytes + 64 + 64 + kResDevBlockBytes + 2 * out_floats * sizeof(float);
+    // pinned host block: doorbell | state | result lines of every workgroup
+    res->wgs = (int)plan.a.total_wgs;
+    res->nval = 2 * plan.cfg.ant_tile * plan.cfg.taps;
+    res->lines_per_wg = (res->nval + kResLinePayload - 1) / kResLinePayload;
+    const size_t host_bytes = kResBellBytes + 64 + kResDevBytes + (size_t)res->wgs * res->lines_per_wg * 64;
     hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&res->h_block), host_bytes, hipHostMallocCoherent | hipHostMallocMapped);
     if (e != hipSuccess) return bail(hipfail(c, e, "hipHostMalloc"));
     std::memset(res->h_block, 0, host_bytes);
     unsigned char *d_host = nullptr;
     if ((e = hipHostGetDevicePointer(reinterpret_cast<void **>(&d_host), res->h_block, 0)) != hipSuccess) return bail(hipfail(c, e, "hipHostGetDevicePointer"));
-    size_t off = 0;
-    auto carve = [&](size_t bytes, unsigned char **host, unsigned char **dev) {
-        *host = res->h_block + off;
-        *dev = d_host + off;
-        off += bytes;
-    };
-    unsigned char *h = nullptr, *d = nullptr;
-    carve(kResBellBytes, &h, &d); res->h_bell = reinterpret_cast<unsigned *>(h); res->r.host_bell = reinterpret_cast<const unsigned *>(d);
-    carve(64, &h, &d); res->h_flag = reinterpret_cast<unsigned *>(h); res->r.host_flag = reinterpret_cast<unsigned *>(d);
-    carve(64, &h, &d); res->h_state = reinterpret_cast<unsigned *>(h); res->r.host_state = reinterpret_cast<unsigned *>(d);
-    carve(kResDevBlockBytes, &h, &d); res->h_init = reinterpret_cast<unsigned *>(h);
-    carve(out_floats * sizeof(float), &h, &d); res->h_out_re = reinterpret_cast<float *>(h); res->r.host_out_re = reinterpret_cast<float *>(d);
-    carve(out_floats * sizeof(float), &h, &d); res->h_out_im = reinterpret_cast<float *>(h); res->r.host_out_im = reinterpret_cast<float *>(d);
-
-    if ((e = hipMalloc(reinterpret_cast<void **>(&res->d_block), kResDevBlockBytes)) != hipSuccess) return bail(hipfail(c, e, "hipMalloc"));
-    res->r.dev_bell = res->d_block;
-    res->r.dev_done_seq = res->d_block + kResBellBytes / sizeof(unsigned);
-    res->r.done_counter = res->d_block + kResBellBytes / sizeof(unsigned) + 16;
-    if (res->a.splits > 1) {
-        const size_t pb = (size_t)K * res->a.splits * L * res->M * 2 * sizeof(float);
-        if ((e = hipMalloc(reinterpret_cast<void **>(&res->d_partial), pb)) != hipSuccess) return bail(hipfail(c, e, "hipMalloc"));
-    }
-    res->a.partial = res->d_partial;
-    res->a.out_re = res->r.host_out_re; // one split: the workgroups store their results straight into host memory
-    res->a.out_im = res->r.host_out_im;
+    res->h_bell = reinterpret_cast<unsigned *>(res->h_block);
+    res->r.host_bell = reinterpret_cast<const unsigned *>(d_host);
+    res->h_state = reinterpret_cast<unsigned *>(res->h_block + kResBellBytes);
+    res->r.host_state = reinterpret_cast<unsigned *>(d_host + kResBellBytes);
+    res->h_init = reinterpret_cast<unsigned *>(res->h_block + kResBellBytes + 64); // staging of the device words' start values
+    res->h_lines = reinterpret_cast<unsigned *>(res->h_block + kResBellBytes + 64 + kResDevBytes);
+    res->r.host_lines = reinterpret_cast<unsigned *>(d_host + kResBellBytes + 64 + kResDevBytes);
+    if ((e = hipMalloc(reinterpret_cast<void **>(&res->d_quit), kResDevBytes)) != hipSuccess) return bail(hipfail(c, e, "hipMalloc"));
+    res->r.dev_quit = res->d_quit;
+    res->r.dev_bell = res->d_quit + 16;
+    res->r.forward = res->wgs > (cf.host_pollers ? (int)cf.host_pollers : kResHostPollers) ? 1 : 0;
+    // the body posts its sums through LDS: it stores nothing to device or host memory itself
+    res->a.partial = nullptr;
+    res->a.out_re = nullptr;
+    res->a.out_im = nullptr;
     res->a.done_counter = nullptr;
     res->a.host_flag = nullptr;
     res->r.max_calls = res->max_calls;
@@ -1648,14 +1642,26 @@ GAT_API int32_t gat_resident_correlate(gat_resident *res, const gat_channel_para
         GAT_HIP(c, hipSetDevice(c->device));
         if ((rc = resident_start(res, prev)) != GAT_OK) return rc;
     }
-    // wait: the kernel stores the call's number after its results (system-scope release)
+    // wait: every result line of every workgroup carries the call's number and passes its check
+    const int nlines = res->wgs * res->lines_per_wg;
+    auto answered = [&]() {
+        const unsigned *ln = res->h_lines;
+        for (int j = nlines - 1; j >= 0; --j) { // (the last line first: the first workgroups tend to be done first)
+            if (__atomic_load_n(&ln[(size_t)j * 16 + 15], __ATOMIC_RELAXED) != seq) return false;
+            unsigned x = seq;
+            for (int i = 0; i < kResLinePayload; ++i) x ^= __atomic_load_n(&ln[(size_t)j * 16 + i], __ATOMIC_RELAXED);
+            if (__atomic_load_n(&ln[(size_t)j * 16 + 14], __ATOMIC_RELAXED) != x) return false;
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        return true;
+    };
     const double t0 = mono_us(), deadline = (double)res->life_ms * 1000.0 + 1.0e6;
     for (unsigned spins = 0;; ++spins) {
-        if (__atomic_load_n(res->h_flag, __ATOMIC_ACQUIRE) == seq) break;
-        if ((spins & 63u) != 63u) continue;
+        if (answered()) break;
+        if ((spins & 15u) != 15u) continue;
         if (__atomic_load_n(&res->h_state[0], __ATOMIC_ACQUIRE) != kResidentRuns) {
             // the kernel has left (idle, lifetime, call budget) -- with this call served or not
-            if (__atomic_load_n(res->h_flag, __ATOMIC_ACQUIRE) == seq) break;
+            if (answered()) break;
             res->last_exit = res->h_state[0];
             GAT_HIP(c, hipSetDevice(c->device));
             if ((rc = resident_start(res, prev)) != GAT_OK) return rc;
@@ -1665,9 +1671,24 @@ GAT_API int32_t gat_resident_correlate(gat_resident *res, const gat_channel_para
             return fail(c, GAT_ERR_STATE, "resident correlator: no answer from the device");
         }
     }
+    // second stage on the host: the workgroups' sums added split by split in fixed order (deterministic)
     const size_t n = (size_t)res->K * res->L * res->M;
-    std::memcpy(out_re_host, res->h_out_re, n * sizeof(float));
-    std::memcpy(out_im_host, res->h_out_im, n * sizeof(float));
+    std::memset(out_re_host, 0, n * sizeof(float));
+    std::memset(out_im_host, 0, n * sizeof(float));
+    const int MT = res->cfg.ant_tile, KG = res->a.KG, AG = res->a.ant_groups, SP = res->a.splits;
+    const float *lines = reinterpret_cast<const float *>(res->h_lines);
+    for (int sp = 0; sp < SP; ++sp)
+        for (int ag = 0; ag < AG; ++ag)
+            for (int kg = 0; kg < KG; ++kg) {
+                const size_t slot = ((size_t)ag * SP + sp) * KG + kg; // the kernel's: tile * KG + kg, tile = ag * splits + split
+                const float *w = lines + slot * res->lines_per_wg * 16;
+                for (int o = 0; o < res->nval; ++o) {
+                    const float v = w[(o / kResLinePayload) * 16 + o % kResLinePayload];
+                    const int ml = o >> 1, m = ag * MT + ml % MT, l = res->a.tap_index[ml / MT];
+                    float *dst = (o & 1) ? out_im_host : out_re_host;
+                    dst[((size_t)kg * res->L + l) * res->M + m] += v;
+                }
+            }
     ++res->calls;
     return GAT_OK;
 }
@@ -1700,6 +1721,10 @@ GAT_API int32_t gat_resident_close(gat_resident *res)
     gat_ctx *c = res->ctx;
     (void)hipSetDevice(c->device);
     const int32_t rc = resident_park(res);
+#ifdef GAT_RES_STAMPS
+    std::fprintf(stderr, "resident stamps of the last call (10 ns ticks since the ring was seen): acquire+preload %u, setup %u, first segment %u, steps %u, reduction %u, flag %u\n",
+                 res->h_state[4 + 1], res->h_state[4 + 2], res->h_state[4 + 3], res->h_state[4 + 4], res->h_state[4 + 5], res->h_state[4 + 6]);
+#endif
     c->residents.erase(std::remove(c->residents.begin(), c->residents.end(), res), c->residents.end());
     resident_free(res);
     return rc;

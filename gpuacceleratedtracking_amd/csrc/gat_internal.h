@@ -8,9 +8,10 @@
 
 // Diagnostic code (ablations, latency cuts, cycle stamps: kernels that compute WRONG results on purpose) and the
 // environment knobs of gat_create exist in development builds only; gat_version() names every flag of a build.
-#if (defined(GAT_DC_ABLATE) || defined(GAT_DC_LAT_CUT) || defined(GAT_ABLATE) || defined(GAT_MFMA_STAMPS) || defined(GAT_MB_CW8)) && \
+#if (defined(GAT_DC_ABLATE) || defined(GAT_DC_LAT_CUT) || defined(GAT_ABLATE) || defined(GAT_MFMA_STAMPS) || defined(GAT_MB_CW8) || \
+     defined(GAT_RES_STAMPS)) &&                                                                                                   \
     !defined(GAT_DEV)
-#error "diagnostic builds (-DGAT_DC_ABLATE, -DGAT_DC_LAT_CUT, -DGAT_ABLATE, -DGAT_MFMA_STAMPS, -DGAT_MB_CW8) need -DGAT_DEV"
+#error "diagnostic builds (-DGAT_DC_ABLATE, -DGAT_DC_LAT_CUT, -DGAT_ABLATE, -DGAT_MFMA_STAMPS, -DGAT_MB_CW8, -DGAT_RES_STAMPS) need -DGAT_DEV"
 #endif
 
 namespace gat {
@@ -111,21 +112,24 @@ struct DcLaunch {
 };
 // ---- resident correlator (gat_resident.h): calls without a launch ----------------------------------------------------
 // One bounded-lifetime kernel stays on the device and serves single-block calls that the host rings in through a
-// doorbell in pinned host memory; results and the completion flag go back to pinned host memory.
+// doorbell in pinned host memory; every workgroup posts its sums to pinned host memory as result lines.
 // Doorbell: one 64-byte line per channel (K <= kInlineParams lines, written by the host in descending order, line 0 last):
 //   dword 0 seq | 1 reserved | 2..11 gat_channel_params | 12..13 block offset in samples (int64) | 14 check | 15 seq
 // check = XOR of dwords 0..13: a poll that catches a line half-written fails the check and is repeated.
+// Result lines: workgroup `slot` (tile * KG + channel group, the body's decode of blockIdx) owns ceil(2 MT L / 14) lines of
+//   14 values | check = XOR of the 14 values and seq | seq
+// its value o is the sum for (tap l, antenna m of its tile, re / im) = (o / 2 / MT, o / 2 % MT, o % 2).  Written with plain
+// stores and no fence: the host takes a call's results when every line carries the call's number and passes its check.
 constexpr int kBellDwords = 16;
 constexpr unsigned kBellQuit = 0xffffffffu; // never a call's sequence number
+constexpr int kResLinePayload = 14;
 struct ResidentArgs {
     const unsigned *host_bell; // pinned host (device address): [K][16]
-    unsigned *dev_bell;        // device: the master workgroup's copy for the other workgroups (total_wgs > 1)
-    unsigned *dev_done_seq;    // device: sequence number of the last call all workgroups have finished
-    unsigned *done_counter;    // device: arrival counter
-    unsigned *host_flag;       // pinned host: sequence number of the last finished call (results are in place)
-    unsigned *host_state;      // pinned host: [0] why the kernel ended (0: it runs), [1] calls it served
-    float *host_out_re;        // pinned host: [K][Ltot][M]
-    float *host_out_im;
+    unsigned *host_lines;      // pinned host: [workgroups][lines per workgroup][16]
+    unsigned *host_state;      // pinned host: [0] why the kernel ended (0: it runs), [1] calls the master served
+    unsigned *dev_quit;        // device: set by the master when it leaves (every workgroup polls the host: forward == 0)
+    unsigned *dev_bell;        // device: [8][K lines] copies of the doorbell written by the master (forward != 0)
+    int forward;               // 1: only the master polls the host and forwards; 0: every workgroup polls the host
     unsigned start_seq;        // sequence number of the last call served before this launch
     unsigned max_calls;        // the kernel ends after this many calls ...
     long long idle_ticks;      // ... or this long without one (100 MHz wall clock) ...

@@ -3,21 +3,28 @@
 // The reference times ONE 1 ms block per call (src/benchmarks.jl:120-146); on this platform a launch plus the wait for its
 // end costs 7 us before the kernel has done anything (scripts/probes/sync_probe.hip), a doorbell in pinned host memory that
 // a kernel already on the device polls costs 2-3 us there and back (scripts/probes/doorbell_probe.hip).  dc_resident_kernel
-// is the fused correlator of gat_dc.h (the same body, gat_dc_body.inc) inside a loop:
+// is the fused correlator of gat_dc.h (the same body, gat_dc_body.inc) inside a loop, and every workgroup of it is on its
+// own:
 //
 //   poll the doorbell -> the call's channel records and block offset arrive WITH the ring (one 64-byte line per channel)
 //   -> system-scope acquire (the signal may have been rewritten by a copy engine or another kernel since the last call)
-//   -> correlate -> results into pinned host memory -> release store of the call's sequence number -> poll again.
+//   -> correlate this workgroup's share (antenna tile, channel, sample split) -> post its sums to the host as result lines
+//   (64 bytes: 14 values | check | the call's number; plain stores, no fence, nothing to wait for) -> poll again.
 //
+// The host takes a call's results when every line of every workgroup carries the call's number and passes its check, and
+// adds the sample splits in fixed order (the second stage of the ordinary call, on ~100 floats).  No workgroup exchanges
+// anything with another one: no arrival counter, no release / acquire pair, no partial sums in device memory -- each of
+// those was a trip through the memory system on the critical path (0.5-1.2 us apiece, profiles/r04/r04r_*).
 // Chip tables stay staged in LDS from call to call; the kernel's arguments are read once.
 //
 // Lifetime: the kernel ends BY ITSELF, whatever the host does -- after `max_calls` calls, after `idle_ticks` without a
-// ring, after `life_ticks` in total, or when the host rings kBellQuit.  Only workgroup 0 (the master) polls host memory and
-// only it decides to leave; with several workgroups it copies every ring (and its decision to leave) into a doorbell in
-// device memory that the others poll, and it leaves only when the call it forwarded last has been finished by all of them
-// -- a forwarded ring is never left half served.  The other workgroups leave when told to, or when 1.5 x life_ticks have
-// passed (the master can no longer be there).  No workgroup ever waits for another one to make progress: every wait in
-// here is a poll with a deadline on the constant 100 MHz clock, so the grid drains even if workgroups never run together.
+// ring, after `life_ticks` in total, or when the host rings kBellQuit.  Workgroup 0 (the master) decides: it sets a word
+// in device memory that the others read with every poll (or, when it forwards the rings, puts kBellQuit into the
+// forwarded doorbells), and tells the host why it left.  The others leave when that word
+// is set, or when 1.5 x life_ticks have passed (the master can no longer be there).  Every wait in here is a poll with a
+// deadline on the constant 100 MHz clock: the grid drains even if its workgroups never run together.  A ring that arrives
+// while the master is leaving may be served by some workgroups and not by others: the host sees the kernel gone and the
+// call unanswered, starts the kernel again and the call is served whole (same values: the results are deterministic).
 //
 // Which shapes: one block per call, K <= 4 channels, one tap launch, 16-byte aligned block starts with N a multiple of the
 // load group (what runs as ONE vector launch otherwise); antennas in tiles of MT <= 4, one tile per workgroup (AW = KT = 1).
@@ -31,6 +38,7 @@ constexpr bool dc_resident_instance(int mt, int l) { return dc_instance(mt, l, 4
 
 struct ResidentEnv {
     const unsigned *line; // LDS: the call's doorbell lines
+    float *stage;         // LDS: the workgroup's sums, in the order of the body's output loop (value o = 2 * (l * MT + m) + comp)
     __device__ __forceinline__ gat_channel_params params(int k) const
     {
         const unsigned *w = line + k * kBellDwords;
@@ -57,16 +65,18 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
 {
     constexpr int VEC = 4, AW = 1, KT = 1, NW = 4, D = 1;
     constexpr bool KEEP = false;
+    constexpr int NVAL = 2 * MT * L;                                          // sums one workgroup posts per call
+    constexpr int LW = (NVAL + kResLinePayload - 1) / kResLinePayload;        // its result lines
     __shared__ unsigned s_bell[kInlineParams * kBellDwords];
-    __shared__ unsigned s_ctl[2]; // [0] the call's sequence number or kBellQuit, [1] this workgroup arrived last
+    __shared__ unsigned s_ctl[1]; // the call's sequence number or kBellQuit
+    __shared__ float s_out[64];
 
     kernarg_prefetch<sizeof(DcArgs) + sizeof(ResidentArgs)>();
-    { // padding of the grid (same decode as the body's)
-        const unsigned tile0 = ((blockIdx.x >> 3) / (unsigned)a.KG) * 8u + (blockIdx.x & 7u);
-        if (tile0 >= (unsigned)a.num_tiles) return;
-    }
+    // the working workgroup's ordinal (the body's decode of blockIdx: tile, channel group); padding of the grid leaves
+    const unsigned tile0 = ((blockIdx.x >> 3) / (unsigned)a.KG) * 8u + (blockIdx.x & 7u);
+    if (tile0 >= (unsigned)a.num_tiles) return;
+    const unsigned slot = tile0 * (unsigned)a.KG + (blockIdx.x >> 3) % (unsigned)a.KG;
     const bool master = blockIdx.x == 0;
-    const bool alone = a.total_wgs == 1u;
     const int K = a.K;
     int staged_prn[KT];
 #pragma unroll
@@ -74,21 +84,28 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
     unsigned last = r.start_seq, calls = 0, why = kResidentRuns;
     const long long t_start = wall_clock64();
     long long t_last = t_start;
-    const ResidentEnv env{s_bell};
+    const ResidentEnv env{s_bell, s_out};
 
     for (;;) {
-        // ---- wait for a ring: wave 0 reads all K lines with ONE load (lane i <-> dword i)
+        // ---- wait for a ring: wave 0 reads all K lines with ONE load (lane i <-> dword i).  Few workgroups: every one polls
+        // the host's doorbell itself (nothing between the ring and any workgroup).  Many: reads of one host line queue up
+        // behind each other (~0.15 us apiece: 33 pollers took 10 us to see a ring), so only the master polls the host and
+        // copies what it sees -- rings and its decision to leave -- into eight doorbells in device memory (one per
+        // blockIdx % 8, on different memory channels) that the others poll.
         if (threadIdx.x < 64) {
             const int ln = (int)threadIdx.x;
-            const unsigned *src = (master ? r.host_bell : r.dev_bell) + ln;
+            const bool from_host = master || r.forward == 0;
+            const unsigned *src = (from_host ? r.host_bell : r.dev_bell + (blockIdx.x & 7u) * (kInlineParams * kBellDwords)) + ln;
             const bool mine = ln < K * kBellDwords;
             unsigned v = 0, seq = last;
             for (;;) {
-                if (mine) v = master ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                                     : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (mine) v = from_host ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                        : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (direct polling: the master's word in device memory is read with the same poll, both loads in flight together)
+                const unsigned leave = (master || r.forward != 0) ? 0u : __hip_atomic_load(r.dev_quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 seq = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+                if (seq == kBellQuit || leave != 0u) { why = kResidentQuit; seq = kBellQuit; break; }
                 if (seq != last) {
-                    if (seq == kBellQuit) { why = kResidentQuit; break; }
                     // every line whole and of this ring: first and last dword = seq, XOR of dwords 0..13 = dword 14
                     unsigned x = (ln & 15) < 14 ? v : 0u;
                     x ^= __shfl_xor(x, 8, 64); x ^= __shfl_xor(x, 4, 64); x ^= __shfl_xor(x, 2, 64); x ^= __shfl_xor(x, 1, 64);
@@ -99,25 +116,27 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
                 }
                 const long long now = wall_clock64();
                 if (master) {
-                    // the master leaves only between calls: the one it forwarded last is finished by every workgroup
                     unsigned reason = kResidentRuns;
                     if (calls >= r.max_calls) reason = kResidentCalls;
                     else if (now - t_last > r.idle_ticks) reason = kResidentIdle;
                     else if (now - t_start > r.life_ticks) reason = kResidentLife;
-                    if (reason != kResidentRuns) {
-                        const bool finished = alone || __hip_atomic_load(r.dev_done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == last;
-                        if (finished || now - t_start > r.life_ticks + (r.life_ticks >> 2)) { why = reason; seq = kBellQuit; break; }
-                    }
-                } else if (now - t_start > r.life_ticks + (r.life_ticks >> 1)) { // the master is gone: nobody will ring again
+                    if (reason != kResidentRuns) { why = reason; seq = kBellQuit; break; }
+                } else if (now - t_start > r.life_ticks + (r.life_ticks >> 1)) { // the master is gone and has not said so
                     why = kResidentLife;
                     seq = kBellQuit;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
             }
-            if (master && !alone) { // pass the ring (or the decision to leave) on
-                const unsigned fwd = (seq == kBellQuit && ln == 0) ? kBellQuit : v;
-                if (mine) __hip_atomic_store(r.dev_bell + ln, fwd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (master) {
+                if (r.forward != 0) { // the ring, or the decision to leave, to the eight device doorbells
+                    const unsigned fwd = (seq == kBellQuit && ln == 0) ? kBellQuit : v;
+                    if (mine)
+                        for (int c8 = 0; c8 < 8; ++c8)
+                            __hip_atomic_store(r.dev_bell + c8 * (kInlineParams * kBellDwords) + ln, fwd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (seq == kBellQuit && ln == 0) {
+                    __hip_atomic_store(r.dev_quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             s_bell[ln] = v;
             if (ln == 0) s_ctl[0] = seq;
@@ -130,55 +149,34 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
         // nothing of it may come from this XCD's caches
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 
+#ifdef GAT_RES_STAMPS // development builds: where a call's time goes (100 MHz clock), read back by gat_resident_close
+        long long st_[8] = {};
+        st_[0] = wall_clock64();
+#undef GAT_DC_LAT_CUT_AT
+#define GAT_DC_LAT_CUT_AT(n) do { st_[n] = wall_clock64(); } while (0)
+#endif
         { // the correlator itself: the text dc_kernel is made of
 #define GAT_DC_BODY_RESIDENT 1
 #include "gat_dc_body.inc"
 #undef GAT_DC_BODY_RESIDENT
         }
 
-        // ---- completion: the results (splits == 1: written to host memory by the body; else partial sums in device memory)
+        // ---- this workgroup's NVAL sums (staged in LDS by the body) go to the host as LW result lines
         __syncthreads();
-        bool last_wg = true;
-        if (!alone) {
-            if (threadIdx.x == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); // this workgroup's stores: out of its XCD, on their way to the host
-                const unsigned arrived = __hip_atomic_fetch_add(r.done_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-                s_ctl[1] = arrived == a.total_wgs - 1u ? 1u : 0u;
-            }
-            __syncthreads();
-            last_wg = uni(s_ctl[1]) != 0u;
+        for (int t = (int)threadIdx.x; t < LW * 16; t += 256) {
+            const int i = t & 15, pidx = (t >> 4) * kResLinePayload + i;
+            unsigned v = (i < kResLinePayload && pidx < NVAL) ? __float_as_uint(s_out[pidx]) : 0u;
+            unsigned x = i < kResLinePayload ? v : 0u;
+            x ^= __shfl_xor(x, 8, 64); x ^= __shfl_xor(x, 4, 64); x ^= __shfl_xor(x, 2, 64); x ^= __shfl_xor(x, 1, 64);
+            if (i == 14) v = x ^ seq;
+            if (i == 15) v = seq;
+            __hip_atomic_store(r.host_lines + (size_t)slot * (LW * 16) + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        if (last_wg) {
-            if (a.splits > 1) {
-                // second stage: the order of finalize_few_kernel (four interleaved chains, (0+1)+(2+3)): deterministic
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                const int elems = a.Ltot * a.M * 2, total = K * elems, splits = a.splits;
-                for (int o = (int)threadIdx.x; o < total; o += 256) {
-                    const int g = o / elems, e = o - g * elems;
-                    const float *p = a.partial + (size_t)g * splits * elems + e;
-                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-                    int i = 0;
-                    for (; i + 4 <= splits; i += 4) {
-                        s0 += p[(size_t)(i + 0) * elems];
-                        s1 += p[(size_t)(i + 1) * elems];
-                        s2 += p[(size_t)(i + 2) * elems];
-                        s3 += p[(size_t)(i + 3) * elems];
-                    }
-                    if (i < splits) s0 += p[(size_t)i * elems];
-                    if (i + 1 < splits) s1 += p[(size_t)(i + 1) * elems];
-                    if (i + 2 < splits) s2 += p[(size_t)(i + 2) * elems];
-                    ((e & 1) ? r.host_out_im : r.host_out_re)[(size_t)g * (elems / 2) + (e >> 1)] = (s0 + s1) + (s2 + s3);
-                }
-                __syncthreads();
-            }
-            if (threadIdx.x == 0) {
-                if (!alone) {
-                    __hip_atomic_store(r.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(r.dev_done_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __hip_atomic_store(r.host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
+#ifdef GAT_RES_STAMPS
+        st_[6] = wall_clock64();
+        if (master && threadIdx.x == 0)
+            for (int i = 0; i < 7; ++i) r.host_state[4 + i] = (unsigned)(st_[i] - st_[0]);
+#endif
         ++calls;
         t_last = wall_clock64();
     }

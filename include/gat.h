@@ -390,6 +390,8 @@ typedef struct gat_resident_config {
     uint32_t life_ms;        /* ... and after this long whatever happens                (0: default, 2 000 ms)   */
     uint32_t max_calls;      /* ... and after this many calls                           (0: no limit)            */
     uint32_t max_workgroups; /* workgroups one block's samples may be split over        (0: default, 64)         */
+    uint32_t host_pollers;   /* up to this many workgroups poll the host's doorbell themselves; with more, one does and    */
+                             /* forwards the ring through device memory                 (0: default, 20)         */
 } gat_resident_config;
 typedef struct gat_resident_info {
     int32_t workgroups;  /* workgroups of the resident kernel (sample splits x antenna tiles x channels)          */

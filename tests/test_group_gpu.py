@@ -191,7 +191,8 @@ def test_native_latency_example_and_completion_flag(gat):
     """examples/gat_latency.c: the harness's timed body from plain C on a library-owned stream -- every grid point runs the
     host-parameter call, the device-parameter call (completion flag: gat_sync spins on the sequence number the launch's
     last workgroup stores into pinned host memory) and the hipGraph replay; each point prints the prompt correlation, which
-    must be N (noise-free signal, zero phases): a flag that fired before the results were out would show here."""
+    must be N (noise-free signal, zero phases): a flag that fired before the results were out would show here.  The same
+    call through a resident correlator (no launch: rung into a kernel that stays on the device) prints its prompt too."""
     import re
     from gpuacceleratedtracking_amd import build
     exe = build.build_c_example(name="gat_latency")
@@ -202,10 +203,15 @@ def test_native_latency_example_and_completion_flag(gat):
     assert sum(ln.split()[0] == "GPSL5" for ln in rows) == 8
     for ln in rows:
         n = int(ln.split()[1])
-        m = re.search(r"\(prompt (\d+)\)", ln)
+        m = re.search(r"\(prompt (\d+) / (\d+)\)", ln)
         assert m and int(m.group(1)) == n, ln
         dev_min = float(ln.split("|")[2].split("/")[0])
         assert 3.0 < dev_min < 200.0, ln  # microseconds: a call + sync is neither free nor a stall
+        res_min, wgs = float(ln.split("|")[6].split("/")[0]), int(re.search(r"\(\s*(\d+)\)", ln.split("|")[6]).group(1))
+        if wgs:  # (seven taps at 262 MHz span more than one launch's replica: no resident correlator for that point)
+            assert int(m.group(2)) == n and 1.0 < res_min < 200.0, ln
+        else:
+            assert n == 262144 and ln.split()[3] == "7", ln
 
 
 def test_sync_after_flagged_launch_sees_results_and_later_work_falls_back(gat):

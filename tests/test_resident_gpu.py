@@ -1,7 +1,8 @@
 """Resident correlator (include/gat.h gat_resident_*; kernel gat_resident.h): single-block calls rung into a kernel that
 stays on the device -- parity with the FP64 oracle through every path of the doorbell protocol (one workgroup, several
-workgroups with the forwarded doorbell and the in-kernel second stage, several channels, block offsets), visibility of a
-signal rewritten between calls, and the kernel's bounded lifetime (idle exit, call budget, park, restart).  Run with -m gpu."""
+workgroups polling the host's doorbell or a forwarded one, the host's second stage over their result lines, several
+channels, block offsets), visibility of a signal rewritten between calls, and the kernel's bounded lifetime (idle exit,
+call budget, park, restart).  Run with -m gpu."""
 import time
 
 import numpy as np
@@ -46,22 +47,25 @@ def _open(g, case, layout=0, **config):
     return ctx, res
 
 
-@pytest.mark.parametrize("N,M,L,K,layout,max_wgs", [
-    (2048, 4, 3, 1, 0, 0),     # one workgroup: the reference grid's smallest point
-    (2048, 1, 7, 1, 0, 0),
-    (4096, 4, 3, 1, 1, 0),     # ComplexF32 pairs
-    (32768, 4, 3, 1, 0, 0),    # sample splits: forwarded doorbell, in-kernel second stage
-    (32768, 1, 3, 1, 1, 8),
-    (16384, 16, 3, 1, 0, 16),  # four antenna tiles x splits
-    (8192, 2, 5, 3, 0, 0),     # three channels: three doorbell lines, channel workgroups
-    (2500 - 2500 % 4, 3, 3, 4, 0, 0),
-    (262144, 4, 3, 1, 0, 0),   # the grid's largest point
+@pytest.mark.parametrize("N,M,L,K,layout,max_wgs,pollers", [
+    (2048, 4, 3, 1, 0, 1, 0),     # ONE workgroup: the reference grid's smallest point
+    (2048, 4, 3, 1, 0, 0, 0),     # the same split over workgroups that all poll the host's doorbell
+    (2048, 1, 7, 1, 0, 0, 0),
+    (4096, 4, 3, 1, 1, 0, 0),     # ComplexF32 pairs
+    (4096, 4, 8, 1, 0, 0, 1),     # 64 sums per workgroup (five result lines); the master forwards the ring
+    (32768, 4, 3, 1, 0, 0, 0),    # 33 workgroups: forwarded doorbell
+    (32768, 4, 3, 1, 0, 0, 64),   # ... and all 33 polling the host
+    (32768, 1, 3, 1, 1, 8, 0),
+    (16384, 16, 3, 1, 0, 16, 0),  # four antenna tiles x splits
+    (8192, 2, 5, 3, 0, 0, 0),     # three channels: three doorbell lines, channel workgroups
+    (2500 - 2500 % 4, 3, 3, 4, 0, 0, 0),
+    (262144, 4, 3, 1, 0, 0, 0),   # the grid's largest point
 ])
-def test_resident_matches_oracle(gat, N, M, L, K, layout, max_wgs):
+def test_resident_matches_oracle(gat, N, M, L, K, layout, max_wgs, pollers):
     g = gat
     case = make_case(900 + N % 97 + M + K, N=N, M=M, L=L, K=K, B=3)
     ref = oracle_result(case)
-    ctx, res = _open(g, case, layout, max_workgroups=max_wgs, idle_us=200000)
+    ctx, res = _open(g, case, layout, max_workgroups=max_wgs, host_pollers=pollers, idle_us=200000)
     try:
         info = res.info()
         assert info["running"] == 1 and info["launches"] == 1
