@@ -67,6 +67,9 @@ ALGODICT = {
     # this build's own entry: the fused HIP path under its own name
     "hip_fused": 9000,
     "hip_fused_atomic": 9001,
+    # the same kernel body inside a kernel that stays on the device: a call is a doorbell ring, not a launch
+    # (gat_resident_*, include/gat.h) -- the benchmark harness's timed call only, not a kernel_algorithm form
+    "hip_resident": 9002,
 }
 # src/GPUAcceleratedTracking.jl:63-72
 REDDICT = {"pure": ReductionAlgorithm(1), "cplx": ReductionAlgorithm(2), "cplx_multi": ReductionAlgorithm(3)}
@@ -79,7 +82,7 @@ ALGODICTINV = {
     2330: "2_3_cplx_multi", 2331: "2_3_cplx_multi_textmem", 2430: "2_4_cplx_multi",
     2431: "2_4_cplx_multi_textmem", 3430: "3_4_cplx_multi", 3431: "3_4_cplx_multi_textmem",
     4431: "4_4_cplx_multi_textmem", 5431: "5_4_cplx_multi_textmem",
-    9000: "hip_fused", 9001: "hip_fused_atomic",
+    9000: "hip_fused", 9001: "hip_fused_atomic", 9002: "hip_resident",
 }
 
 _FORM_A = {1330, 1331, 1431}                     # ..., partial_sum, carrier.., 25 positional

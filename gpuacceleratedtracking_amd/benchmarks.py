@@ -93,6 +93,29 @@ def _run_kernel_benchmark(gnss, num_samples: int, num_ants: int, num_correlators
     op.set_params(make_params(prn - 1, code_frequency, carrier_frequency, start_code_phase, carrier_phase, shape=(1, 1)))
     desc = op.describe(signal.re, signal.im)
     torch.cuda.synchronize()  # inputs and parameters were produced on PyTorch's stream; ctx runs on its own
+    if algorithm.id == ALGODICT["hip_resident"]:
+        # the call rung into a resident kernel: what is timed is ring + wait + the outputs' copy to the host (the
+        # reference's timed call leaves them on the device and its receiver loop copies them afterwards)
+        prm = make_params(prn - 1, code_frequency, carrier_frequency, start_code_phase, carrier_phase, shape=(1,))
+        with ctx.open_resident(desc, 1, shifts, fs, idle_us=200000, life_ms=60000) as res:
+            for _ in range(3):
+                res.correlate(prm)
+            times = []
+            t_end = time.perf_counter() + seconds
+            while len(times) < max_samples and (time.perf_counter() < t_end or len(times) < 10):
+                t0 = time.perf_counter_ns()
+                res.correlate(prm)
+                times.append(time.perf_counter_ns() - t0)
+            re, im = res.correlate(prm)
+            out = (re + 1j * im).astype(np.complex64)[None]  # [1, K, L, M]: StreamCorrelator.result()'s shape
+            info = res.info()
+
+        class _Result:  # what run_kernel_benchmark reads from the operator
+            def result(self):
+                return out
+        r = _Result()
+        r.resident_info = info
+        return np.asarray(times, dtype=np.float64), r, ctx
     for _ in range(3):  # warm-up (BenchmarkTools tunes/warms before sampling)
         op.launch(desc)
     ctx.sync()

@@ -51,6 +51,43 @@ function _run_kernel_benchmark(
     return result
 end
 
+# The same scenario through a resident correlator (ALGODICT entry "hip_resident" => 9002): one kernel stays on the device,
+# the timed call is a doorbell ring + the wait for the result lines + the second stage on the host -- no launch, no stream
+# wait, outputs ON THE HOST when it returns (GATHip.Resident; include/gat.h gat_resident_*).
+function _run_kernel_benchmark(
+    gnss,
+    enable_gpu::Val{true},
+    num_samples,
+    num_ants,
+    num_correlators,
+    algorithm::KernelAlgorithm{9002}
+)
+    cpu_system = gnss(use_gpu = Val(false))
+    system = GATHip.HipSystem(cpu_system)
+    code_frequency = get_code_frequency(cpu_system)
+    carrier_frequency = 1500Hz
+    prn = 1
+    signal_cpu, sampling_frequency = gen_signal(cpu_system, prn, carrier_frequency, num_samples,
+        num_ants = NumAnts(num_ants), start_code_phase = 0.0f0, start_carrier_phase = 0.0f0)
+    signal = GATHip.HipSignal(system.ctx, Matrix{Float32}(reshape(signal_cpu.re, num_samples, num_ants)),
+                              Matrix{Float32}(reshape(signal_cpu.im, num_samples, num_ants)))
+    correlator = EarlyPromptLateCorrelator(NumAnts(num_ants), NumAccumulators(num_correlators))
+    correlator_sample_shifts = get_correlator_sample_shifts(cpu_system, correlator, sampling_frequency, 0.5)
+    desc = GATHip.signal_desc(signal, 1, num_samples)
+    GATHip.sync(system.ctx)                              # the signal is on the device before the first ring
+    resident = GATHip.Resident(system.ctx, desc, 1, Int32[correlator_sample_shifts...], Float64(ustrip(Hz, sampling_frequency));
+                               idle_us = 200000, life_ms = 60000)
+    resident.prm[1] = GATHip.ChannelParams(prn - 1, 0, ustrip(Hz, code_frequency), ustrip(Hz, carrier_frequency), 0.0, 0.0)
+    result = @benchmark GATHip.correlate!($resident)
+    close(resident)
+    GATHip.free!(system.ctx, signal)
+    return result
+end
+add_metadata!(benchmark_results_w_params, processor, algorithm::KernelAlgorithm{9002}) = begin
+    add_metadata!(benchmark_results_w_params, processor, KernelAlgorithm(9000))
+    processor == "GPU" ? benchmark_results_w_params["algorithm"] = ALGODICTINV[9002] : nothing
+end
+
 # add_metadata!(benchmark_results_w_params, processor, ::KernelAlgorithm{ALGN}) (src/benchmarks.jl:11-32) for id 9000:
 # more specific than the reference's `where ALGN` method, so `run_kernel_benchmark` (src/benchmarks.jl:977) lands here.
 # Same keys as the reference writes ("os", "CPU_model", "GPU_model", "CUDA", "algorithm" -- `collect_results` builds its

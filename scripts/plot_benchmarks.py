@@ -23,7 +23,7 @@ def sweep_figure(rows, out, cpu_rows=()):
     fig, axes = plt.subplots(2, 3, figsize=(15, 8))
     for ax, (gnss, m, l) in zip(axes.ravel(), panels):
         sel = [r for r in rows if r["GNSS"] == gnss and r["num_ants"] == m and r["num_correlators"] == l]
-        for alg, style in (("hip_fused", "o-"), ("hip_fused_atomic", "s--")):
+        for alg, style in (("hip_fused", "o-"), ("hip_fused_atomic", "s--"), ("hip_resident", "d-")):
             pts = sorted((r["num_samples"] / 1e-3, r["Minimum"] * 1e-9) for r in sel if r["algorithm"] == alg)
             if pts:
                 ax.plot([p[0] for p in pts], [p[1] for p in pts], style, label=f"MI355X {alg} (minimum)")

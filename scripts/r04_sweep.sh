@@ -18,15 +18,21 @@ lib=""
 for line in open("gpurun_out/r04s/sweep_gpu_native.txt"):
     if line.startswith("# one 1 ms"): lib=line.strip().split(";")[-1].strip()
     if line.startswith("#") or "|" not in line: continue
-    head, host, dev, graph, rest = line.split("|")[:5]
+    cols = line.split("|")
+    head, host, dev, graph, rest = cols[:5]
     s, n, m, l = head.split()
-    nat[(s, int(n), int(m), int(l))] = (float(host.split("/")[0]), float(dev.split("/")[0]), float(rest.split()[0]))
+    resn = float(cols[6].split("/")[0]) if len(cols) > 6 else 0.0  # resident correlator, native (0: not served)
+    nat[(s, int(n), int(m), int(l))] = (float(host.split("/")[0]), float(dev.split("/")[0]), float(rest.split()[0]), resn)
 print("# one 1 ms block per call, minimum over repeated calls (BenchmarkTools 'Minimum', paper/paper.tex:150); CPU: %s, one thread; %s" % (c[0]["CPU_model"], lib))
-print("GNSS      N        M L   GPU python us   GPU native host-params / dev-params+flag us   device per call us   CPU us    CPU / GPU native")
+resp={(r["GNSS"],r["num_samples"],r["num_ants"],r["num_correlators"]):r["Minimum"] for r in g if r["algorithm"]=="hip_resident"}
+print("# launch = gat_downconvert_and_correlate + gat_sync (completion flag); resident = gat_resident_correlate (ring + wait + outputs on the host)")
+print("GNSS      N        M L   python: launch / resident us   native: launch host-params / dev-params / resident us   device per call us   CPU us    CPU / launch   CPU / resident")
 for r in g:
     if r["algorithm"]!="hip_fused": continue
     k=(r["GNSS"],r["num_samples"],r["num_ants"],r["num_correlators"])
     n=nat.get(k)
-    print("%-6s %8d %2d %d   %9.2f       %s   %10.2f   %s" % (k[0],k[1],k[2],k[3],r["Minimum"]/1e3,
-          ("%8.2f / %8.2f                  %8.2f   " % n) if n else " "*58, cpu[k]/1e3, ("%6.2f" % (cpu[k]/1e3/n[1])) if n else ""))
+    rp=resp.get(k)
+    print("%-6s %8d %2d %d   %9.2f / %s       %s   %10.2f   %s" % (k[0],k[1],k[2],k[3],r["Minimum"]/1e3, ("%6.2f" % (rp/1e3)) if rp else "     -",
+          ("%8.2f / %8.2f / %s                  %8.2f   " % (n[0], n[1], ("%6.2f" % n[3]) if n[3] else "     -", n[2])) if n else " "*70, cpu[k]/1e3,
+          ("%6.2f          %s" % (cpu[k]/1e3/n[1], ("%6.2f" % (cpu[k]/1e3/n[3])) if n[3] else "     -")) if n else ""))
 PY

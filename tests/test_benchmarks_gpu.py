@@ -32,9 +32,10 @@ def test_run_replica_benchmark(g, alg):
     assert 0 < r["Minimum"] <= r["Median"]
 
 
-def test_run_kernel_benchmark_known_answer(g):
+@pytest.mark.parametrize("alg", ["hip_fused", "hip_resident"])
+def test_run_kernel_benchmark_known_answer(g, alg):
     r = g.run_kernel_benchmark({"processor": "GPU", "GNSS": "GPSL1", "num_samples": 2500, "num_ants": 4,
-                                "num_correlators": 3, "algorithm": "hip_fused"}, seconds=0.02)
+                                "num_correlators": 3, "algorithm": alg}, seconds=0.02)
     assert np.allclose(r["accumulators"][:, 0], [1476, 2500, 1476], rtol=1e-5)  # test/algorithms.jl:85
     for key in ("Minimum", "Median", "Mean", "σ", "Maximum", "RawTimes", "os", "CPU_model", "GPU_model", "algorithm"):
         assert key in r

@@ -163,6 +163,32 @@ def test_resident_lifetime_is_bounded_on_the_device(gat):
         res.close()
 
 
+@pytest.mark.parametrize("N,pollers", [(2048, 0), (16384, 0), (16384, 1), (65536, 0)])
+def test_resident_survives_rings_that_race_with_its_exit(gat, N, pollers):
+    """Calls at random distances around the kernel's idle limit (and a small call budget): some rings arrive while the
+    master is leaving -- served by some workgroups, by none, or by a kernel that is started for them.  Every call must
+    return the same bits, none may hang (the host's own deadline would turn a lost ring into an error)."""
+    g = gat
+    rng = np.random.default_rng(N + pollers)
+    case = make_case(21, N=N, M=4, L=3, K=1, B=1)
+    ctx, res = _open(g, case, idle_us=300, life_ms=50, max_calls=37, host_pollers=pollers)
+    try:
+        prm = _params(g, case, 0)
+        first = tuple(a.copy() for a in res.correlate(prm))
+        check_close((first[0] + 1j * first[1])[None], oracle_result(case))
+        for i in range(400):
+            gap = rng.uniform(0.0, 600e-6)
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < gap:
+                pass
+            re, im = res.correlate(prm)
+            assert np.array_equal(re, first[0]) and np.array_equal(im, first[1]), i
+        info = res.info()
+        assert info["calls"] == 401 and info["launches"] > 5, info  # it did leave and come back many times
+    finally:
+        res.close()
+
+
 def test_resident_is_parked_by_free_and_invalidated_by_new_codes(gat):
     g = gat
     import ctypes as C
