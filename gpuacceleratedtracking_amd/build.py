@@ -14,6 +14,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgat.so")
 SOURCES = ["gat_dc_f0.hip", "gat_dc_f1.hip", "gat_dc_f2.hip", "gat_dc_f3.hip", "gat_resident_f0.hip", "gat_resident_f1.hip",
+           "gat_resident_f2.hip", "gat_resident_f3.hip",
            "gat_kernels.hip", "gat_mfma.hip", "gat_mfma_bf16.hip", "gat_api.cpp", "gat_codes.cpp"]
 # gat_version.cpp is not in SOURCES: it is compiled at every link with the build's identity (git commit, flags)
 HEADERS = [os.path.join(CSRC, "gat_internal.h"), os.path.join(CSRC, "gat_phase.h"), os.path.join(CSRC, "gat_dc.h"),

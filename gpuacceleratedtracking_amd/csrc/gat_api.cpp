@@ -1530,8 +1530,6 @@ GAT_API int32_t gat_resident_open(gat_ctx *c, const gat_signal_desc *sig, int32_
     }
     if (cf.max_workgroups > 1024) return fail(c, GAT_ERR_RANGE, "max_workgroups above 1024");
     GAT_HIP(c, hipSetDevice(c->device));
-    if (sig->layout != GAT_LAYOUT_PLANAR && sig->layout != GAT_LAYOUT_INTERLEAVED)
-        return fail(c, GAT_ERR_UNSUPPORTED, "resident correlator: float samples only (GAT_LAYOUT_PLANAR, GAT_LAYOUT_INTERLEAVED)");
 
     gat_resident *res = new (std::nothrow) gat_resident();
     if (!res) return fail(c, GAT_ERR_NOMEM, "out of memory");
