@@ -466,7 +466,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     int max_taps = 1; // taps of the widest launch (register accumulators 2 * MT * taps * kt)
     for (int t0 = 0; t0 < L;) {
         int t1 = t0 + 1;
-        while (t1 < L && t1 - t0 < kMaxTapsPerLaunch && (long long)shifts[order[t1]] - shifts[order[t0]] <= kMaxReplicaSpan) ++t1;
+        while (t1 < L && t1 - t0 < kMaxTapsPerLaunch && (long long)shifts[order[t1]] - shifts[order[t0]] <= kMaxLaunchSpan) ++t1;
         max_taps = std::max(max_taps, t1 - t0);
         t0 = t1;
     }
@@ -613,7 +613,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     for (int t0 = 0; t0 < L;) {
         int t1 = t0 + 1;
         while (t1 < L && t1 - t0 < kMaxTapsPerLaunch &&
-               (long long)shifts[order[t1]] - shifts[order[t0]] <= kMaxReplicaSpan)
+               (long long)shifts[order[t1]] - shifts[order[t0]] <= kMaxLaunchSpan)
             ++t1;
         cfg.taps = t1 - t0;
         for (int l = 0; l < kMaxTapsPerLaunch; ++l) {
@@ -639,9 +639,16 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             // 10 KB chip tables (GPS L5) the full eight-step segment makes a workgroup 47 KB -- three per CU.  Such launches
             // take a segment short enough for 40 KB (configs[2]: six steps; 1.151 -> 1.106 ms together with the two-sample
             // passes that bring the five-tap instance to 128 registers, profiles/r04/r04g_c2_four_waves.txt).
+            // (a tap span beyond the default sizing -- seven taps half a chip apart at 262 MHz span 768 samples -- gets the
+            // room it needs in the same launch instead of a second launch: 22.8 -> 17 us for that call)
+            const int span_sz = std::max(kMaxReplicaSpan, a.rep_span);
             if (dc_min_waves(MT, cfg.taps, kt, 1, fmt) >= 4)
-                while (seg > 2 && dc_lds_bytes_floats(kt, c->code_row_stride, dc_rep_chan_floats_steps(seg, (int)chunk)) > 40 * 1024) --seg;
-            const int chan_floats = dc_rep_chan_floats_steps(seg, (int)chunk);
+                while (seg > 2 && dc_lds_bytes_floats(kt, c->code_row_stride, dc_rep_chan_floats_steps(seg, (int)chunk, span_sz)) > 40 * 1024) --seg;
+            if (span_sz > kMaxReplicaSpan)
+                while (seg > 1 && dc_lds_bytes_floats(kt, c->code_row_stride, dc_rep_chan_floats_steps(seg, (int)chunk, span_sz)) > 64 * 1024) --seg;
+            const int chan_floats = dc_rep_chan_floats_steps(seg, (int)chunk, span_sz);
+            if (dc_lds_bytes_floats(kt, c->code_row_stride, chan_floats) > 160 * 1024)
+                return fail(c, GAT_ERR_RANGE, "tap span and code table do not fit the LDS of one workgroup");
             a.rep_chan_floats = chan_floats;
             cfg.lds_bytes = (unsigned)dc_lds_bytes_floats(kt, c->code_row_stride, chan_floats);
             if (odd)

@@ -21,8 +21,9 @@ constexpr int kMaxTapsPerLaunch = 8; // taps handled by one launch (register acc
 constexpr int kInlineParams = 4;     // channel parameter records of a host call that travel inside the kernel arguments
 constexpr int kMaxAntTile = 4;       // antennas handled by one workgroup
 constexpr int kFinalizeFewSplits = 32; // second stage: up to this many splits are summed by one thread per output element
-constexpr int kMaxReplicaSpan = 512;  // largest tap span served from the LDS replica segment of one launch (wider tap
-                                      // lists are cut into several launches)
+constexpr int kMaxReplicaSpan = 512;  // tap span the LDS replica segment of a launch is sized for by default
+constexpr int kMaxLaunchSpan = 2048;  // largest tap span one launch serves (the replica's LDS grows with the span beyond
+                                      // kMaxReplicaSpan; wider tap lists are cut into several launches)
 
 // Sample ownership of one lane per step in dc_kernel: G groups of S consecutive samples, one
 // 16-byte load per plane and group (vec == 4) or scalar loads (vec == 1).  S by format:
@@ -162,10 +163,10 @@ constexpr int dc_segment_steps(int chunk, int kt, int mt)
 // then halves the segment so that both fit here.  Room: segment samples + kMaxReplicaSpan taps + one entry per
 // producer thread of overshoot; at least one step with two copies.
 constexpr int dc_rep_copy_floats(int steps, int chunk, int span, int threads = kThreads) { return (steps * chunk + span + threads + 2 + 1) & ~1; }
-constexpr int dc_rep_chan_floats_steps(int steps, int chunk)
+constexpr int dc_rep_chan_floats_steps(int steps, int chunk, int span = kMaxReplicaSpan)
 {
-    const int one = dc_rep_copy_floats(steps, chunk, kMaxReplicaSpan);
-    const int two = 2 * dc_rep_copy_floats(1, chunk, kMaxReplicaSpan);
+    const int one = dc_rep_copy_floats(steps, chunk, span);
+    const int two = 2 * dc_rep_copy_floats(1, chunk, span);
     return ((one > two ? one : two) + 7) & ~7;
 }
 constexpr int dc_rep_chan_floats(int chunk, int kt, int mt) { return dc_rep_chan_floats_steps(dc_segment_steps(chunk, kt, mt), chunk); }

@@ -208,10 +208,7 @@ def test_native_latency_example_and_completion_flag(gat):
         dev_min = float(ln.split("|")[2].split("/")[0])
         assert 3.0 < dev_min < 200.0, ln  # microseconds: a call + sync is neither free nor a stall
         res_min, wgs = float(ln.split("|")[6].split("/")[0]), int(re.search(r"\(\s*(\d+)\)", ln.split("|")[6]).group(1))
-        if wgs:  # (seven taps at 262 MHz span more than one launch's replica: no resident correlator for that point)
-            assert int(m.group(2)) == n and 1.0 < res_min < 200.0, ln
-        else:
-            assert n == 262144 and ln.split()[3] == "7", ln
+        assert wgs > 0 and int(m.group(2)) == n and 1.0 < res_min < 200.0, ln
 
 
 def test_sync_after_flagged_launch_sees_results_and_later_work_falls_back(gat):

@@ -445,7 +445,9 @@ def test_gen_signal_int_layouts(gat):
 
 
 # ---- taps in any order / wider than the LDS replica segment: host-side tap grouping ----------------
-@pytest.mark.parametrize("shifts", [[5, -3000, 0, 2500, -1, 7], [3, 2, 1, 0, -1, -2, -3, 4, 5, 6, -7], [0], [40000, -40000]])
+@pytest.mark.parametrize("shifts", [[5, -3000, 0, 2500, -1, 7], [3, 2, 1, 0, -1, -2, -3, 4, 5, 6, -7], [0], [40000, -40000],
+                                    [-900, -301, 0, 300, 901],   # span 1801: one launch with a replica segment sized for it
+                                    [1024, -1024, 0]])            # span 2048: the widest single launch
 def test_unsorted_and_wide_taps(gat, shifts):
     case = make_case(31 + len(shifts), N=12000, M=2, L=3, K=2, B=2, fs=8e6)
     case["shifts"] = np.asarray(shifts, dtype=np.int32)

@@ -60,6 +60,7 @@ def _open(g, case, layout=0, **config):
     (8192, 2, 5, 3, 0, 0, 0),     # three channels: three doorbell lines, channel workgroups
     (2500 - 2500 % 4, 3, 3, 4, 0, 0, 0),
     (262144, 4, 3, 1, 0, 0, 0),   # the grid's largest point
+    (262144, 1, 7, 1, 0, 0, 0),   # ... with seven taps half a chip apart: a tap span of 768 samples in one launch
 ])
 def test_resident_matches_oracle(gat, N, M, L, K, layout, max_wgs, pollers):
     g = gat
@@ -253,7 +254,7 @@ def test_resident_rejects_what_it_cannot_serve(gat):
     cases = [
         (L.SignalDesc(re.data_ptr(), re.data_ptr(), g.GAT_LAYOUT_PLANAR, 2, 4096, 4096, 4096, 0), 5, [-1, 0, 1], 4),    # five channels
         (L.SignalDesc(re.data_ptr(), re.data_ptr(), g.GAT_LAYOUT_PLANAR, 1, 4098, 4098, 4098, 0), 1, [-1, 0, 1], 4),    # ragged block length
-        (L.SignalDesc(re.data_ptr(), re.data_ptr(), g.GAT_LAYOUT_PLANAR, 1, 4096, 4096, 4096, 0), 1, [-2000, 0, 2000], 4),  # taps of two launches
+        (L.SignalDesc(re.data_ptr(), re.data_ptr(), g.GAT_LAYOUT_PLANAR, 1, 4096, 4096, 4096, 0), 1, [-2000, 0, 2000], 4),  # taps of two launches (span > 2048)
     ]
     for desc, K, shifts, want in cases:
         with pytest.raises(L.GatError) as e:
