@@ -74,6 +74,7 @@ def parse_args(argv=None):
                     help="sample format: planar/interleaved ComplexF32 (headline), int16 / int8 ingest")
     ap.add_argument("--atomic", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-block", action="store_true", help="skip the one-block-per-call latency figures")
     ap.add_argument("--no-shard-config3", action="store_true", help="N > 1: skip the configs[3] shard measurement")
     ap.add_argument("--no-group-check", action="store_true",
                     help="N > 1: skip the device-group self-check (build/gat_multi_gpu in a fresh process after the ranks are done)")
@@ -444,6 +445,33 @@ def parity_check(g, m):
     return err, h_re, h_im
 
 
+def single_block(g, args) -> dict:
+    """What the reference's own benchmark times (src/benchmarks.jl:120-146): ONE 1 ms block of the headline shape per call,
+    synchronised -- through an ordinary launch + wait (library-owned stream, completion flag) and rung into the resident
+    correlator (gat_resident_*: no launch; outputs on the host when the call returns).  Python host layer, a fraction of a
+    second; never fails the line (an error record instead).  examples/gat_latency.c is the native form over the whole grid."""
+    try:
+        from gpuacceleratedtracking_amd.algorithms import ALGODICT, KernelAlgorithm
+        from gpuacceleratedtracking_amd.benchmarks import _run_kernel_benchmark
+
+        N, M, L = args.num_samples, args.num_ants, args.num_taps
+        rec = {"workload": f"{args.gnss}, {M} ants, 1 PRN, {L} correlators, one 1 ms block of {N} samples per call", "unit": "us",
+               "host_layer": "python/ctypes"}
+        res = {}
+        for name in ("hip_fused", "hip_resident"):
+            t, op, _ = _run_kernel_benchmark(g.GNSSDICT[args.gnss], N, M, L, KernelAlgorithm(ALGODICT[name]), seconds=0.15, max_samples=3000)
+            res[name] = op.result()[0, 0]
+            rec["launch_and_wait" if name == "hip_fused" else "resident_call"] = {
+                "min": round(float(t.min()) / 1e3, 2), "median": round(float(np.median(t)) / 1e3, 2), "calls": int(t.size)}
+            if name == "hip_resident":
+                rec["resident_call"]["workgroups"] = op.resident_info["workgroups"]
+        a, b = res["hip_fused"], res["hip_resident"]
+        rec["resident_vs_launch_max_rel_diff"] = float(np.abs(a - b).max() / np.abs(a).max())
+        return rec
+    except Exception as exc:  # noqa: BLE001
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def main():
     args = parse_args()
     if args.cpu_sweep:
@@ -550,6 +578,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, h_re, h_im, m["prm"], m["op"].shifts, fs, m["op"].system)
     del m
+    if rank == 0 and world == 1 and not args.no_single_block:
+        torch.cuda.empty_cache()
+        out["single_block"] = single_block(g, args)
 
     # N > 1: the shape the 8-GPU node of BASELINE configs[3] runs -- 16 antennas, 32 PRNs sharded 4 per GPU, 50 MHz
     if world > 1 and not args.no_shard_config3 and args.baseline_config is None:
