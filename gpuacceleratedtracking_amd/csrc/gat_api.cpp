@@ -181,12 +181,15 @@ bool code_span_ok(double ratio, double tau, double reach, int Lc)
     return span < 1073741824.0 && (Lc <= 0 || span < 2097152.0 * (double)Lc) && ratio >= 0.0;
 }
 
+void park_residents(gat_ctx *c); // (below) hipFree waits for every kernel on the device: resident ones are asked to leave first
+
 int32_t ensure_partial(gat_ctx *c, size_t bytes)
 {
     if (bytes <= c->partial_bytes) return GAT_OK;
     drop_loop_graphs(c); // recorded launches point at the old buffer
     if (c->d_partial) {
         GAT_HIP(c, hipStreamSynchronize(c->stream)); // previous launches may still read it
+        park_residents(c);
         GAT_HIP(c, hipFree(c->d_partial));
         c->d_partial = nullptr;
         c->partial_bytes = 0;
@@ -202,6 +205,7 @@ int32_t upload_params(gat_ctx *c, const gat_channel_params *params_host, size_t 
     if (n > c->params_cap) {
         if (c->d_params) {
             GAT_HIP(c, hipStreamSynchronize(c->stream));
+            park_residents(c);
             GAT_HIP(c, hipFree(c->d_params));
             c->d_params = nullptr;
             c->params_cap = 0;
@@ -1267,6 +1271,7 @@ GAT_API int32_t gat_downconvert_and_accumulate(gat_ctx *c, const gat_signal_desc
     if (need > c->params_cap) {
         if (c->d_params) {
             GAT_HIP(c, hipStreamSynchronize(c->stream));
+            park_residents(c);
             GAT_HIP(c, hipFree(c->d_params));
             c->d_params = nullptr;
             c->params_cap = 0;
