@@ -15,7 +15,7 @@ export TMPDIR=/tmp
 cd /tmp
 pmc() { # set counters args...
   s=$1; cnt=$2; shift; shift
-  timeout -k 10 240 rocprofv3 --pmc $cnt --kernel-trace --output-format csv -d $RAW/pmc_${tag}_$s -- python3 $REPO/bench.py --no-cpu-baseline --steps 6 --warmup 40 --settle 64 "$@" > $OUT/pmc_${tag}_$s.json 2> $OUT/pmc_${tag}_$s.log
+  timeout -k 10 240 rocprofv3 --pmc $cnt --kernel-trace --output-format csv -d $RAW/pmc_${tag}_$s -- python3 $REPO/bench.py --no-cpu-baseline --no-single-block --steps 6 --warmup 40 --settle 64 "$@" > $OUT/pmc_${tag}_$s.json 2> $OUT/pmc_${tag}_$s.log
   python3 - $RAW/pmc_${tag}_$s $tag $s <<'PY' | tee -a $OUT/pmc_$tag.txt
 import csv, glob, os, sys
 acc={}; name=None
