@@ -118,6 +118,28 @@ int main(void)
         gat_free(ctx, rep2); gat_free(ctx, rep1); gat_free(ctx, prm2_dev);
     }
     bad += bad2;
+
+    /* ---- the same call rung into a resident correlator: one kernel stays on the device, a call is a doorbell ring through
+     * pinned host memory and the outputs come back on the host (what a receiver loop calling block after block uses) */
+    {
+        gat_resident *rs = NULL;
+        float r_re[M * L], r_im[M * L];
+        int bad3 = 0;
+        CHECK(gat_sync(ctx)); /* the signal is in device memory before the first ring */
+        CHECK(gat_resident_open(ctx, &sig, 1, L, shifts, fs, NULL /* default lifetime limits */, &rs));
+        for (int rep = 0; rep < 3; ++rep) {
+            CHECK(gat_resident_correlate(rs, &p, 0 /* block offset in samples */, r_re, r_im));
+            for (int l = 0; l < L; ++l)
+                for (int m = 0; m < M; ++m)
+                    if (fabsf(r_re[m + l * M] - want[l]) > 1e-5f * N || fabsf(r_im[m + l * M]) > 1e-5f * N) ++bad3;
+        }
+        gat_resident_info ri;
+        CHECK(gat_resident_info_get(rs, &ri, sizeof ri));
+        CHECK(gat_resident_close(rs));
+        printf("resident correlator: 3 calls, %d workgroup(s), %llu kernel start(s) -> antenna 0: [%.2f, %.2f, %.2f]  %s\n", ri.workgroups,
+               (unsigned long long)ri.launches, r_re[0], r_re[M], r_re[2 * M], bad3 ? "MISMATCH" : "OK");
+        bad += bad3;
+    }
     gat_free(ctx, re); gat_free(ctx, im); gat_free(ctx, prm_dev); gat_free(ctx, out_re); gat_free(ctx, out_im);
     gat_destroy(ctx);
     free(codes);
