@@ -1541,7 +1541,8 @@ GAT_API int32_t gat_resident_open(gat_ctx *c, const gat_signal_desc *sig, int32_
         if (config->struct_size < sizeof(uint32_t)) return fail(c, GAT_ERR_ARG, "gat_resident_config.struct_size not set");
         std::memcpy(&cf, config, std::min<size_t>(config->struct_size, sizeof cf));
     }
-    if (cf.max_workgroups > 1024) return fail(c, GAT_ERR_RANGE, "max_workgroups above 1024");
+    // (every workgroup has to be ON the device for a call to complete: no more of them than compute units)
+    if ((int)cf.max_workgroups > c->num_cus) return fail(c, GAT_ERR_RANGE, "max_workgroups above the device's compute units");
     GAT_HIP(c, hipSetDevice(c->device));
 
     gat_resident *res = new (std::nothrow) gat_resident();

@@ -389,7 +389,8 @@ typedef struct gat_resident_config {
     uint32_t idle_us;        /* the kernel ends after this long without a call          (0: default, 5 000 us)   */
     uint32_t life_ms;        /* ... and after this long whatever happens                (0: default, 2 000 ms)   */
     uint32_t max_calls;      /* ... and after this many calls                           (0: no limit)            */
-    uint32_t max_workgroups; /* workgroups one block's samples may be split over        (0: default, 64)         */
+    uint32_t max_workgroups; /* workgroups one block's samples may be split over        (0: default, 64; at most */
+                             /* the device's compute units: all of them have to be on the device at once)        */
     uint32_t host_pollers;   /* up to this many workgroups poll the host's doorbell themselves; with more, one does and    */
                              /* forwards the ring through device memory                 (0: default, 20)         */
 } gat_resident_config;
@@ -412,6 +413,7 @@ GAT_API int32_t gat_resident_correlate(gat_resident *resident, const gat_channel
 GAT_API int32_t gat_resident_info_get(const gat_resident *resident, gat_resident_info *out, size_t struct_size);
 /* asks the kernel to leave and waits until it has (bounded by the kernel's own limits); the next call starts it again */
 GAT_API int32_t gat_resident_park(gat_resident *resident);
+/* (a correlator that is still open when its context is destroyed is closed by gat_destroy: its handle dies with the context) */
 GAT_API int32_t gat_resident_close(gat_resident *resident);
 
 /* ---- several devices from one host thread --------------------------------------------------
