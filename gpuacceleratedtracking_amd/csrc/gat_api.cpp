@@ -648,7 +648,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
             const int span_sz = std::max(kMaxReplicaSpan, a.rep_span);
             const int want_waves = dc_min_waves(MT, cfg.taps, kt, 1, fmt);
             if (want_waves >= 4)
-                while (seg > 2 && dc_lds_bytes_floats(kt, c->code_row_stride, dc_rep_chan_floats_steps(seg, (int)chunk, span_sz)) > (160 / want_waves) * 1024) --seg;
+                while (seg > 2 && dc_lds_bytes_floats(kt, c->code_row_stride, dc_rep_chan_floats_steps(seg, (int)chunk, span_sz)) > (size_t)(160 / want_waves) * 1024) --seg;
             if (span_sz > kMaxReplicaSpan)
                 while (seg > 1 && dc_lds_bytes_floats(kt, c->code_row_stride, dc_rep_chan_floats_steps(seg, (int)chunk, span_sz)) > 64 * 1024) --seg;
             const int chan_floats = dc_rep_chan_floats_steps(seg, (int)chunk, span_sz);

@@ -258,27 +258,7 @@ __global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D, FMT)) dc_k
     completion_flag(a.done_counter, a.host_flag, a.flag_seq, a.total_wgs);
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// instance table: which (MT, L, VEC, AW, KT) combinations exist, per sample format (one translation unit each)
-// ------------------------------------------------------------------------------------------------------------
-// Which instances exist.  Register accumulators 2 * MT * L * KT <= 64; antenna-parallel waves (AW > 1) need full
-// 4-antenna tiles; unaligned input (VEC == 1, scalar loads) is served one antenna per workgroup.
-constexpr bool dc_instance(int mt, int l, int vec, int aw, int kt, int nw = 4, int depth = 1)
-{
-    if (depth != 1 && !(vec == 4 && depth == dc_depth_max(mt, l, aw, kt, nw))) return false;
-    // one-wave workgroups: short blocks of one- and two-antenna tiles
-    if (nw != 4 && !(nw == 1 && vec == 4 && aw == 1 && kt == 1 && mt <= 2)) return false;
-#ifdef GAT_DC_DEV // development builds: only the instances the BASELINE shapes use (compiles in seconds)
-    if (!((mt == 1 || mt == 4) && (l == 3 || l == 5) && vec == 4)) return false;
-#endif
-    if (mt < 1 || mt > kMaxAntTile || l < 1 || l > kMaxTapsPerLaunch) return false;
-    if (vec != 4) return vec == 1 && mt == 1 && aw == 1 && kt == 1;
-    if (aw != 1 && (mt != 4 || aw != 4)) return false;
-    // several channels per workgroup only with antenna-parallel waves: measured on MI355X, a channel loop over one
-    // antenna tile never beat separate channel workgroups sharing the tile through L2 (M = 1, 4; K = 8, 12)
-    if (kt != 1 && aw != 4) return false;
-    return (kt == 1 || kt == 2 || kt == 4) && mt * l * kt <= 48;
-}
+// (which instances exist: dc_instance, gat_internal.h)
 
 template <int FMT, int MT, int L, int VEC, int AW, int KT, int NW>
 static hipError_t launch_dc_nw(const DcArgs &a, const DcLaunch &cfg, hipStream_t s)

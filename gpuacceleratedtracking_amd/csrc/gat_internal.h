@@ -217,6 +217,25 @@ constexpr size_t dc_lds_bytes_one_wave(int rep_chan_floats, int code_row_stride)
     return 32 + 64 * sizeof(float) + kUcarFloats * sizeof(float) + (size_t)rep_chan_floats * sizeof(float) + (size_t)code_row_stride;
 }
 
+// Which instances exist.  Register accumulators 2 * MT * L * KT <= 64; antenna-parallel waves (AW > 1) need full
+// 4-antenna tiles; unaligned input (VEC == 1, scalar loads) is served one antenna per workgroup.
+constexpr bool dc_instance(int mt, int l, int vec, int aw, int kt, int nw = 4, int depth = 1)
+{
+    if (depth != 1 && !(vec == 4 && depth == dc_depth_max(mt, l, aw, kt, nw))) return false;
+    // one-wave workgroups: short blocks of one- and two-antenna tiles
+    if (nw != 4 && !(nw == 1 && vec == 4 && aw == 1 && kt == 1 && mt <= 2)) return false;
+#ifdef GAT_DC_DEV // development builds: only the instances the BASELINE shapes use (compiles in seconds)
+    if (!((mt == 1 || mt == 4) && (l == 3 || l == 5) && vec == 4)) return false;
+#endif
+    if (mt < 1 || mt > kMaxAntTile || l < 1 || l > kMaxTapsPerLaunch) return false;
+    if (vec != 4) return vec == 1 && mt == 1 && aw == 1 && kt == 1;
+    if (aw != 1 && (mt != 4 || aw != 4)) return false;
+    // several channels per workgroup only with antenna-parallel waves: measured on MI355X, a channel loop over one
+    // antenna tile never beat separate channel workgroups sharing the tile through L2 (M = 1, 4; K = 8, 12)
+    if (kt != 1 && aw != 4) return false;
+    return (kt == 1 || kt == 2 || kt == 4) && mt * l * kt <= 48;
+}
+
 // Arguments of the matrix-core kernel (gat_mfma.hip): 16-antenna tiles, planar f32 input.
 constexpr int kMfmaMaxTaps = 16;     // 2 * CT * L <= 32 columns with CT >= 1
 constexpr int kMfmaMaxSpan = 768;    // replica halo served per 256-sample step
