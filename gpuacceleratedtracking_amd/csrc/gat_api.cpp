@@ -551,7 +551,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     a.re = sig->re;
     a.im = sig->im;
     a.params = params_dev;
-    if (!params_dev) std::memcpy(a.inl, params_inline, (size_t)B * K * sizeof(gat_channel_params));
+    if (!params_dev && !plan_out) std::memcpy(a.inl, params_inline, (size_t)B * K * sizeof(gat_channel_params));
     a.codes = c->d_codes;
     a.out_re = out_re;
     a.out_im = out_im;
@@ -736,7 +736,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
 namespace {
 
 // ---- resident correlator: host side --------------------------------------------------------------------------------
-constexpr size_t kResBellBytes = kInlineParams * kBellDwords * sizeof(unsigned); // 256
+constexpr size_t kResBellBytes = kResMaxChannels * kBellDwords * sizeof(unsigned); // 1024
 constexpr size_t kResDevBytes = 64 + 8 * kResBellBytes;                          // "leaving" word (own line) | eight forwarded doorbells
 // up to this many workgroups poll the host's doorbell themselves (gat_resident.h; 17 workgroups: 6.0 / 6.4 us polling
 // directly, 5.7 / 7.4 forwarded; 33: 10.5 / 11.7 directly, 6.7 / 7.4 forwarded -- profiles/r04/r04r_*)
@@ -775,7 +775,7 @@ int32_t resident_start(gat_resident *res, unsigned start_seq)
     res->h_state[1] = 0;
     // device words: the master's "leaving" word = 0; the eight forwarded doorbells say "nothing newer than start_seq"
     std::memset(res->h_init, 0, kResDevBytes);
-    for (int c8 = 0; c8 < 8; ++c8) res->h_init[16 + c8 * (kInlineParams * kBellDwords)] = start_seq;
+    for (int c8 = 0; c8 < 8; ++c8) res->h_init[16 + c8 * (kResMaxChannels * kBellDwords)] = start_seq;
     GAT_HIP(c, hipMemcpyAsync(res->d_quit, res->h_init, kResDevBytes, hipMemcpyHostToDevice, res->stream));
     res->r.start_seq = start_seq;
     res->a.codes = c->d_codes;
@@ -1535,7 +1535,7 @@ GAT_API int32_t gat_resident_open(gat_ctx *c, const gat_signal_desc *sig, int32_
     if (!c) return GAT_ERR_ARG;
     if (!out || !sig || !shifts) return fail(c, GAT_ERR_ARG, "null argument");
     *out = nullptr;
-    if (K < 1 || K > kInlineParams) return fail(c, K < 1 ? GAT_ERR_ARG : GAT_ERR_UNSUPPORTED, "resident correlator: 1 .. 4 channels");
+    if (K < 1 || K > kResMaxChannels) return fail(c, K < 1 ? GAT_ERR_ARG : GAT_ERR_UNSUPPORTED, "resident correlator: 1 .. 16 channels");
     gat_resident_config cf{};
     if (config) {
         if (config->struct_size < sizeof(uint32_t)) return fail(c, GAT_ERR_ARG, "gat_resident_config.struct_size not set");
@@ -1555,7 +1555,7 @@ GAT_API int32_t gat_resident_open(gat_ctx *c, const gat_signal_desc *sig, int32_
     // geometry: the planner's, restricted to the resident instances
     DcPlan plan;
     plan.max_wgs = cf.max_workgroups ? cf.max_workgroups : 64;
-    const gat_channel_params dummy[kInlineParams] = {};
+    const gat_channel_params dummy[kResMaxChannels] = {};
     float *const nonnull = reinterpret_cast<float *>(uintptr_t(64));
     int32_t rc = correlate_impl(c, sig, nullptr, 1, K, L, shifts, fs, nonnull, nonnull, 0, dummy, &plan);
     if (rc != GAT_OK) return bail(rc);

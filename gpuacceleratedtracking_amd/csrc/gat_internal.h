@@ -114,7 +114,7 @@ struct DcLaunch {
 // ---- resident correlator (gat_resident.h): calls without a launch ----------------------------------------------------
 // One bounded-lifetime kernel stays on the device and serves single-block calls that the host rings in through a
 // doorbell in pinned host memory; every workgroup posts its sums to pinned host memory as result lines.
-// Doorbell: one 64-byte line per channel (K <= kInlineParams lines, written by the host in descending order, line 0 last):
+// Doorbell: one 64-byte line per channel (K <= kResMaxChannels lines, written by the host in descending order, line 0 last):
 //   dword 0 seq | 1 reserved | 2..11 gat_channel_params | 12..13 block offset in samples (int64) | 14 check | 15 seq
 // check = XOR of dwords 0..13: a poll that catches a line half-written fails the check and is repeated.
 // Result lines: workgroup `slot` (tile * KG + channel group, the body's decode of blockIdx) owns ceil(2 MT L / 14) lines of
@@ -122,6 +122,7 @@ struct DcLaunch {
 // its value o is the sum for (tap l, antenna m of its tile, re / im) = (o / 2 / MT, o / 2 % MT, o % 2).  Written with plain
 // stores and no fence: the host takes a call's results when every line carries the call's number and passes its check.
 constexpr int kBellDwords = 16;
+constexpr int kResMaxChannels = 16;    // channels (doorbell lines) of a resident correlator: four 256-byte loads of one wave
 constexpr unsigned kBellQuit = 0xffffffffu; // never a call's sequence number
 constexpr int kResLinePayload = 14;
 struct ResidentArgs {

@@ -26,7 +26,7 @@
 // while the master is leaving may be served by some workgroups and not by others: the host sees the kernel gone and the
 // call unanswered, starts the kernel again and the call is served whole (same values: the results are deterministic).
 //
-// Which shapes: one block per call, K <= 4 channels, one tap launch, 16-byte aligned block starts with N a multiple of the
+// Which shapes: one block per call, K <= 16 channels, one tap launch, 16-byte aligned block starts with N a multiple of the
 // load group (what runs as ONE vector launch otherwise); antennas in tiles of MT <= 4, one tile per workgroup (AW = KT = 1).
 #pragma once
 
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
     constexpr bool KEEP = false;
     constexpr int NVAL = 2 * MT * L;                                          // sums one workgroup posts per call
     constexpr int LW = (NVAL + kResLinePayload - 1) / kResLinePayload;        // its result lines
-    __shared__ unsigned s_bell[kInlineParams * kBellDwords];
+    __shared__ unsigned s_bell[kResMaxChannels * kBellDwords];
     __shared__ unsigned s_ctl[1]; // the call's sequence number or kBellQuit
     __shared__ float s_out[64];
 
@@ -95,9 +95,19 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
         if (threadIdx.x < 64) {
             const int ln = (int)threadIdx.x;
             const bool from_host = master || r.forward == 0;
-            const unsigned *src = (from_host ? r.host_bell : r.dev_bell + (blockIdx.x & 7u) * (kInlineParams * kBellDwords)) + ln;
-            const bool mine = ln < K * kBellDwords;
-            unsigned v = 0, seq = last;
+            const unsigned *src = (from_host ? r.host_bell : r.dev_bell + (blockIdx.x & 7u) * (kResMaxChannels * kBellDwords)) + ln;
+            // lane i <-> dword i of the first four lines; channels 4 .. 15 (rare: a receiver's whole constellation in one
+            // call) sit in three more 256-byte groups that are read only once line 0 shows a new ring -- one more trip
+            const int K0 = K < 4 ? K : 4;
+            const bool mine = ln < K0 * kBellDwords;
+            unsigned v = 0, vx[3] = {0u, 0u, 0u}, seq = last;
+            auto whole = [&](unsigned w, bool have, unsigned want) { // every line of a 256-byte group is whole and of ring `want`
+                unsigned x = (ln & 15) < 14 ? w : 0u;
+                x ^= __shfl_xor(x, 8, 64); x ^= __shfl_xor(x, 4, 64); x ^= __shfl_xor(x, 2, 64); x ^= __shfl_xor(x, 1, 64);
+                const unsigned chk = __shfl(w, (ln & ~15) + 14, 64), head = __shfl(w, ln & ~15, 64), tail = __shfl(w, (ln & ~15) + 15, 64);
+                const bool ok = !have || (x == chk && head == want && tail == want);
+                return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+            };
             for (;;) {
                 if (mine) v = from_host ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
                                         : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -107,11 +117,18 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
                 if (seq == kBellQuit || leave != 0u) { why = kResidentQuit; seq = kBellQuit; break; }
                 if (seq != last) {
                     // every line whole and of this ring: first and last dword = seq, XOR of dwords 0..13 = dword 14
-                    unsigned x = (ln & 15) < 14 ? v : 0u;
-                    x ^= __shfl_xor(x, 8, 64); x ^= __shfl_xor(x, 4, 64); x ^= __shfl_xor(x, 2, 64); x ^= __shfl_xor(x, 1, 64);
-                    const unsigned chk = __shfl(v, (ln & ~15) + 14, 64), head = __shfl(v, ln & ~15, 64), tail = __shfl(v, (ln & ~15) + 15, 64);
-                    const bool ok = !mine || (x == chk && head == seq && tail == seq);
-                    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                    bool ok = whole(v, mine, seq);
+                    if (ok && K > 4) {
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            const bool have = ln < (K - 4 * (g + 1)) * kBellDwords;
+                            if (have) vx[g] = from_host ? __hip_atomic_load(src + 64 * (g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                                        : __hip_atomic_load(src + 64 * (g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) ok = whole(vx[g], ln < (K - 4 * (g + 1)) * kBellDwords, seq) && ok;
+                    }
+                    if (ok) break;
                     seq = last; // a line caught half-written (or the host has not reached line 0's siblings yet): read again
                 }
                 const long long now = wall_clock64();
@@ -129,16 +146,25 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
                 __builtin_amdgcn_s_sleep(2);
             }
             if (master) {
-                if (r.forward != 0) { // the ring, or the decision to leave, to the eight device doorbells
+                if (r.forward != 0) { // the ring, or the decision to leave, to the eight device doorbells (line 0's group last)
                     const unsigned fwd = (seq == kBellQuit && ln == 0) ? kBellQuit : v;
+                    for (int c8 = 0; c8 < 8; ++c8) {
+                        unsigned *dst = r.dev_bell + c8 * (kResMaxChannels * kBellDwords) + ln;
+#pragma unroll
+                        for (int g = 0; g < 3; ++g)
+                            if (ln < (K - 4 * (g + 1)) * kBellDwords) __hip_atomic_store(dst + 64 * (g + 1), vx[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (K > 4) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // a poller that sees line 0 new finds the other groups new
                     if (mine)
                         for (int c8 = 0; c8 < 8; ++c8)
-                            __hip_atomic_store(r.dev_bell + c8 * (kInlineParams * kBellDwords) + ln, fwd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(r.dev_bell + c8 * (kResMaxChannels * kBellDwords) + ln, fwd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else if (seq == kBellQuit && ln == 0) {
                     __hip_atomic_store(r.dev_quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             s_bell[ln] = v;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) s_bell[64 * (g + 1) + ln] = vx[g];
             if (ln == 0) s_ctl[0] = seq;
         }
         __syncthreads();

@@ -378,7 +378,7 @@ GAT_API int32_t gat_last_launch_info(const gat_ctx *ctx, gat_launch_info *out, s
  * chan_stride as for the correlator) at the START of a device buffer; every call names its block by an offset in
  * samples from there (a ring buffer of blocks, or always 0).  Supported: what gat_downconvert_and_correlate would run as
  * ONE launch of the vector kernel -- any sample layout, block starts 16-byte aligned and num_samples a multiple of the
- * samples one 16-byte load holds (4 / 2 / 4 / 8 by layout), num_channels <= 4, at most 8 taps within a span of 2048
+ * samples one 16-byte load holds (4 / 2 / 4 / 8 by layout), num_channels <= 16, at most 8 taps within a span of 2048
  * samples -- else GAT_ERR_UNSUPPORTED (use the ordinary call).  The caller makes sure the block's samples are in
  * device memory before the call (e.g. gat_sync after the copy that brought them); the kernel reads them past its caches.
  * Results: host arrays [M x L x K], the ordinary call's layout for one block; same values as the ordinary call up to the

@@ -92,7 +92,7 @@ static void check_dc(const DcArgs &a, const DcLaunch &cfg, bool resident)
         REQUIRE((a.done_counter == nullptr) == (a.host_flag == nullptr) && (a.done_counter == nullptr || a.flag_seq != 0), "launch: completion flag half set");
         REQUIRE(cfg.depth == 1 || (a.splits == 1 && a.KG == 1 && !a.keep_l2), "launch: two sample sets outside the streaming regime");
     } else {
-        REQUIRE(a.B == 1 && kt == 1 && aw == 1 && nw == 4 && cfg.depth == 1 && vec == 4 && a.n_vec == a.N && a.K <= kInlineParams, "resident: geometry");
+        REQUIRE(a.B == 1 && kt == 1 && aw == 1 && nw == 4 && cfg.depth == 1 && vec == 4 && a.n_vec == a.N && a.K <= kResMaxChannels, "resident: geometry");
     }
 }
 

@@ -224,7 +224,7 @@ int main(int argc, char **argv)
     // ---- 3. the resident correlator against an emulated device -------------------------------------------------------------
     long res_calls = 0, res_opened = 0, res_refused = 0;
     for (int it = 0; it < 60; ++it) {
-        const int fmt = (int)uni(0, 3), M = (int)pick<long long>({1, 2, 3, 4, 8, 16}), K = (int)uni(1, 5), L = (int)pick<long long>({1, 3, 5, 7, 8, 9});
+        const int fmt = (int)uni(0, 3), M = (int)pick<long long>({1, 2, 3, 4, 8, 16}), K = (int)pick<long long>({1, 1, 2, 3, 4, 5, 9, 12, 16, 17}), L = (int)pick<long long>({1, 3, 5, 7, 8, 9});
         long long N = pick<long long>({2048, 2500, 4096, 16384, 20000, 65536, 262144, uni(100, 100000)});
         if (uni(0, 4) != 0) N -= N % kSpv[fmt];
         if (N < kSpv[fmt]) N = kSpv[fmt];
@@ -239,7 +239,7 @@ int main(int argc, char **argv)
         const int32_t rc = gat_resident_open(ctx, &sig, K, L, sh.data(), N / 1e-3, uni(0, 4) ? &cfg : nullptr, &res);
         std::vector<int32_t> sorted(sh);
         std::sort(sorted.begin(), sorted.end());
-        const bool servable = K <= 4 && L <= 8 && sorted.back() - sorted.front() <= 2048 && N % kSpv[fmt] == 0 && mis == 0;
+        const bool servable = K <= 16 && L <= 8 && sorted.back() - sorted.front() <= 2048 && N % kSpv[fmt] == 0 && mis == 0;
         EXPECT((rc == GAT_OK) == servable, "resident open: rc %d for fmt %d M %d K %d L %d N %lld span %d mis %d (%s)", rc, fmt, M, K, L, N, sorted.back() - sorted.front(),
                (int)mis, gat_last_error(ctx));
         if (rc != GAT_OK) {

@@ -61,6 +61,9 @@ def _open(g, case, layout=0, **config):
     (2500 - 2500 % 4, 3, 3, 4, 0, 0, 0),
     (262144, 4, 3, 1, 0, 0, 0),   # the grid's largest point
     (262144, 1, 7, 1, 0, 0, 0),   # ... with seven taps half a chip apart: a tap span of 768 samples in one launch
+    (8192, 2, 3, 7, 0, 0, 64),    # seven channels: two 256-byte doorbell groups, every workgroup polling the host
+    (20000, 4, 3, 12, 0, 0, 0),   # a whole constellation in one call: twelve channels, forwarded doorbell (72 workgroups)
+    (4096, 1, 3, 16, 1, 16, 0),   # sixteen channels, one workgroup each
 ])
 def test_resident_matches_oracle(gat, N, M, L, K, layout, max_wgs, pollers):
     g = gat
@@ -252,7 +255,7 @@ def test_resident_rejects_what_it_cannot_serve(gat):
     torch.cuda.synchronize()
     L = g._lib
     cases = [
-        (L.SignalDesc(re.data_ptr(), re.data_ptr(), g.GAT_LAYOUT_PLANAR, 2, 4096, 4096, 4096, 0), 5, [-1, 0, 1], 4),    # five channels
+        (L.SignalDesc(re.data_ptr(), re.data_ptr(), g.GAT_LAYOUT_PLANAR, 2, 4096, 4096, 4096, 0), 17, [-1, 0, 1], 4),   # seventeen channels
         (L.SignalDesc(re.data_ptr(), re.data_ptr(), g.GAT_LAYOUT_PLANAR, 1, 4098, 4098, 4098, 0), 1, [-1, 0, 1], 4),    # ragged block length
         (L.SignalDesc(re.data_ptr(), re.data_ptr(), g.GAT_LAYOUT_PLANAR, 1, 4096, 4096, 4096, 0), 1, [-2000, 0, 2000], 4),  # taps of two launches (span > 2048)
     ]
