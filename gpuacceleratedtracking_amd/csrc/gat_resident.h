@@ -86,6 +86,9 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
     long long t_last = t_start;
     const ResidentEnv env{s_bell, s_out};
 
+#ifdef GAT_RES_STAMPS
+    long long t_seen_ = 0;
+#endif
     for (;;) {
         // ---- wait for a ring: wave 0 reads all K lines with ONE load (lane i <-> dword i).  Few workgroups: every one polls
         // the host's doorbell itself (nothing between the ring and any workgroup).  Many: reads of one host line queue up
@@ -166,6 +169,9 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
 #pragma unroll
             for (int g = 0; g < 3; ++g) s_bell[64 * (g + 1) + ln] = vx[g];
             if (ln == 0) s_ctl[0] = seq;
+#ifdef GAT_RES_STAMPS
+            t_seen_ = wall_clock64();
+#endif
         }
         __syncthreads();
         const unsigned seq = uni(s_ctl[0]);
@@ -202,6 +208,7 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
         st_[6] = wall_clock64();
         if (master && threadIdx.x == 0)
             for (int i = 0; i < 7; ++i) r.host_state[4 + i] = (unsigned)(st_[i] - st_[0]);
+        if (master && threadIdx.x == 0) r.host_state[11] = (unsigned)(st_[0] - t_seen_);
 #endif
         ++calls;
         t_last = wall_clock64();
