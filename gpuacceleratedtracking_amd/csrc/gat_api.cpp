@@ -1734,8 +1734,8 @@ GAT_API int32_t gat_resident_close(gat_resident *res)
     (void)hipSetDevice(c->device);
     const int32_t rc = resident_park(res);
 #ifdef GAT_RES_STAMPS
-    std::fprintf(stderr, "resident stamps of the last call (10 ns ticks): ring seen -> barrier + acquire %u; then tile decode %u, setup %u, first segment %u, steps %u, reduction %u, result lines %u\n",
-                 res->h_state[11], res->h_state[4 + 1], res->h_state[4 + 2], res->h_state[4 + 3], res->h_state[4 + 4], res->h_state[4 + 5], res->h_state[4 + 6]);
+    std::fprintf(stderr, "resident stamps of the last call (10 ns ticks): ring seen -> barrier + acquire %u; then tile decode %u, first loads issued %u, parameters %u, setup (barrier) %u, first segment %u, steps %u, reduction %u, result lines %u (= %u counts of clock64)\n",
+                 res->h_state[11], res->h_state[4 + 1], res->h_state[12], res->h_state[13], res->h_state[4 + 2], res->h_state[4 + 3], res->h_state[4 + 4], res->h_state[4 + 5], res->h_state[4 + 6], res->h_state[14]);
 #endif
     c->residents.erase(std::remove(c->residents.begin(), c->residents.end(), res), c->residents.end());
     resident_free(res);

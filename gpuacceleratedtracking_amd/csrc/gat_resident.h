@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
     // the working workgroup's ordinal (the body's decode of blockIdx: tile, channel group); padding of the grid leaves
     const unsigned tile0 = ((blockIdx.x >> 3) / (unsigned)a.KG) * 8u + (blockIdx.x & 7u);
     if (tile0 >= (unsigned)a.num_tiles) return;
-    const unsigned slot = tile0 * (unsigned)a.KG + (blockIdx.x >> 3) % (unsigned)a.KG;
+    const unsigned slot = tile0 * (unsigned)a.KG + (blockIdx.x >> 3) % (unsigned)a.KG; // (B = 1: tile = antenna group * splits + split)
     const bool master = blockIdx.x == 0;
     const int K = a.K;
     int staged_prn[KT];
@@ -182,8 +182,9 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 
 #ifdef GAT_RES_STAMPS // development builds: where a call's time goes (100 MHz clock), read back by gat_resident_close
-        long long st_[8] = {};
+        long long st_[10] = {};
         st_[0] = wall_clock64();
+        const long long cyc0_ = clock64();
 #undef GAT_DC_LAT_CUT_AT
 #define GAT_DC_LAT_CUT_AT(n) do { st_[n] = wall_clock64(); } while (0)
 #endif
@@ -208,7 +209,12 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
         st_[6] = wall_clock64();
         if (master && threadIdx.x == 0)
             for (int i = 0; i < 7; ++i) r.host_state[4 + i] = (unsigned)(st_[i] - st_[0]);
-        if (master && threadIdx.x == 0) r.host_state[11] = (unsigned)(st_[0] - t_seen_);
+        if (master && threadIdx.x == 0) {
+            r.host_state[11] = (unsigned)(st_[0] - t_seen_);
+            r.host_state[12] = (unsigned)(st_[8] - st_[0]);
+            r.host_state[13] = (unsigned)(st_[7] - st_[0]);
+            r.host_state[14] = (unsigned)(clock64() - cyc0_); // shader-clock cycles of the same span as st_[6] - st_[0]
+        }
 #endif
         ++calls;
         t_last = wall_clock64();
