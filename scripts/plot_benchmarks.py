@@ -40,7 +40,7 @@ def sweep_figure(rows, out, cpu_rows=()):
         ax.set_ylabel("Processing Time [s]")
         ax.set_title(f"{gnss} T=1 ms, M={m}, L={l}")
         ax.grid(True, which="both", lw=0.3)
-        ax.legend(fontsize=7, loc="lower right")
+        ax.legend(fontsize=6, loc="upper left", bbox_to_anchor=(0.0, 0.9))
     fig.suptitle("downconvert + correlate, one 1 ms block per call, sync-inclusive (BenchmarkTools 'Minimum')")
     fig.tight_layout()
     fig.savefig(out, dpi=80)
