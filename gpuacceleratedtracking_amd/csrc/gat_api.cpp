@@ -634,6 +634,10 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
         if (nw == 1) { // the replica's LDS is sized for this launch: segment + tap span + one entry per producer lane
             cfg.depth = 1;
             a.seg_steps = (int)std::min<long long>(seg, cps);
+            if (deep_ok && seg >= 2 && dc_has_instance(MT, cfg.taps, vec, aw, kt, nw, 2)) {
+                cfg.depth = 2; // whole groups of two steps per segment; the kernel pads the block's last group
+                a.seg_steps = (int)std::min<long long>(seg - seg % 2, (cps + 1) / 2 * 2);
+            }
             const int one = dc_rep_copy_floats(a.seg_steps, (int)chunk, a.rep_span, 64);
             a.rep_copy_stride = odd ? one : 0;
             a.rep_chan_floats = ((odd ? 2 : 1) * one + 7) & ~7;

@@ -212,7 +212,12 @@ constexpr int kOneWaveSegSteps = 4;
 // Deepest sample prefetch an instance family is built with.  Two register sets (steps c+1 and c+2 in flight) exist for
 // the four-antenna, <= 3-tap, one-channel tile only -- the configs[1] family, streaming every byte once at the HBM rate:
 // measured + 1.3 % there on fast and slow boxes alike; every other family measured no gain or a loss.
-constexpr int dc_depth_max(int mt, int l, int aw, int kt, int nw) { return nw == 4 && aw == 1 && kt == 1 && mt == 4 && l <= 3 ? 2 : 1; }
+constexpr int dc_depth_max(int mt, int l, int aw, int kt, int nw)
+{
+    // (round 4: and the one-antenna one-wave tile of short blocks in a long stream -- 6-7 waves per SIMD with ONE step of 2 KB
+    // in flight each are 13.5 KB per SIMD, 0.78 of the HBM rate by Little's law at 2.2 us: what that shape measured, 0.74)
+    return (nw == 4 && aw == 1 && kt == 1 && mt == 4 && l <= 3) || (nw == 1 && aw == 1 && kt == 1 && mt == 1 && l <= 3) ? 2 : 1;
+}
 constexpr size_t dc_lds_bytes_one_wave(int rep_chan_floats, int code_row_stride)
 {
     return 32 + 64 * sizeof(float) + kUcarFloats * sizeof(float) + (size_t)rep_chan_floats * sizeof(float) + (size_t)code_row_stride;
