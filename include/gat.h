@@ -363,13 +363,15 @@ GAT_API int32_t gat_last_launch_info(const gat_ctx *ctx, gat_launch_info *out, s
  * (Tracking.jl's discriminators).  Through gat_downconvert_and_correlate + gat_sync such a call costs a kernel launch and
  * the wait for its end: 7 us on this platform before the kernel has done anything.  A resident correlator keeps ONE
  * kernel on the device for a fixed call geometry; a call rings a doorbell in pinned host memory (the channel records
- * and the block's position travel with the ring), the kernel correlates and writes the results and a completion
- * number into pinned host memory, the host copies them out: no launch, no stream wait, outputs already on the host.
+ * and the block's position travel with the ring), every workgroup of the kernel correlates its share and posts its
+ * sums to pinned host memory stamped with the call's number, the host adds them in a fixed order: no launch, no stream
+ * wait, outputs already on the host (2 MHz .. 8 MHz blocks: 5-6 us instead of 10.5-13.5; it pays for up to four
+ * channels per call, is on a par at eight and loses beyond -- DESIGN.md 4.2b).
  *
  * Lifetime is bounded on the DEVICE side, whatever the host does: the kernel ends by itself after `idle_us` without a
  * call, after `life_ms` in total, or after `max_calls` calls; the next call starts it again (that call then costs a
- * launch).  It occupies one workgroup slot per workgroup it uses (info.workgroups, <= max_workgroups) and polls host
- * memory from one of them while it waits.  Other work of the process runs next to it on other streams; calls that
+ * launch).  It occupies one workgroup slot per workgroup it uses (info.workgroups: about max_workgroups at most) and polls
+ * host memory from up to `host_pollers` of them while it waits.  Other work of the process runs next to it on other streams; calls that
  * synchronise the whole device (hipDeviceSynchronize, hipFree) wait until it has ended: gat_free, gat_set_codes and
  * gat_destroy therefore ask every resident correlator of the context to leave first (gat_set_codes: for good -- the
  * correlator answers GAT_ERR_STATE afterwards and has to be opened again).
