@@ -6,7 +6,8 @@
 // is the fused correlator of gat_dc.h (the same body, gat_dc_body.inc) inside a loop, and every workgroup of it is on its
 // own:
 //
-//   poll the doorbell -> the call's channel records and block offset arrive WITH the ring (one 64-byte line per channel)
+//   poll the doorbell (the host's, or -- more than ~20 workgroups -- the master's copy of it in device memory)
+//   -> the call's channel records and block offset arrive WITH the ring (one 64-byte line per channel)
 //   -> system-scope acquire (the signal may have been rewritten by a copy engine or another kernel since the last call)
 //   -> correlate this workgroup's share (antenna tile, channel, sample split) -> post its sums to the host as result lines
 //   (64 bytes: 14 values | check | the call's number; plain stores, no fence, nothing to wait for) -> poll again.
@@ -14,7 +15,7 @@
 // The host takes a call's results when every line of every workgroup carries the call's number and passes its check, and
 // adds the sample splits in fixed order (the second stage of the ordinary call, on ~100 floats).  No workgroup exchanges
 // anything with another one: no arrival counter, no release / acquire pair, no partial sums in device memory -- each of
-// those was a trip through the memory system on the critical path (0.5-1.2 us apiece, profiles/r04/r04r_*).
+// those was a trip through the memory system on the critical path (0.5-1.2 us apiece, profiles/r04/resident/).
 // Chip tables stay staged in LDS from call to call; the kernel's arguments are read once.
 //
 // Lifetime: the kernel ends BY ITSELF, whatever the host does -- after `max_calls` calls, after `idle_ticks` without a
@@ -26,8 +27,9 @@
 // while the master is leaving may be served by some workgroups and not by others: the host sees the kernel gone and the
 // call unanswered, starts the kernel again and the call is served whole (same values: the results are deterministic).
 //
-// Which shapes: one block per call, K <= 16 channels, one tap launch, 16-byte aligned block starts with N a multiple of the
-// load group (what runs as ONE vector launch otherwise); antennas in tiles of MT <= 4, one tile per workgroup (AW = KT = 1).
+// Which shapes: one block per call, K <= 16 channels, one tap launch (<= 8 taps within 2048 samples), 16-byte aligned block
+// starts with N a multiple of the load group (what runs as ONE vector launch otherwise), all four sample formats; antennas
+// in tiles of MT <= 4, one tile and one channel per workgroup (AW = KT = 1).
 #pragma once
 
 #include "gat_dc.h"
