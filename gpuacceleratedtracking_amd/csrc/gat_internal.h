@@ -271,6 +271,45 @@ struct MfArgs {
     int shifts[kMfmaMaxTaps];    // ascending
     int tap_index[kMfmaMaxTaps]; // position in the caller's list
 };
+// Geometry of the matrix-core kernels that the host's planner and the kernels share (gat_mfma.hip, gat_mfma_bf16.hip).
+// split-bf16 kernel: workgroup size -- 4 consumer waves + 12 producer waves (4 per SIMD, 128 VGPRs) where the instance fits
+// that register budget, otherwise + 8 producer waves (3 per SIMD, 168 VGPRs)
+constexpr int mb_threads(int RT, int NCT) { return ((RT == 2 && NCT == 1) || (RT == 4 && NCT == 2)) ? 768 : 1024; }
+// consumer waves: one per SIMD, or (experiment GAT_MB_CW8) two per SIMD for the 4 x 4 instance
+#ifdef GAT_MB_CW8
+constexpr int mb_consumer_waves(int RT, int NCT) { return (RT == 4 && NCT == 4) ? 8 : 4; }
+#else
+constexpr int mb_consumer_waves(int, int) { return 4; }
+#endif
+constexpr int kMbMaxChain = 8192;  // samples per accumulation chain (f32 rounding of the running sum)
+constexpr int kMbMaxSlots = 24;    // channel slots per workgroup (header size)
+constexpr int kMbHeader = 1536;    // ChanInfoB[<= 20] (64 B each) + slack, 16-byte aligned
+constexpr int mb_tile_samples(int RT, int NCT)
+{
+    const int t = 32 * (4 / NCT), cap = 128 / RT;
+    return t < cap ? t : cap;
+}
+constexpr int mb_slots(int nct, int L, int K)
+{ // upper bound of the channels a workgroup's 32 * nct flat columns touch
+    const int s = (32 * nct + 2 * L - 1) / (2 * L) + 1;
+    return s < K ? s : K;
+}
+constexpr size_t mb_lds_bytes(int rt, int nct, int fmt, int nslots, int rep_stride, int code_bits_stride)
+{
+    const bool x1 = fmt == GAT_LAYOUT_INTERLEAVED_I8;
+    const int T = mb_tile_samples(rt, nct);
+    const int xs = x1 ? T + 2 : T + 1, wbytes = x1 ? 8 : 16;
+    return (size_t)kMbHeader + (size_t)2 * rt * 32 * xs * 8 + (size_t)2 * (2 * nslots + 1) * xs * wbytes +
+           (size_t)((2 * nslots * rep_stride + 3) & ~3) * 4 + (size_t)nslots * code_bits_stride * 4;
+}
+// f32-MFMA kernel: 256-sample tiles, 32 planes per row tile
+constexpr int kMfTile = 256;
+constexpr int kMfXStride = kMfTile + 1; // floats per plane row in LDS: odd (bank spread)
+constexpr size_t mf_lds_bytes(int nct, int ct, int rep_stride, int code_row_stride, int codes_in_lds)
+{
+    return (size_t)1024 + (size_t)2 * 32 * kMfXStride * sizeof(float) + (size_t)2 * nct * ct * rep_stride * sizeof(float) +
+           (codes_in_lds ? (size_t)nct * ct * code_row_stride + 16 : 0);
+}
 hipError_t launch_mfma(const MfArgs &a, int nct, unsigned grid, unsigned lds_bytes, hipStream_t s);
 size_t mfma_lds_bytes(int nct, int ct, int rep_stride, int code_row_stride, int codes_in_lds);
 // split-bf16 matrix-core kernel (gat_mfma_bf16.hip): rt = 16-antenna row tiles per workgroup (1, 2, 4)

@@ -37,9 +37,9 @@ typedef float f32x4_ __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int kTile = 256;          // samples per step
-constexpr int kXStride = kTile + 1; // floats per plane row in LDS: odd, so that for one sample the 32 planes
-                                    // (what one MFMA A fetch reads) sit in 32 different banks
+constexpr int kTile = kMfTile;       // samples per step (gat_internal.h: the host sizes LDS with the same numbers)
+constexpr int kXStride = kMfXStride; // floats per plane row in LDS: odd, so that for one sample the 32 planes
+                                     // (what one MFMA A fetch reads) sit in 32 different banks
 
 struct ChanInfo { // per channel slot of the workgroup, in LDS
     double ratio, tau, step, phi;
@@ -400,8 +400,7 @@ hipError_t launch_mfma(const MfArgs &a, int nct, unsigned grid, unsigned lds_byt
 size_t mfma_lds_bytes(int nct, int ct, int rep_stride, int code_row_stride, int codes_in_lds)
 {
     static_assert(sizeof(ChanInfo) * 20 <= 1024, "channel table must fit its 1 KB slot");
-    return (size_t)1024 + (size_t)2 * 32 * kXStride * sizeof(float) + (size_t)2 * nct * ct * rep_stride * sizeof(float) +
-           (codes_in_lds ? (size_t)nct * ct * code_row_stride + 16 : 0);
+    return mf_lds_bytes(nct, ct, rep_stride, code_row_stride, codes_in_lds);
 }
 
 } // namespace gat

@@ -47,19 +47,12 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-// workgroup size: 4 consumer waves + 12 producer waves (4 per SIMD, 128 VGPRs) where the instance fits that
-// register budget, otherwise + 8 producer waves (3 per SIMD, 168 VGPRs)
-constexpr int mb_threads(int RT, int NCT) { return ((RT == 2 && NCT == 1) || (RT == 4 && NCT == 2)) ? 768 : 1024; }
-// consumer waves: one per SIMD, or (experiment GAT_MB_CW8) two per SIMD for the 4 x 4 instance
-#ifdef GAT_MB_CW8
-constexpr int consumer_waves(int RT, int NCT) { return (RT == 4 && NCT == 4) ? 8 : 4; }
-#else
-constexpr int consumer_waves(int, int) { return 4; }
-#endif
-constexpr int kMaxChain = 8192;  // samples per accumulation chain (f32 rounding of the running sum)
+// (workgroup size mb_threads, consumer waves, tile size, slot and chain limits, LDS bytes: gat_internal.h -- the host's
+// planner and this kernel size everything with the same functions)
+constexpr int consumer_waves(int RT, int NCT) { return mb_consumer_waves(RT, NCT); }
+constexpr int kMaxChain = kMbMaxChain;
 constexpr int kReanchor = 16;   // steps between FP64 re-anchors of the producers' carried phasor / code index
-constexpr int kMbMaxSlots = 24;  // channel slots per workgroup (header size)
-constexpr int kHeader = 1536; // ChanInfoB[<= 20] (64 B each) + slack, 16-byte aligned
+constexpr int kHeader = kMbHeader;
 
 // hi/mid/lo bf16 terms of a float by TRUNCATION: hi = top 16 bits of v, mid = top 16 bits of
 // r = v - hi, lo = top 16 bits of r2 = r - mid.  Every residual is exact in f32 and each term takes 8
@@ -296,11 +289,7 @@ struct ChanInfoB { // per channel slot of the workgroup, in LDS
 };
 static_assert(sizeof(ChanInfoB) == 64, "ChanInfoB layout");
 
-constexpr int tile_samples(int RT, int NCT)
-{
-    const int t = 32 * (4 / NCT), cap = 128 / RT;
-    return t < cap ? t : cap;
-}
+constexpr int tile_samples(int RT, int NCT) { return mb_tile_samples(RT, NCT); }
 
 } // namespace
 
@@ -872,20 +861,12 @@ int mfma_bf16_max_slots() { return kMbMaxSlots; }
 int mfma_bf16_threads(int rt, int nct) { return mb_threads(rt, nct); }
 int mfma_bf16_producer_threads(int rt, int nct) { return mb_threads(rt, nct) - 64 * consumer_waves(rt, nct); }
 
-int mfma_bf16_slots(int nct, int L, int K)
-{ // upper bound of the channels a workgroup's 32 * nct flat columns touch
-    const int s = (32 * nct + 2 * L - 1) / (2 * L) + 1;
-    return s < K ? s : K;
-}
+int mfma_bf16_slots(int nct, int L, int K) { return mb_slots(nct, L, K); }
 
 size_t mfma_bf16_lds_bytes(int rt, int nct, int fmt, int nslots, int rep_stride, int code_bits_stride)
 {
-    const bool x1 = fmt == GAT_LAYOUT_INTERLEAVED_I8;
     static_assert(sizeof(ChanInfoB) * kMbMaxSlots <= kHeader, "channel table must fit the header");
-    const int T = tile_samples(rt, nct);
-    const int xs = x1 ? T + 2 : T + 1, wbytes = x1 ? 8 : 16;
-    return (size_t)kHeader + (size_t)2 * rt * 32 * xs * 8 + (size_t)2 * (2 * nslots + 1) * xs * wbytes +
-           (size_t)((2 * nslots * rep_stride + 3) & ~3) * 4 + (size_t)nslots * code_bits_stride * 4;
+    return mb_lds_bytes(rt, nct, fmt, nslots, rep_stride, code_bits_stride);
 }
 
 hipError_t launch_mfma_bf16(const MfArgs &a, int rt, int nct, int fmt, unsigned grid, unsigned lds_bytes, hipStream_t s)

@@ -115,17 +115,60 @@ hipError_t launch_dc_tail(const DcTailArgs &a, hipStream_t)
     REQUIRE(a.n_vec < a.N && a.N - a.n_vec < 8 && a.out_re && a.out_im, "tail: n_vec %d of %lld", a.n_vec, a.N);
     return hipSuccess;
 }
-// matrix-core kernels: not simulated -- the planner is told they do not fit, every call takes the vector path
-hipError_t launch_mfma(const MfArgs &, int, unsigned, unsigned, hipStream_t) { return hipErrorInvalidValue; }
-hipError_t launch_mfma_bf16(const MfArgs &, int, int, int, unsigned, unsigned, hipStream_t) { return hipErrorInvalidValue; }
-size_t mfma_lds_bytes(int, int, int, int, int) { return size_t(1) << 30; }
-size_t mfma_bf16_lds_bytes(int, int, int, int, int, int) { return size_t(1) << 30; }
-int mfma_bf16_slots(int, int, int K) { return K; }
-int mfma_bf16_max_slots() { return 0; }
-int mfma_bf16_tile_samples(int, int) { return 64; }
-int mfma_bf16_max_chain() { return 1 << 20; }
-int mfma_bf16_threads(int, int) { return 768; }
-int mfma_bf16_producer_threads(int, int) { return 512; }
+// matrix-core kernels: the planner's helpers are the kernels' own (gat_internal.h); every launch is checked against what
+// the kernels assume
+size_t mfma_lds_bytes(int nct, int ct, int rep_stride, int code_row_stride, int codes_in_lds) { return mf_lds_bytes(nct, ct, rep_stride, code_row_stride, codes_in_lds); }
+size_t mfma_bf16_lds_bytes(int rt, int nct, int fmt, int nslots, int rep_stride, int code_bits_stride) { return mb_lds_bytes(rt, nct, fmt, nslots, rep_stride, code_bits_stride); }
+int mfma_bf16_slots(int nct, int L, int K) { return mb_slots(nct, L, K); }
+int mfma_bf16_max_slots() { return kMbMaxSlots; }
+int mfma_bf16_tile_samples(int rt, int nct) { return mb_tile_samples(rt, nct); }
+int mfma_bf16_max_chain() { return kMbMaxChain; }
+int mfma_bf16_threads(int rt, int nct) { return mb_threads(rt, nct); }
+int mfma_bf16_producer_threads(int rt, int nct) { return mb_threads(rt, nct) - 64 * mb_consumer_waves(rt, nct); }
+
+static void check_mf_common(const MfArgs &a, unsigned grid, int T, const char *tag)
+{
+    REQUIRE(a.re && a.params && a.codes && a.out_re && a.out_im, "%s: null pointer", tag);
+    REQUIRE(a.total_steps == (a.N + T - 1) / T && a.steps_per_split >= 1 && (long long)a.splits * a.steps_per_split >= a.total_steps &&
+                (long long)(a.splits - 1) * a.steps_per_split < a.total_steps,
+            "%s: %d splits x %d steps for %d", tag, a.splits, a.steps_per_split, a.total_steps);
+    REQUIRE(a.num_tiles == a.B * a.ant_tiles * a.splits && grid == (unsigned)(((a.num_tiles + 7) / 8) * 8 * a.chan_groups), "%s: tiles %d grid %u", tag, a.num_tiles, grid);
+    REQUIRE(a.splits == 1 || (a.flags & GAT_FLAG_ATOMIC) || a.partial != nullptr, "%s: split without a partial buffer", tag);
+    REQUIRE(a.L >= 1 && a.L <= kMfmaMaxTaps && a.rep_span == a.shifts[a.L - 1] - a.shifts[0] && a.rep_span <= kMfmaMaxSpan, "%s: taps %d span %d", tag, a.L, a.rep_span);
+    for (int l = 1; l < a.L; ++l) REQUIRE(a.shifts[l] >= a.shifts[l - 1], "%s: taps not ascending", tag);
+    for (int l = 0; l < a.L; ++l) REQUIRE(a.tap_index[l] >= 0 && a.tap_index[l] < a.L, "%s: tap index", tag);
+    REQUIRE(a.rep_stride >= T + a.rep_span && (a.rep_stride & 1), "%s: replica row %d for a tile of %d + %d", tag, a.rep_stride, T, a.rep_span);
+    REQUIRE((reinterpret_cast<uintptr_t>(a.re) & 15u) == 0 && a.ant_stride % 2 == 0, "%s: alignment", tag);
+}
+
+hipError_t launch_mfma(const MfArgs &a, int nct, unsigned grid, unsigned lds_bytes, hipStream_t)
+{
+    ++counters.mfma_launches;
+    REQUIRE((nct == 1 || nct == 2 || nct == 4) && a.CT >= 1 && a.CT == 16 / a.L && nct * a.CT <= 20, "f32 mfma: nct %d CT %d L %d", nct, a.CT, a.L);
+    REQUIRE(a.M % 16 == 0 && a.ant_tiles == a.M / 16 && a.im != nullptr, "f32 mfma: antennas %d tiles %d", a.M, a.ant_tiles);
+    REQUIRE(a.chan_groups == ((a.K + a.CT - 1) / a.CT + nct - 1) / nct, "f32 mfma: channel groups %d", a.chan_groups);
+    REQUIRE(lds_bytes == mf_lds_bytes(nct, a.CT, a.rep_stride, a.code_row_stride, a.codes_in_lds) && lds_bytes <= 160 * 1024, "f32 mfma: LDS %u", lds_bytes);
+    check_mf_common(a, grid, kMfTile, "f32 mfma");
+    return hipSuccess;
+}
+hipError_t launch_mfma_bf16(const MfArgs &a, int rt, int nct, int fmt, unsigned grid, unsigned lds_bytes, hipStream_t)
+{
+    ++counters.mfma_launches;
+    const bool inst = (rt == 1 || rt == 2 || rt == 4) && (nct == 1 || nct == 2 || nct == 4) && !(rt == 4 && nct == 1);
+    REQUIRE(inst && fmt >= 0 && fmt <= 3, "bf16 mfma: instance rt %d nct %d fmt %d", rt, nct, fmt);
+    const int T = mb_tile_samples(rt, nct), spv = dc_group_samples(4, fmt);
+    REQUIRE(a.M % (16 * rt) == 0 && a.ant_tiles == a.M / (16 * rt), "bf16 mfma: antennas %d rt %d tiles %d", a.M, rt, a.ant_tiles);
+    REQUIRE(a.N % spv == 0, "bf16 mfma: N %lld is no multiple of the load group", a.N);
+    const int tiles = (2 * a.L * a.K + 31) / 32;
+    REQUIRE(a.chan_groups == (tiles + nct - 1) / nct, "bf16 mfma: %d column tiles in %d groups of %d", tiles, a.chan_groups, nct);
+    REQUIRE(a.nslots == mb_slots(nct, a.L, a.K) && a.nslots <= kMbMaxSlots && a.nslots * T / 2 <= mb_threads(rt, nct) - 64 * mb_consumer_waves(rt, nct),
+            "bf16 mfma: %d slots x %d samples for %d producers", a.nslots, T, mb_threads(rt, nct) - 64 * mb_consumer_waves(rt, nct));
+    REQUIRE((long long)a.steps_per_split * T <= kMbMaxChain || a.steps_per_split == 1, "bf16 mfma: chain of %d x %d samples", a.steps_per_split, T);
+    REQUIRE(a.code_bits && a.zeros && a.code_bits_stride % 4 == 0 && a.code_bits_stride * 32 >= a.Lc, "bf16 mfma: sign-bit tables");
+    REQUIRE(lds_bytes == mb_lds_bytes(rt, nct, fmt, a.nslots, a.rep_stride, a.code_bits_stride) && lds_bytes <= 160 * 1024, "bf16 mfma: LDS %u", lds_bytes);
+    check_mf_common(a, grid, T, "bf16 mfma");
+    return hipSuccess;
+}
 
 hipError_t launch_gen_code_replica(float *, long long, const int8_t *, int, double, double, double, long long, bool, hipStream_t) { ++counters.other_launches; return hipSuccess; }
 hipError_t launch_gen_code_replica_multi(float *, long long, long long, int, const gat_channel_params *, const int8_t *, int, int, int, double, long long, hipStream_t) { ++counters.other_launches; return hipSuccess; }

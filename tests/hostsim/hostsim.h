@@ -8,7 +8,7 @@
 namespace hostsim {
 struct Counters {
     std::atomic<long> mallocs{0}, frees{0}, graphs{0}, graph_launches{0};
-    std::atomic<long> dc_launches{0}, finalize_launches{0}, tail_launches{0}, other_launches{0}, resident_starts{0}, resident_calls{0};
+    std::atomic<long> dc_launches{0}, finalize_launches{0}, tail_launches{0}, mfma_launches{0}, other_launches{0}, resident_starts{0}, resident_calls{0};
     std::atomic<long> violations{0}; // planner invariants broken (each one is printed)
 };
 extern Counters counters;

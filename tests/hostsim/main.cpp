@@ -74,7 +74,7 @@ int main(int argc, char **argv)
                           "dc_one_wave_min", "dc_ow_seg", "dc_depth", "dc_keep_l2", "dc_align"};
     const long long opt_lo[] = {0, 1, 1, 1, 1, 0, 0, 0, -1, 1, 1, -1, 0}, opt_hi[] = {2048, 4, 4, 4, 64, 8, 16, 1, 64, 8, 2, 1, 1};
     EXPECT(gat_set_option(ctx, "no_such_option", 1) == GAT_ERR_ARG && gat_set_option(ctx, "dc_depth", 7) == GAT_ERR_RANGE, "option errors");
-    EXPECT(gat_set_matrix_core(ctx, 0) == GAT_OK, "vector kernel only (the matrix kernels are not simulated)");
+    EXPECT(gat_set_matrix_core(ctx, 7) != GAT_OK, "kernel selection: bad mode");
     long ok_calls = 0, rejected = 0;
     bool l5 = false;
     for (int it = 0; it < calls; ++it) {
@@ -82,12 +82,14 @@ int main(int argc, char **argv)
             l5 = !l5;
             EXPECT((l5 ? gat_set_codes(ctx, codes5.data(), lc5, 8) : gat_set_codes(ctx, codes.data(), lc, 32)) == GAT_OK, "rebind codes");
         }
+        if (it % 13 == 0) EXPECT(gat_set_matrix_core(ctx, (int32_t)uni(0, 3)) == GAT_OK, "kernel selection");
         if (it % 11 == 0) {
             const int o = (int)uni(0, 12);
             EXPECT(gat_set_option(ctx, opts[o], uni(opt_lo[o], opt_hi[o])) == GAT_OK, "option %s", opts[o]);
         }
-        const int fmt = (int)uni(0, 3), M = (int)pick<long long>({1, 1, 2, 3, 4, 4, 5, 8, 12, 16, 16, 20, 32});
-        const int K = (int)pick<long long>({1, 1, 1, 2, 3, 4, 5, 8, 12}), B = (int)pick<long long>({1, 1, 1, 2, 3, 7, 16, 64, 500});
+        const int fmt = (int)uni(0, 3), M = (int)pick<long long>({1, 1, 2, 3, 4, 4, 5, 8, 12, 16, 16, 20, 32, 48, 64, 128});
+        const int K = (int)pick<long long>({1, 1, 1, 2, 3, 4, 5, 8, 12, 16, 24, 32, 64});
+        const int B = M * K >= 256 ? (int)pick<long long>({1, 1, 2, 3}) : (int)pick<long long>({1, 1, 1, 2, 3, 7, 16, 64, 500});
         const int L = (int)pick<long long>({1, 2, 3, 3, 5, 7, 8, 11, 17, 32});
         long long N = pick<long long>({uni(1, 64), uni(64, 5000), 2048, 2500, 4096, 20000, 50000, uni(5000, 300000), 262144});
         if (uni(0, 3) == 0) N -= N % kSpv[fmt];
@@ -140,10 +142,12 @@ int main(int argc, char **argv)
         gat_free(ctx, o_im);
         if (prm_dev) gat_free(ctx, prm_dev);
     }
-    std::printf("correlate sweep: %ld calls planned and launched, %ld rejected by validation; %ld vector launches, %ld second stages, %ld tails, %ld graphs (%ld replays)\n",
-                ok_calls, rejected, hostsim::counters.dc_launches.load(), hostsim::counters.finalize_launches.load(), hostsim::counters.tail_launches.load(),
+    std::printf("correlate sweep: %ld calls planned and launched, %ld rejected by validation; %ld vector launches, %ld matrix-core launches, %ld second stages, %ld tails, %ld graphs (%ld replays)\n",
+                ok_calls, rejected, hostsim::counters.dc_launches.load(), hostsim::counters.mfma_launches.load(), hostsim::counters.finalize_launches.load(), hostsim::counters.tail_launches.load(),
                 hostsim::counters.graphs.load(), hostsim::counters.graph_launches.load());
-    EXPECT(ok_calls > calls / 2 && hostsim::counters.tail_launches > 0 && hostsim::counters.finalize_launches > 0, "the sweep covers second stages and tails");
+    EXPECT(ok_calls > calls / 2 && hostsim::counters.tail_launches > 0 && hostsim::counters.finalize_launches > 0 && (calls < 500 || hostsim::counters.mfma_launches > 0),
+           "the sweep covers second stages, tails and the matrix-core kernels");
+    EXPECT(gat_set_matrix_core(ctx, 1) == GAT_OK, "kernel selection back to auto");
     for (int o = 0; o < 13; ++o) gat_set_option(ctx, opts[o], o == 0 ? 1024 : o == 1 ? 4 : o == 2 ? 4 : o == 3 ? 4 : o == 4 ? 16 : o == 5 ? 0 : o == 6 ? 0 : o == 7 ? 1 : o == 8 ? -1 : o == 9 ? 4 : o == 10 ? 2 : o == 11 ? -1 : 1);
     EXPECT(gat_set_codes(ctx, codes.data(), lc, 32) == GAT_OK, "rebind L1");
 
