@@ -22,85 +22,9 @@
 #include <string>
 #include <vector>
 
-#include "gat_internal.h"
+#include "gat_ctx.h"
 
 using namespace gat;
-
-struct gat_ctx;
-
-// A resident correlator (gat_resident_open): one bounded-lifetime kernel serving single-block calls rung in through
-// pinned host memory (gat_resident.h).  Owned by its context's list until gat_resident_close.
-struct gat_resident {
-    gat_ctx *ctx = nullptr;
-    hipStream_t stream = nullptr;  // its own non-blocking stream: the kernel runs next to the context's work
-    DcArgs a{};
-    DcLaunch cfg{};
-    ResidentArgs r{};
-    unsigned char *h_block = nullptr; // pinned: doorbell lines | state | result lines
-    unsigned *h_bell = nullptr, *h_state = nullptr, *h_lines = nullptr, *h_init = nullptr;
-    unsigned *d_quit = nullptr;       // device: the master's "I am leaving" word | eight forwarded doorbells
-    int wgs = 0, lines_per_wg = 0, nval = 0; // working workgroups, result lines and values of each
-    unsigned seq = 0;                 // sequence number of the last call
-    bool running = false;             // a kernel was started and has not been seen to end
-    bool stale = false;               // the code table changed: the correlator has to be opened again
-    int K = 0, L = 0, M = 0, spv = 1;
-    long long N = 0, max_shift = 0;
-    double fs = 0.0;
-    uint32_t idle_us = 0, life_ms = 0, max_calls = 0;
-    long long ticks_per_us = 100;
-    unsigned last_exit = 0;
-    uint64_t launches = 0, calls = 0;
-};
-
-struct gat_ctx {
-    std::vector<gat_resident *> residents; // open resident correlators (parked before device-wide waits)
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int8_t *d_codes = nullptr;
-    // gat_tracking_run with GAT_FLAG_GRAPH: the launch sequence of the last such call, instantiated (replayed when the
-    // next call has the same arguments: a receiver cycling through one ring buffer)
-    struct LoopGraph {
-        std::vector<unsigned char> key;
-        hipGraphExec_t exec = nullptr;
-        unsigned long long last_use = 0;
-    };
-    std::vector<LoopGraph> loop_graphs; // small LRU (kMaxLoopGraphs): e.g. the a/b parameter order of odd block counts
-    unsigned long long loop_graph_clock = 0;
-    void *d_zeros = nullptr;         // 64 zero bytes (out-of-range sample loads of the split-bf16 kernel read these)
-    uint32_t *d_code_bits = nullptr; // bit i of row p = (chip i of PRN p is -1); only when every chip is +-1
-    int code_bits_stride = 0;        // dwords per row, a multiple of 4
-    int Lc = 0, P = 0, code_row_stride = 0; // rows padded to a multiple of 16 bytes
-    float *d_partial = nullptr;
-    size_t partial_bytes = 0;
-    // completion flag (latency regime): small launches of the vector kernel end by storing a sequence number into pinned
-    // host memory; gat_sync spins on it instead of going through hipStreamSynchronize (~5 us sooner)
-    unsigned *h_flag = nullptr;      // pinned, host address
-    unsigned *d_flag = nullptr;      // the same word, device address
-    unsigned *d_done = nullptr;      // device: arrival counter of a launch's workgroups
-    unsigned flag_seq = 0;           // last sequence number handed to a launch
-    unsigned wait_seq = 0;           // != 0: the newest work on the stream is a flagged launch with this number
-    int flag_max_wgs = 1024;         // option sync_flag_wgs: largest launch that carries the flag (0: never)
-    gat_channel_params *d_params = nullptr;
-    size_t params_cap = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timer_running = false;
-    int num_cus = 256;
-    unsigned long long *dbg_ptr = nullptr; // diagnostic builds only
-    int max_ant_tile = kMaxAntTile; // option max_ant_tile (gat_set_option)
-    int max_aw = 4, max_kt = 4, max_bpw = 16; // options dc_aw / dc_kt / dc_bpw (gat_set_vector_tiling): caps of the vector kernel's geometry
-    int force_bpw = 0;                        // option dc_bpw_force: blocks per workgroup whatever the planner's rule says (A/B runs)
-    int wgs_per_cu = 0;                       // option dc_wgs_per_cu: workgroups per CU the split planner aims for (0: by instance)
-    int one_wave = 1;                         // option dc_one_wave = 0: never use one-wave workgroups
-    long long one_wave_min = -1;              // option dc_one_wave_min: fewest (block, channel, tile) groups for them (default 32 per CU)
-    int one_wave_seg = kOneWaveSegSteps;      // option dc_ow_seg: steps per replica segment of a one-wave workgroup
-    int max_depth = 2;                        // option dc_depth: cap of the sample prefetch depth (register sets per wave)
-    int keep_l2 = -1;                         // option dc_keep_l2: cache policy of the sample loads (-1: by rule)
-    int align_head = 1;                       // option dc_align: line-aligned virtual block starts where blocks start off a line
-    int mc_mode = 1; // GAT_MC_* kernel selection (gat_set_matrix_core)
-    std::string err;
-    gat_launch_info last{};
-};
 
 namespace {
 
@@ -152,36 +76,6 @@ void drop_loop_graphs(gat_ctx *c)
     c->loop_graphs.clear();
 }
 
-int32_t fail(gat_ctx *c, int32_t code, const char *msg)
-{
-    if (c) c->err = msg;
-    return code;
-}
-
-int32_t hipfail(gat_ctx *c, hipError_t e, const char *where)
-{
-    if (c) {
-        c->err = std::string(where) + ": " + hipGetErrorString(e);
-    }
-    return -(int32_t)e;
-}
-
-#define GAT_HIP(c, call)                                      \
-    do {                                                      \
-        hipError_t e_ = (call);                               \
-        if (e_ != hipSuccess) return hipfail((c), e_, #call); \
-    } while (0)
-
-bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-
-// host mirror of the kernels' code_span_bad (gat_phase.h): what passes here is not poisoned there
-bool code_span_ok(double ratio, double tau, double reach, int Lc)
-{
-    const double span = std::fabs(tau) + std::fabs(ratio) * reach + 1.0;
-    return span < 1073741824.0 && (Lc <= 0 || span < 2097152.0 * (double)Lc) && ratio >= 0.0;
-}
-
-void park_residents(gat_ctx *c); // (below) hipFree waits for every kernel on the device: resident ones are asked to leave first
 
 int32_t ensure_partial(gat_ctx *c, size_t bytes)
 {
@@ -217,21 +111,14 @@ int32_t upload_params(gat_ctx *c, const gat_channel_params *params_host, size_t 
     return GAT_OK;
 }
 
-// What the planner hands to gat_resident_open instead of launching: the arguments and geometry of the ONE vector launch
-// that would serve the call (four-wave workgroups, one antenna tile and one channel each: the resident instances).
-struct DcPlan {
-    long long max_wgs = 64; // in: workgroups the block's samples may be split over (times antenna tiles and channels)
-    DcArgs a{};
-    DcLaunch cfg{};
-};
 
-// params_dev: [B*K] records on the device -- or null with params_inline: B*K <= kInlineParams validated HOST records that
-// travel inside the vector kernel's arguments (uploaded after all if a matrix-core kernel takes the call)
-// plan != null: nothing is launched; GAT_ERR_UNSUPPORTED unless the call is exactly one launch of the vector kernel
-int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel_params *params_dev,
-                       int32_t B, int32_t K, int32_t L, const int32_t *shifts, double fs,
-                       float *out_re, float *out_im, uint32_t flags, const gat_channel_params *params_inline = nullptr,
-                       DcPlan *plan_out = nullptr)
+} // namespace
+
+// (declared in gat_ctx.h: the resident correlator's host side asks it for a launch plan)
+int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel_params *params_dev,
+                            int32_t B, int32_t K, int32_t L, const int32_t *shifts, double fs,
+                            float *out_re, float *out_im, uint32_t flags, const gat_channel_params *params_inline,
+                            DcPlan *plan_out)
 {
     c->wait_seq = 0;
     const TraceRange trace("gat_downconvert_and_correlate");
@@ -735,88 +622,7 @@ int32_t correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel
     return GAT_OK;
 }
 
-} // namespace
 
-namespace {
-
-// ---- resident correlator: host side --------------------------------------------------------------------------------
-constexpr size_t kResBellBytes = kResMaxChannels * kBellDwords * sizeof(unsigned); // 1024
-constexpr size_t kResDevBytes = 64 + 8 * kResBellBytes;                          // "leaving" word (own line) | eight forwarded doorbells
-// up to this many workgroups poll the host's doorbell themselves (gat_resident.h; 17 workgroups: 6.0 / 6.4 us polling
-// directly, 5.7 / 7.4 forwarded; 33: 10.5 / 11.7 directly, 6.7 / 7.4 forwarded -- profiles/r04/r04r_*)
-constexpr int kResHostPollers = 20;
-
-double mono_us()
-{
-    timespec t;
-    clock_gettime(CLOCK_MONOTONIC, &t);
-    return t.tv_sec * 1e6 + t.tv_nsec * 1e-3;
-}
-
-// host mirror of the kernels' `bad` predicate for host-resident records: what passes here is not poisoned there
-int32_t validate_params(gat_ctx *c, const gat_channel_params *params_host, size_t n, double reach, double fs)
-{
-    for (size_t i = 0; i < n; ++i) {
-        const gat_channel_params &p = params_host[i];
-        if (p.prn < 0 || p.prn >= c->P) return fail(c, GAT_ERR_RANGE, "prn outside the code table");
-        if (!std::isfinite(p.code_freq_hz) || !std::isfinite(p.carrier_freq_hz) ||
-            !std::isfinite(p.code_phase_chips) || !std::isfinite(p.carrier_phase_cycles))
-            return fail(c, GAT_ERR_ARG, "non-finite channel parameter");
-        if (p.code_freq_hz < 0.0) return fail(c, GAT_ERR_RANGE, "negative code frequency");
-        if (std::fabs(p.carrier_freq_hz / fs) >= 1.0e15 || std::fabs(p.carrier_phase_cycles) >= 1.0e15)
-            return fail(c, GAT_ERR_RANGE, "carrier frequency / phase out of range");
-        if (!code_span_ok(p.code_freq_hz / fs, p.code_phase_chips, reach, c->Lc))
-            return fail(c, GAT_ERR_RANGE, "code phase span too large");
-    }
-    return GAT_OK;
-}
-
-// start the kernel: it has served everything up to start_seq; a ring with a newer number is served at once
-int32_t resident_start(gat_resident *res, unsigned start_seq)
-{
-    gat_ctx *c = res->ctx;
-    __atomic_store_n(&res->h_state[0], (unsigned)kResidentRuns, __ATOMIC_RELEASE);
-    res->h_state[1] = 0;
-    // device words: the master's "leaving" word = 0; the eight forwarded doorbells say "nothing newer than start_seq"
-    std::memset(res->h_init, 0, kResDevBytes);
-    for (int c8 = 0; c8 < 8; ++c8) res->h_init[16 + c8 * (kResMaxChannels * kBellDwords)] = start_seq;
-    GAT_HIP(c, hipMemcpyAsync(res->d_quit, res->h_init, kResDevBytes, hipMemcpyHostToDevice, res->stream));
-    res->r.start_seq = start_seq;
-    res->a.codes = c->d_codes;
-    GAT_HIP(c, launch_dc_resident(res->a, res->cfg, res->r, res->stream));
-    res->running = true;
-    ++res->launches;
-    return GAT_OK;
-}
-
-// ask the kernel to leave and wait until it has (its own limits bound the wait)
-int32_t resident_park(gat_resident *res)
-{
-    if (!res->running) return GAT_OK;
-    gat_ctx *c = res->ctx;
-    if (__atomic_load_n(&res->h_state[0], __ATOMIC_ACQUIRE) == kResidentRuns)
-        __atomic_store_n(&res->h_bell[0], kBellQuit, __ATOMIC_RELEASE);
-    GAT_HIP(c, hipStreamSynchronize(res->stream));
-    __atomic_store_n(&res->h_bell[0], res->seq, __ATOMIC_RELEASE); // line 0 is the last call's again
-    res->last_exit = __atomic_load_n(&res->h_state[0], __ATOMIC_ACQUIRE);
-    res->running = false;
-    return GAT_OK;
-}
-
-void park_residents(gat_ctx *c)
-{
-    for (gat_resident *r : c->residents) (void)resident_park(r);
-}
-
-void resident_free(gat_resident *res)
-{
-    if (res->d_quit) (void)hipFree(res->d_quit);
-    if (res->h_block) (void)hipHostFree(res->h_block);
-    if (res->stream) (void)hipStreamDestroy(res->stream);
-    delete res;
-}
-
-} // namespace
 
 namespace {
 
@@ -1528,222 +1334,6 @@ GAT_API int32_t gat_last_launch_info(const gat_ctx *c, gat_launch_info *out, siz
     // the struct grows at its end: a caller built against an older header gets the fields it knows
     std::memcpy(out, &c->last, std::min(struct_size, sizeof(gat_launch_info)));
     return GAT_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Resident correlator (include/gat.h; kernel: gat_resident.h)
-// ---------------------------------------------------------------------------------------------------------------------
-GAT_API int32_t gat_resident_open(gat_ctx *c, const gat_signal_desc *sig, int32_t K, int32_t L, const int32_t *shifts,
-                                  double fs, const gat_resident_config *config, gat_resident **out)
-{
-    if (!c) return GAT_ERR_ARG;
-    if (!out || !sig || !shifts) return fail(c, GAT_ERR_ARG, "null argument");
-    *out = nullptr;
-    if (K < 1 || K > kResMaxChannels) return fail(c, K < 1 ? GAT_ERR_ARG : GAT_ERR_UNSUPPORTED, "resident correlator: 1 .. 16 channels");
-    gat_resident_config cf{};
-    if (config) {
-        if (config->struct_size < sizeof(uint32_t)) return fail(c, GAT_ERR_ARG, "gat_resident_config.struct_size not set");
-        std::memcpy(&cf, config, std::min<size_t>(config->struct_size, sizeof cf));
-    }
-    // (every workgroup has to be ON the device for a call to complete: no more of them than compute units)
-    if ((int)cf.max_workgroups > c->num_cus) return fail(c, GAT_ERR_RANGE, "max_workgroups above the device's compute units");
-    GAT_HIP(c, hipSetDevice(c->device));
-
-    gat_resident *res = new (std::nothrow) gat_resident();
-    if (!res) return fail(c, GAT_ERR_NOMEM, "out of memory");
-    res->ctx = c;
-    auto bail = [&](int32_t rc) {
-        resident_free(res);
-        return rc;
-    };
-    // geometry: the planner's, restricted to the resident instances
-    DcPlan plan;
-    plan.max_wgs = cf.max_workgroups ? cf.max_workgroups : 64;
-    const gat_channel_params dummy[kResMaxChannels] = {};
-    float *const nonnull = reinterpret_cast<float *>(uintptr_t(64));
-    int32_t rc = correlate_impl(c, sig, nullptr, 1, K, L, shifts, fs, nonnull, nonnull, 0, dummy, &plan);
-    if (rc != GAT_OK) return bail(rc);
-    if (!dc_has_resident_instance(plan.cfg.ant_tile, plan.cfg.taps, plan.cfg.format))
-        return bail(fail(c, GAT_ERR_UNSUPPORTED, "resident correlator: no kernel instance for this shape"));
-    res->a = plan.a;
-    res->cfg = plan.cfg;
-    res->K = K;
-    res->L = L;
-    res->M = sig->num_ants;
-    res->N = sig->num_samples;
-    res->fs = fs;
-    res->spv = dc_group_samples(4, sig->layout);
-    for (int l = 0; l < L; ++l) res->max_shift = std::max<long long>(res->max_shift, std::llabs((long long)shifts[l]));
-    res->idle_us = cf.idle_us ? cf.idle_us : 5000u;
-    res->life_ms = cf.life_ms ? cf.life_ms : 2000u;
-    res->max_calls = cf.max_calls ? cf.max_calls : 0xfffffff0u;
-    int khz = 0;
-    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0) res->ticks_per_us = std::max(1, khz / 1000);
-    (void)hipGetLastError();
-
-    // pinned host block: doorbell | state | result lines of every workgroup
-    res->wgs = (int)plan.a.total_wgs;
-    res->nval = 2 * plan.cfg.ant_tile * plan.cfg.taps;
-    res->lines_per_wg = (res->nval + kResLinePayload - 1) / kResLinePayload;
-    const size_t host_bytes = kResBellBytes + 64 + kResDevBytes + (size_t)res->wgs * res->lines_per_wg * 64;
-    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&res->h_block), host_bytes, hipHostMallocCoherent | hipHostMallocMapped);
-    if (e != hipSuccess) return bail(hipfail(c, e, "hipHostMalloc"));
-    std::memset(res->h_block, 0, host_bytes);
-    unsigned char *d_host = nullptr;
-    if ((e = hipHostGetDevicePointer(reinterpret_cast<void **>(&d_host), res->h_block, 0)) != hipSuccess) return bail(hipfail(c, e, "hipHostGetDevicePointer"));
-    res->h_bell = reinterpret_cast<unsigned *>(res->h_block);
-    res->r.host_bell = reinterpret_cast<const unsigned *>(d_host);
-    res->h_state = reinterpret_cast<unsigned *>(res->h_block + kResBellBytes);
-    res->r.host_state = reinterpret_cast<unsigned *>(d_host + kResBellBytes);
-    res->h_init = reinterpret_cast<unsigned *>(res->h_block + kResBellBytes + 64); // staging of the device words' start values
-    res->h_lines = reinterpret_cast<unsigned *>(res->h_block + kResBellBytes + 64 + kResDevBytes);
-    res->r.host_lines = reinterpret_cast<unsigned *>(d_host + kResBellBytes + 64 + kResDevBytes);
-    if ((e = hipMalloc(reinterpret_cast<void **>(&res->d_quit), kResDevBytes)) != hipSuccess) return bail(hipfail(c, e, "hipMalloc"));
-    res->r.dev_quit = res->d_quit;
-    res->r.dev_bell = res->d_quit + 16;
-    res->r.forward = res->wgs > (cf.host_pollers ? (int)cf.host_pollers : kResHostPollers) ? 1 : 0;
-    // the body posts its sums through LDS: it stores nothing to device or host memory itself
-    res->a.partial = nullptr;
-    res->a.out_re = nullptr;
-    res->a.out_im = nullptr;
-    res->a.done_counter = nullptr;
-    res->a.host_flag = nullptr;
-    res->r.max_calls = res->max_calls;
-    res->r.idle_ticks = (long long)res->idle_us * res->ticks_per_us;
-    res->r.life_ticks = (long long)res->life_ms * 1000ll * res->ticks_per_us;
-    if ((e = hipStreamCreateWithFlags(&res->stream, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreateWithFlags"));
-    res->seq = 1; // "the last call": nothing is pending when the kernel starts
-    res->h_bell[0] = res->seq;
-    rc = resident_start(res, res->seq);
-    if (rc != GAT_OK) return bail(rc);
-    c->residents.push_back(res);
-    *out = res;
-    return GAT_OK;
-}
-
-GAT_API int32_t gat_resident_correlate(gat_resident *res, const gat_channel_params *params_host, int64_t block_offset,
-                                       float *out_re_host, float *out_im_host)
-{
-    if (!res) return GAT_ERR_ARG;
-    gat_ctx *c = res->ctx;
-    if (!params_host || !out_re_host || !out_im_host) return fail(c, GAT_ERR_ARG, "null argument");
-    if (res->stale) return fail(c, GAT_ERR_STATE, "the code table changed: open the resident correlator again");
-    if (block_offset < 0 || block_offset % res->spv != 0 || block_offset >= (1ll << 40))
-        return fail(c, GAT_ERR_ARG, "block offset must be a non-negative multiple of the samples one 16-byte load holds");
-    int32_t rc = validate_params(c, params_host, (size_t)res->K, (double)(res->N + res->max_shift), res->fs);
-    if (rc != GAT_OK) return rc;
-
-    // ring: one line per channel, line 0 last; inside a line the two sequence words last
-    unsigned prev = res->seq, seq = prev + 1;
-    if (seq == 0u || seq == kBellQuit) seq = 1;
-    if (seq == prev) ++seq;
-    for (int k = res->K - 1; k >= 0; --k) {
-        unsigned w[kBellDwords] = {};
-        w[0] = seq;
-        std::memcpy(&w[2], &params_host[k], sizeof(gat_channel_params));
-        w[3] = 0; // the record's reserved word
-        std::memcpy(&w[12], &block_offset, sizeof(int64_t));
-        unsigned x = 0;
-        for (int i = 0; i < 14; ++i) x ^= w[i];
-        w[14] = x;
-        w[15] = seq;
-        unsigned *line = res->h_bell + (size_t)k * kBellDwords;
-        for (int i = 1; i < 15; ++i) line[i] = w[i];
-        __atomic_store_n(&line[15], seq, __ATOMIC_RELEASE);
-        __atomic_store_n(&line[0], seq, __ATOMIC_RELEASE);
-    }
-    res->seq = seq;
-    if (!res->running || __atomic_load_n(&res->h_state[0], __ATOMIC_ACQUIRE) != kResidentRuns) {
-        if (res->running) res->last_exit = res->h_state[0];
-        GAT_HIP(c, hipSetDevice(c->device));
-        if ((rc = resident_start(res, prev)) != GAT_OK) return rc;
-    }
-    // wait: every result line of every workgroup carries the call's number and passes its check
-    const int nlines = res->wgs * res->lines_per_wg;
-    auto answered = [&]() {
-        const unsigned *ln = res->h_lines;
-        for (int j = nlines - 1; j >= 0; --j) { // (the last line first: the first workgroups tend to be done first)
-            if (__atomic_load_n(&ln[(size_t)j * 16 + 15], __ATOMIC_RELAXED) != seq) return false;
-            unsigned x = seq;
-            for (int i = 0; i < kResLinePayload; ++i) x ^= __atomic_load_n(&ln[(size_t)j * 16 + i], __ATOMIC_RELAXED);
-            if (__atomic_load_n(&ln[(size_t)j * 16 + 14], __ATOMIC_RELAXED) != x) return false;
-        }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
-        return true;
-    };
-    const double t0 = mono_us(), deadline = (double)res->life_ms * 1000.0 + 1.0e6;
-    for (unsigned spins = 0;; ++spins) {
-        if (answered()) break;
-        if ((spins & 15u) != 15u) continue;
-        if (__atomic_load_n(&res->h_state[0], __ATOMIC_ACQUIRE) != kResidentRuns) {
-            // the kernel has left (idle, lifetime, call budget) -- with this call served or not
-            if (answered()) break;
-            res->last_exit = res->h_state[0];
-            GAT_HIP(c, hipSetDevice(c->device));
-            if ((rc = resident_start(res, prev)) != GAT_OK) return rc;
-        }
-        if (mono_us() - t0 > deadline) {
-            (void)resident_park(res);
-            return fail(c, GAT_ERR_STATE, "resident correlator: no answer from the device");
-        }
-    }
-    // second stage on the host: the workgroups' sums added split by split in fixed order (deterministic)
-    const size_t n = (size_t)res->K * res->L * res->M;
-    std::memset(out_re_host, 0, n * sizeof(float));
-    std::memset(out_im_host, 0, n * sizeof(float));
-    const int MT = res->cfg.ant_tile, KG = res->a.KG, AG = res->a.ant_groups, SP = res->a.splits;
-    const float *lines = reinterpret_cast<const float *>(res->h_lines);
-    for (int sp = 0; sp < SP; ++sp)
-        for (int ag = 0; ag < AG; ++ag)
-            for (int kg = 0; kg < KG; ++kg) {
-                const size_t slot = ((size_t)ag * SP + sp) * KG + kg; // the kernel's: tile * KG + kg, tile = ag * splits + split
-                const float *w = lines + slot * res->lines_per_wg * 16;
-                for (int o = 0; o < res->nval; ++o) {
-                    const float v = w[(o / kResLinePayload) * 16 + o % kResLinePayload];
-                    const int ml = o >> 1, m = ag * MT + ml % MT, l = res->a.tap_index[ml / MT];
-                    float *dst = (o & 1) ? out_im_host : out_re_host;
-                    dst[((size_t)kg * res->L + l) * res->M + m] += v;
-                }
-            }
-    ++res->calls;
-    return GAT_OK;
-}
-
-GAT_API int32_t gat_resident_info_get(const gat_resident *res, gat_resident_info *out, size_t struct_size)
-{
-    if (!res || !out || struct_size == 0) return GAT_ERR_ARG;
-    gat_resident_info i{};
-    i.workgroups = (int32_t)res->a.total_wgs;
-    i.splits = res->a.splits;
-    const bool ended = res->running && __atomic_load_n(&res->h_state[0], __ATOMIC_ACQUIRE) != kResidentRuns;
-    i.running = res->running && !ended ? 1 : 0;
-    i.last_exit = (int32_t)(ended ? res->h_state[0] : res->last_exit);
-    i.launches = res->launches;
-    i.calls = res->calls;
-    std::memcpy(out, &i, std::min(struct_size, sizeof i));
-    return GAT_OK;
-}
-
-GAT_API int32_t gat_resident_park(gat_resident *res)
-{
-    if (!res) return GAT_ERR_ARG;
-    (void)hipSetDevice(res->ctx->device);
-    return resident_park(res);
-}
-
-GAT_API int32_t gat_resident_close(gat_resident *res)
-{
-    if (!res) return GAT_ERR_ARG;
-    gat_ctx *c = res->ctx;
-    (void)hipSetDevice(c->device);
-    const int32_t rc = resident_park(res);
-#ifdef GAT_RES_STAMPS
-    std::fprintf(stderr, "resident stamps of the last call (10 ns ticks): ring seen -> barrier + acquire %u; then tile decode %u, first loads issued %u, parameters %u, setup (barrier) %u, first segment %u, steps %u, reduction %u, result lines %u (= %u counts of clock64)\n",
-                 res->h_state[11], res->h_state[4 + 1], res->h_state[12], res->h_state[13], res->h_state[4 + 2], res->h_state[4 + 3], res->h_state[4 + 4], res->h_state[4 + 5], res->h_state[4 + 6], res->h_state[14]);
-#endif
-    c->residents.erase(std::remove(c->residents.begin(), c->residents.end(), res), c->residents.end());
-    resident_free(res);
-    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -4,8 +4,8 @@ generators, tap-shift helper) with -fsanitize=address,undefined,float-cast-overf
 oracle/sanitize/sanitize_main.c (ragged sizes, negative taps at n = 0, ratio = 1/16 with code phases within an ulp of
 chip edges, carrier phases that round to a whole cycle, GPS L5 lengths).  Any report aborts the run.
 
-`make -C tests/hostsim run` does the same for the REST of the library's host code -- csrc/gat_api.cpp: validation, launch
-planning, scratch management, graph cache, device groups, the resident correlator's host side -- by linking it against a
+`make -C tests/hostsim run` does the same for the REST of the library's host code -- csrc/gat_api.cpp (validation, launch
+planning, scratch management, graph cache, device groups) and csrc/gat_resident_api.cpp (the resident correlator's host side) -- by linking it against a
 host-only stand-in of the HIP runtime ("device" memory = host memory: every copy size is checked) and of the kernel
 launchers, which check each planned launch against what the kernel assumes about its arguments (LDS carve-up, replica
 room, grid decode, tap tables) and play the device's side of the resident correlator's doorbell protocol in a thread."""
