@@ -18,7 +18,7 @@ from .context import Context, ResidentCorrelator, get_context  # noqa: F401
 from .correlator import (EarlyPromptLateCorrelator, NumAccumulators, NumAnts, get_accumulators,  # noqa: F401
                          get_correlator_sample_shifts, get_num_accumulators, get_num_ants)
 from .gen_signal import StructSignal, gen_blank_signal, gen_signal, gen_signal_stream, make_params  # noqa: F401
-from .loop import TrackingLoop  # noqa: F401
+from .loop import ResidentTrackingLoop, TrackingLoop  # noqa: F401
 from .sharding import DeviceGroup, ShardPlan, gather_outputs, shard_channels, shard_params  # noqa: F401
 from .signals import GNSSDICT, GPSL1, GPSL5, generate_codes, get_code_frequency, get_code_length  # noqa: F401
 from .tracking import (StreamCorrelator, downconvert_and_accumulate_strided, downconvert_and_correlate,  # noqa: F401

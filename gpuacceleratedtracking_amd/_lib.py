@@ -38,6 +38,7 @@ EXPORTS = [
     "gat_group_gather", "gat_group_sync",
     # resident correlator: single-block calls without a kernel launch
     "gat_resident_open", "gat_resident_correlate", "gat_resident_info_get", "gat_resident_park", "gat_resident_close",
+    "gat_tracking_update_host",
 ]
 
 
@@ -185,6 +186,7 @@ def load(build_if_missing: bool = True):
         "gat_resident_info_get": (i32, [vp, C.POINTER(ResidentInfo), C.c_size_t]),
         "gat_resident_park": (i32, [vp]),
         "gat_resident_close": (i32, [vp]),
+        "gat_tracking_update_host": (i32, [vp, vp, i32, i32, C.POINTER(LoopConfig), vp, vp, vp]),
     }
     assert sorted(sigs) == sorted(EXPORTS)
     for name, (res, args) in sigs.items():

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "gat.h"
+#include "gat_loop.h"
 
 namespace {
 
@@ -103,5 +104,26 @@ extern "C" GAT_API int32_t gat_sample_shifts(int32_t L, double fs, double fc, do
     const double x = std::nearbyint(spacing * fs / fc); // round-half-even like Julia round(Int, x)
     long long s = x >= 1.0 ? (x < 1.0e9 ? (long long)x : 1000000000ll) : 1;
     for (int l = 0; l < L; ++l) shifts[l] = (int32_t)((l - L / 2) * s);
+    return GAT_OK;
+}
+
+// The closed loop's update on the HOST: what gat_tracking_update does on the device (the same text, gat_loop.h), for a
+// receiver that has its correlator outputs on the host -- from a resident correlator -- and closes its loops there, as
+// Tracking.jl does.  next_host may alias cur_host.
+extern "C" GAT_API int32_t gat_tracking_update_host(const float *acc_re_host, const float *acc_im_host, int32_t num_channels, int32_t num_ants,
+                                                    const gat_loop_config *config, gat_loop_state *state_host, const gat_channel_params *cur_host,
+                                                    gat_channel_params *next_host)
+{
+    if (!acc_re_host || !acc_im_host || !config || !state_host || !cur_host || !next_host) return GAT_ERR_ARG;
+    if (num_channels < 1 || num_ants < 1) return GAT_ERR_ARG;
+    const int L = config->num_taps;
+    if (L < 1 || L > GAT_MAX_TAPS || config->early_index < 0 || config->early_index >= L || config->prompt_index < 0 || config->prompt_index >= L ||
+        config->late_index < 0 || config->late_index >= L || config->code_length < 1 || !(config->block_seconds > 0.0))
+        return GAT_ERR_RANGE;
+    for (int k = 0; k < num_channels; ++k) {
+        gat_channel_params n;
+        gat::loop_update_channel(acc_re_host, acc_im_host, k, num_ants, *config, state_host[k], cur_host[k], n);
+        next_host[k] = n;
+    }
     return GAT_OK;
 }

@@ -124,3 +124,66 @@ class TrackingLoop:
     def accumulators(self) -> np.ndarray:
         """complex64 [K, L, M] of the last block."""
         return (self.out_re.cpu().numpy() + 1j * self.out_im.cpu().numpy())[0].astype(np.complex64)
+
+
+class ResidentTrackingLoop:
+    """The closed loop with the HOST in it, as in the reference's receiver (Tracking.jl's discriminators and loop filters run on
+    the CPU): one step = one call rung into a resident correlator (``gat_resident_correlate``: no kernel launch, outputs
+    arrive on the host) + ``gat_tracking_update_host`` (the arithmetic of the device's ``gat_tracking_update``, csrc/gat_loop.h)
+    that turns the accumulators into the next block's parameters.  Same constructor as ``TrackingLoop`` plus the signal
+    buffer the blocks live in; up to 16 channels (it pays for up to four)."""
+
+    def __init__(self, system: GNSSSystem, prns, num_samples: int, num_ants: int, sampling_frequency: float,
+                 correlator_sample_shifts, init_carrier_doppler, init_code_phase, re: torch.Tensor, im: torch.Tensor | None = None,
+                 if_hz: float = 0.0, carrier_center_hz: float = 1575.42e6, pll_bandwidth_hz: float = 18.0,
+                 dll_bandwidth_hz: float = 1.0, init_carrier_phase=0.0, device=None, ctx: Context | None = None, **resident_config):
+        # the loop configuration, parameters and state: TrackingLoop's, kept on the host
+        dev_loop = TrackingLoop(system, prns, num_samples, num_ants, sampling_frequency, correlator_sample_shifts, init_carrier_doppler,
+                                init_code_phase, if_hz, carrier_center_hz, pll_bandwidth_hz, dll_bandwidth_hz, init_carrier_phase, device, ctx)
+        self.ctx, self.system, self.config = dev_loop.ctx, system, dev_loop.config
+        self.K, self.N, self.M, self.L, self.fs, self.shifts = dev_loop.K, dev_loop.N, dev_loop.M, dev_loop.L, dev_loop.fs, dev_loop.shifts
+        self._cur = dev_loop.params().reshape(-1).copy()
+        self._next = self._cur.copy()
+        self._state = dev_loop.state().copy()
+        self._signal = (re, im)  # kept alive: the resident kernel reads it
+        desc = _signal_desc(re, im, self.N, start=0)
+        torch.cuda.current_stream(self.ctx.device).synchronize()  # the signal is on the device before the first ring
+        self.resident = self.ctx.open_resident(desc, self.K, self.shifts, self.fs, **resident_config)
+        self._lib = self.ctx.lib
+        self._fn = self._lib.gat_tracking_update_host
+        self.acc_re = self.acc_im = None
+        self.blocks_done = 0
+
+    def step(self, start: int = 0):
+        """Correlate the block that starts ``start`` samples into the buffer with the current parameters, update them."""
+        re, im = self.resident.correlate(self._cur, block_offset=start)
+        rc = self._fn(C.c_void_p(re.ctypes.data), C.c_void_p(im.ctypes.data), self.K, self.M, C.byref(self.config),
+                      C.c_void_p(self._state.ctypes.data), C.c_void_p(self._cur.ctypes.data), C.c_void_p(self._next.ctypes.data))
+        if rc != 0:
+            raise _lib.GatError(rc, "gat_tracking_update_host")
+        self._cur, self._next = self._next, self._cur
+        self.acc_re, self.acc_im = re, im
+        self.blocks_done += 1
+
+    def run(self, num_blocks: int, start: int = 0):
+        for b in range(int(num_blocks)):
+            self.step(start + b * self.N)
+
+    def params(self) -> np.ndarray:
+        return self._cur.copy()
+
+    def state(self) -> np.ndarray:
+        return self._state.copy()
+
+    def accumulators(self) -> np.ndarray:
+        """complex64 [K, L, M] of the last block."""
+        return (self.acc_re + 1j * self.acc_im).astype(np.complex64)
+
+    def close(self):
+        self.resident.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -289,6 +289,13 @@ GAT_API int32_t gat_tracking_update(gat_ctx *ctx, const float *acc_re_dev, const
                                     const gat_loop_config *config_host, gat_loop_state *state_dev,
                                     const gat_channel_params *cur_dev, gat_channel_params *next_dev);
 
+/* The same update on the HOST (the same arithmetic: csrc/gat_loop.h), for a receiver that takes its correlator outputs on
+ * the host -- from a resident correlator, below -- and closes its loops there, as Tracking.jl does.  All pointers are host
+ * memory; next_host may alias cur_host.  Needs no context and no device. */
+GAT_API int32_t gat_tracking_update_host(const float *acc_re_host, const float *acc_im_host, int32_t num_channels,
+                                         int32_t num_ants, const gat_loop_config *config_host, gat_loop_state *state_host,
+                                         const gat_channel_params *cur_host, gat_channel_params *next_host);
+
 /* num_blocks consecutive integration blocks of a device-resident signal (block b starts b * sig->block_stride
  * samples in) through {correlate, tracking update} with the parameters ping-ponging between params_a (current at
  * entry) and params_b: 2 * num_blocks launches enqueued from native code, no host round trip and no

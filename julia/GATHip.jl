@@ -543,6 +543,14 @@ function memcpy_peer!(g::DeviceGroup, dst_rank::Integer, dst::Ptr{Cvoid}, src_ra
                     member_handle(g, dst_rank), dst, member_handle(g, src_rank), src, bytes))
 end
 
+# the closed loop's update on the host (same arithmetic as gat_tracking_update on the device): `acc_re` / `acc_im` are HOST arrays
+# [M x L x K] of one block -- e.g. a `Resident`'s `re` / `im` --, `state` / `cur` / `next` host vectors of length K
+tracking_update_host!(acc_re::Array{Float32}, acc_im::Array{Float32}, num_channels::Integer, num_ants::Integer, cfg::LoopConfig,
+                      state::Vector{LoopState}, cur::Vector{ChannelParams}, next::Vector{ChannelParams}) =
+    ccall((:gat_tracking_update_host, libgat), Int32,
+          (Ptr{Cfloat}, Ptr{Cfloat}, Int32, Int32, Ref{LoopConfig}, Ptr{LoopState}, Ptr{ChannelParams}, Ptr{ChannelParams}),
+          acc_re, acc_im, Int32(num_channels), Int32(num_ants), Ref(cfg), state, cur, next) == GAT_OK || throw(GatError(Int32(1), "gat_tracking_update_host"))
+
 # ---- resident correlator: what `@benchmark CUDA.@sync kernel_algorithm(...)` (src/benchmarks.jl:120-146) times, without
 #      the launch -- one kernel stays on the device for a fixed call geometry (signal buffer, channels, taps), a call rings
 #      it through pinned host memory and returns the outputs on the host, ComplexF32 [M x L x K].  The kernel ends by itself

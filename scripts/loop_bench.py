@@ -1,4 +1,6 @@
-"""Closed tracking loop per 1 ms block: per-block step() calls from Python vs one native gat_tracking_run call."""
+"""Closed tracking loop per 1 ms block: per-block step() calls from Python vs one native gat_tracking_run call (both never
+leave the device), and the loop with the HOST in it -- a resident correlator's call + gat_tracking_update_host per block, as
+the reference's receiver closes its loops on the CPU (ResidentTrackingLoop; K <= 16)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,7 +10,7 @@ import gpuacceleratedtracking_amd as g
 system = g.GPSL1()
 side = torch.cuda.Stream()
 torch.cuda.set_stream(side)  # a non-default stream: hipGraph capture is not allowed on the legacy default stream
-for (K, M, fs) in ((12, 4, 20e6), (4, 16, 50e6)):
+for (K, M, fs) in ((1, 4, 4e6), (4, 4, 20e6), (12, 4, 20e6), (4, 16, 50e6)):
     N, nblk = int(fs * 1e-3), 400
     prns = np.arange(1, K + 1)
     dop = np.linspace(-3000, 3000, K)
@@ -29,3 +31,10 @@ for (K, M, fs) in ((12, 4, 20e6), (4, 16, 50e6)):
     ctx.sync(); t_graph = (time.perf_counter() - t0) / nblk
     print(f"   hipGraph replay {t_graph*1e6:.1f} us (RTF {1e-3/t_graph:.0f})")
     print(f"K={K} M={M} fs={fs/1e6:g} MHz: per-block step() {t_step*1e6:.1f} us (RTF {1e-3/t_step:.0f}) | native run {t_run*1e6:.1f} us (RTF {1e-3/t_run:.0f})")
+    if K <= 16:
+        torch.cuda.synchronize()
+        with g.ResidentTrackingLoop(system, prns, N, M, fs, shifts, re=re, im=im, init_carrier_doppler=dop, init_code_phase=np.linspace(5, 900, K),
+                                    idle_us=200000) as h:
+            h.run(20); t0 = time.perf_counter(); h.run(nblk - 20); t_host = (time.perf_counter() - t0) / (nblk - 20)
+            print(f"   host-closed loop through the resident correlator: {t_host*1e6:.1f} us per block (RTF {1e-3/t_host:.0f}), "
+                  f"{h.resident.info()['workgroups']} workgroups (Python host layer; every block's accumulators and parameters are on the host)")

@@ -174,6 +174,16 @@ int main(int argc, char **argv)
                                     (float *)are, (float *)aim, (long long)K * L * M, GAT_FLAG_GRAPH, &is_b) == GAT_OK, "tracking run %d: %s", rep, gat_last_error(ctx));
         }
         EXPECT(hostsim::counters.graph_launches >= 3, "the repeated tracking run replays its graph (%ld replays)", hostsim::counters.graph_launches.load());
+        { // the loop's update on the host (needs no device): K channels of the accumulators left in `are` / `aim`
+            std::vector<gat_loop_state> hs(K);
+            std::vector<gat_channel_params> hc(K, gat_channel_params{1, 0, fc, 1000.0, 10.0, 0.0}), hn(K);
+            std::vector<float> hre((size_t)K * L * M, 100.f), him((size_t)K * L * M, -3.f);
+            EXPECT(gat_tracking_update_host(hre.data(), him.data(), K, M, &cfg, hs.data(), hc.data(), hn.data()) == GAT_OK && hn[0].code_freq_hz > 0.0, "host loop update");
+            EXPECT(gat_tracking_update_host(hre.data(), him.data(), K, M, &cfg, hs.data(), hc.data(), hc.data()) == GAT_OK, "host loop update in place");
+            gat_loop_config badc = cfg;
+            badc.prompt_index = L;
+            EXPECT(gat_tracking_update_host(hre.data(), him.data(), K, M, &badc, hs.data(), hc.data(), hn.data()) == GAT_ERR_RANGE, "host loop update: tap index");
+        }
         EXPECT(gat_tracking_update(ctx, (float *)are, (float *)aim, K, M, &cfg, (gat_loop_state *)state, (gat_channel_params *)pa, (gat_channel_params *)pb) == GAT_OK, "tracking update");
         void *rep;
         gat_malloc(ctx, sizeof(float) * (N + 2) * 2, &rep);

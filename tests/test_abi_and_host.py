@@ -134,6 +134,40 @@ def test_sample_shifts_match_oracle(g, L, fs, fc):
     assert got.tolist() == oracle.sample_shifts(L, fs, fc).tolist()
 
 
+def test_host_loop_update_matches_oracle_restatement(g):
+    """gat_tracking_update_host (the device kernel's arithmetic on the host, csrc/gat_loop.h; needs no GPU) against the oracle's
+    restatement of the loop equations, several steps so that the filter integrators are exercised; error codes."""
+    lib = g.load_library()
+    L_ = g._lib
+    K, M, L = 5, 3, 3
+    rng = np.random.default_rng(4)
+    cfg = L_.LoopConfig(1e-3, 18.0, 2.0, 1.023e6, 1575.42e6, 1.0e5, 1.0, 1023, L, 0, 1, 2)
+    cfgd = {n: getattr(cfg, n) for n, _ in cfg._fields_}
+    dop = rng.uniform(-3e3, 3e3, K)
+    cur = g.make_params(np.arange(K), 1.023e6 + dop * 1.023e6 / 1575.42e6, 1.0e5 + dop, rng.uniform(0, 1023, K), rng.uniform(0, 1, K), shape=(K,))
+    nxt = cur.copy()
+    st = np.zeros(K, dtype=L_.LOOP_STATE_DTYPE)
+    st["init_carrier_doppler_hz"] = dop
+    st["carrier_doppler_hz"] = dop
+    ostate = {n: st[n].copy() for n in st.dtype.names}
+    ocur = oracle.make_params(cur["prn"], cur["code_freq_hz"], cur["carrier_freq_hz"], cur["code_phase_chips"], cur["carrier_phase_cycles"])
+    vp = C.c_void_p
+    for it in range(5):
+        acc = (rng.standard_normal((K, L, M)) + 1j * rng.standard_normal((K, L, M))).astype(np.complex64) * 1000
+        re, im = np.ascontiguousarray(acc.real), np.ascontiguousarray(acc.imag)
+        assert lib.gat_tracking_update_host(vp(re.ctypes.data), vp(im.ctypes.data), K, M, C.byref(cfg), vp(st.ctypes.data), vp(cur.ctypes.data),
+                                            vp(nxt.ctypes.data)) == 0
+        cur, nxt = nxt, cur
+        ocur, ostate = oracle.np_tracking_update(acc, cfgd, ostate, ocur)
+        for f in ("code_freq_hz", "carrier_freq_hz", "code_phase_chips", "carrier_phase_cycles"):
+            assert np.allclose(cur[f], ocur[f], rtol=1e-12, atol=1e-9), (it, f)
+        for name in ostate:
+            assert np.allclose(st[name], ostate[name], rtol=1e-10, atol=1e-9), (it, name)
+    bad = L_.LoopConfig(1e-3, 18.0, 2.0, 1.023e6, 1575.42e6, 0.0, 1.0, 1023, L, 0, 1, 7)  # late tap outside the list
+    assert lib.gat_tracking_update_host(vp(re.ctypes.data), vp(im.ctypes.data), K, M, C.byref(bad), vp(st.ctypes.data), vp(cur.ctypes.data), vp(nxt.ctypes.data)) == 2
+    assert lib.gat_tracking_update_host(None, vp(im.ctypes.data), K, M, C.byref(cfg), vp(st.ctypes.data), vp(cur.ctypes.data), vp(nxt.ctypes.data)) == 1
+
+
 def test_selectors_and_dicts(g):
     assert g.KernelAlgorithm(1330) == g.KernelAlgorithm(1330) != g.KernelAlgorithm(1331)
     assert g.ALGODICT["4_4_cplx_multi_textmem"] == 4431 and g.ALGODICTINV[4431] == "4_4_cplx_multi_textmem"

@@ -275,3 +275,38 @@ def test_two_systems_share_one_context(g):
             op = ops[name][0]
             op(sig[name], zero)
             assert op.result()[0, 0, 0, 0].real == N, (order, name)
+
+
+def test_host_closed_loop_through_the_resident_correlator(g):
+    """The loop with the host in it (ResidentTrackingLoop: a call rung into a resident correlator + gat_tracking_update_host per
+    block, as the reference's receiver closes its loops on the CPU) against the loop that never leaves the device
+    (TrackingLoop.run), same signal and start values: both sit on the truth, and on each other -- the correlator outputs of
+    the two differ in summation order only (1e-7), which the discriminators see as 1e-7 of a cycle."""
+    system = g.GPSL1()
+    N, M, fs, fc, nblk = 4000, 2, 4e6, 1.023e6, 600
+    prns = np.array([3, 11, 25])
+    true_dop = np.array([1500.0, -800.0, 2400.0])
+    tau0, phi0 = np.array([200.4, 700.1, 33.3]), np.array([0.2, 0.7, 0.4])
+    fcode = fc * (1 + true_dop / 1575.42e6)
+    b = np.arange(nblk, dtype=np.float64)[:, None]
+    prm_sig = g.make_params(prns - 1, fcode, true_dop, np.mod(tau0[None, :] + fcode[None, :] * (N / fs) * b, 1023.0),
+                            2 * np.pi * np.mod(phi0[None, :] + true_dop[None, :] * (N / fs) * b, 1.0), shape=(nblk, prns.size))
+    re, im = g.gen_signal_stream(system, prm_sig, fs, N, M)
+    shifts = g.get_correlator_sample_shifts(system, g.EarlyPromptLateCorrelator(M, 3), fs, 0.5)
+    kw = dict(init_carrier_doppler=true_dop + 8.0, init_code_phase=tau0 + 0.1, init_carrier_phase=0.0, dll_bandwidth_hz=4.0)
+    dev = g.TrackingLoop(system, prns, N, M, fs, shifts, **kw)
+    dev.run(re, im, nblk, keep=False)
+    dev.ctx.sync()
+    import torch
+    torch.cuda.synchronize()
+    with g.ResidentTrackingLoop(system, prns, N, M, fs, shifts, re=re, im=im, idle_us=200000, **kw) as host:
+        host.run(nblk)
+        info = host.resident.info()
+        hs, hp, hacc = host.state(), host.params(), host.accumulators()
+    ds, dp = dev.state(), dev.params().reshape(-1)
+    assert info["calls"] == nblk
+    assert np.abs(hs["carrier_doppler_hz"] - true_dop).max() < 1.0 and np.abs(ds["carrier_doppler_hz"] - true_dop).max() < 1.0
+    assert np.abs(hs["carrier_doppler_hz"] - ds["carrier_doppler_hz"]).max() < 1e-3
+    assert np.abs(hp["code_phase_chips"] - dp["code_phase_chips"]).max() < 1e-4
+    assert np.abs(hp["carrier_freq_hz"] - dp["carrier_freq_hz"]).max() < 1e-3
+    assert (np.abs(hacc[:, 1, :]) > 0.85 * N).all()  # prompt ~ N on every antenna of every channel
