@@ -1,6 +1,11 @@
 """Closed tracking loop per 1 ms block: per-block step() calls from Python vs one native gat_tracking_run call (both never
 leave the device), and the loop with the HOST in it -- a resident correlator's call + gat_tracking_update_host per block, as
-the reference's receiver closes its loops on the CPU (ResidentTrackingLoop; K <= 16)."""
+the reference's receiver closes its loops on the CPU (ResidentTrackingLoop; K <= 16).
+usage: python scripts/loop_bench.py [K,M,fs ...]
+(The per-block step() column of every third shape in one process reads ~110 us instead of ~16: the time sits inside
+hipLaunchKernel on the host -- 45 us per launch for that whole 400-step loop, device kernels unchanged at 7 us, whatever the shape
+and whether the recorded graphs are dropped or not: scripts/probes/loop_step_probe.py, rocprofv3 --hip-trace.  The native run,
+the graph replay and the resident correlator do not go through that path.)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,7 +15,7 @@ import gpuacceleratedtracking_amd as g
 system = g.GPSL1()
 side = torch.cuda.Stream()
 torch.cuda.set_stream(side)  # a non-default stream: hipGraph capture is not allowed on the legacy default stream
-for (K, M, fs) in ((1, 4, 4e6), (4, 4, 20e6), (12, 4, 20e6), (4, 16, 50e6)):
+for (K, M, fs) in [tuple(float(x) if i == 2 else int(x) for i, x in enumerate(s.split(","))) for s in sys.argv[1:]] or ((1, 4, 4e6), (4, 4, 20e6), (12, 4, 20e6), (4, 16, 50e6)):
     N, nblk = int(fs * 1e-3), 400
     prns = np.arange(1, K + 1)
     dop = np.linspace(-3000, 3000, K)
@@ -31,7 +36,7 @@ for (K, M, fs) in ((1, 4, 4e6), (4, 4, 20e6), (12, 4, 20e6), (4, 16, 50e6)):
     ctx.sync(); t_graph = (time.perf_counter() - t0) / nblk
     print(f"   hipGraph replay {t_graph*1e6:.1f} us (RTF {1e-3/t_graph:.0f})")
     print(f"K={K} M={M} fs={fs/1e6:g} MHz: per-block step() {t_step*1e6:.1f} us (RTF {1e-3/t_step:.0f}) | native run {t_run*1e6:.1f} us (RTF {1e-3/t_run:.0f})")
-    if K <= 16:
+    if K <= 16 and not os.environ.get("GAT_LOOP_BENCH_NO_RESIDENT"):
         torch.cuda.synchronize()
         with g.ResidentTrackingLoop(system, prns, N, M, fs, shifts, re=re, im=im, init_carrier_doppler=dop, init_code_phase=np.linspace(5, 900, K),
                                     idle_us=200000) as h:
