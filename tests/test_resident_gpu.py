@@ -107,6 +107,25 @@ def test_resident_integer_samples(gat, N, M, L, K, dtype, amp, layout):
             check_close((re + 1j * im)[None], ref[b:b + 1], what=f"{dtype.__name__} block {b}")
 
 
+def test_resident_one_signal_per_channel(gat):
+    """chan_stride != 0 (the reference's _3d_4431! form, src/algorithms.jl:668): channel k correlates ITS signal."""
+    import torch
+    g = gat
+    N, M, L, K = 8192, 2, 3, 3
+    cases = [make_case(40 + k, N=N, M=M, L=L, K=1, B=1) for k in range(K)]
+    ctx = g.get_context()
+    ctx.set_codes(cases[0]["codes"])
+    re = torch.from_numpy(np.stack([c["re"] for c in cases])).to(ctx.device)  # [K, M, N]
+    im = torch.from_numpy(np.stack([c["im"] for c in cases])).to(ctx.device)
+    torch.cuda.synchronize()
+    desc = g._lib.SignalDesc(re.data_ptr(), im.data_ptr(), g.GAT_LAYOUT_PLANAR, M, N, N, N, M * N)
+    prm = np.concatenate([_params(g, c, 0) for c in cases])
+    with ctx.open_resident(desc, K, cases[0]["shifts"], cases[0]["fs"], idle_us=200000) as res:
+        r, i = res.correlate(prm)
+        for k, c in enumerate(cases):
+            check_close((r[k:k + 1] + 1j * i[k:k + 1])[None], oracle_result(c), what=f"channel {k} on its own signal")
+
+
 def test_resident_calls_are_bit_identical_and_agree_with_the_ordinary_call(gat):
     g = gat
     import torch
