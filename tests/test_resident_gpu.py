@@ -64,6 +64,9 @@ def _open(g, case, layout=0, **config):
     (8192, 2, 3, 7, 0, 0, 64),    # seven channels: two 256-byte doorbell groups, every workgroup polling the host
     (20000, 4, 3, 12, 0, 0, 0),   # a whole constellation in one call: twelve channels, forwarded doorbell (72 workgroups)
     (4096, 1, 3, 16, 1, 16, 0),   # sixteen channels, one workgroup each
+    (2052, 4, 3, 1, 0, 0, 0),     # blocks that start 16 / 32 / 48 ... bytes into a 128-byte line: walked from the line, trimmed per call
+    (20004, 3, 5, 2, 0, 0, 0),
+    (6146, 2, 3, 1, 1, 0, 0),     # ComplexF32 pairs, block starts 16 bytes off the line
 ])
 def test_resident_matches_oracle(gat, N, M, L, K, layout, max_wgs, pollers):
     g = gat
