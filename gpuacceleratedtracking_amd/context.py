@@ -278,15 +278,22 @@ class ResidentCorrelator:
         self._im = np.empty(self.shape, dtype=np.float32)
         self._fn = self.lib.gat_resident_correlate
         self._pre, self._pim = C.c_void_p(self._re.ctypes.data), C.c_void_p(self._im.ctypes.data)
+        self._prm_obj, self._prm_ptr = None, None
 
     def correlate(self, params, block_offset: int = 0):
         """params: structured array of ``num_channels`` records (``_lib.PARAMS_DTYPE``).  Returns (re, im): float32 views
         [K, L, M] that the NEXT call overwrites (copy what has to last)."""
-        prm = params if (isinstance(params, np.ndarray) and params.dtype == _lib.PARAMS_DTYPE and params.flags.c_contiguous) \
-            else np.ascontiguousarray(params, dtype=_lib.PARAMS_DTYPE)
-        if prm.size != self.shape[0]:
-            raise ValueError("params must hold num_channels entries")
-        rc = self._fn(self._h, prm.ctypes.data_as(C.POINTER(_lib.ChannelParams)), int(block_offset), self._pre, self._pim)
+        if params is self._prm_obj:  # a loop that rewrites one record array in place: its pointer is converted once
+            pp = self._prm_ptr
+        else:
+            prm = params if (isinstance(params, np.ndarray) and params.dtype == _lib.PARAMS_DTYPE and params.flags.c_contiguous) \
+                else np.ascontiguousarray(params, dtype=_lib.PARAMS_DTYPE)
+            if prm.size != self.shape[0]:
+                raise ValueError("params must hold num_channels entries")
+            pp = prm.ctypes.data_as(C.POINTER(_lib.ChannelParams))
+            if prm is params:
+                self._prm_obj, self._prm_ptr = params, pp
+        rc = self._fn(self._h, pp, int(block_offset), self._pre, self._pim)
         if rc != 0:
             self.ctx.check(rc, "gat_resident_correlate")
         return self._re, self._im
