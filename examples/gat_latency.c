@@ -12,7 +12,7 @@
  *   call   : host time inside the `dev` call itself (planning + the launches), median -- the rest of `dev` is waiting
  *   resident: gat_resident_correlate -- the call rung into a kernel that stays on the device (no launch, no stream wait),
  *             outputs copied to the host included; "wgs" = workgroups of that kernel
- * Output: one line per grid point, minimum / median in microseconds.   build/gat_latency [reps [resident max_workgroups [host_pollers]]]
+ * Output: one line per grid point, minimum / median in microseconds.   build/gat_latency [reps [resident max_workgroups [host_pollers [doorbell]]]]
  */
 #include <math.h>
 #include <stdio.h>
@@ -45,6 +45,7 @@ int main(int argc, char **argv)
     const int reps = argc > 1 ? atoi(argv[1]) : 2000;
     const unsigned res_wgs = argc > 2 ? (unsigned)atoi(argv[2]) : 0u; /* resident correlator: max_workgroups (0: library default) */
     const unsigned res_pollers = argc > 3 ? (unsigned)atoi(argv[3]) : 0u; /* ... host_pollers (0: library default) */
+    const unsigned res_bell = argc > 4 ? (unsigned)atoi(argv[4]) : 0u;    /* ... doorbell: 0 library's choice, 1 pinned host memory, 2 device memory */
     CHECK(gat_create(0, GAT_OWN_STREAM, &ctx));
     double *t = malloc(sizeof(double) * (size_t)reps), *tc = malloc(sizeof(double) * (size_t)reps);
     const int Ms[2] = {1, 4}, Ls[2] = {3, 7};
@@ -107,7 +108,7 @@ int main(int argc, char **argv)
                 int rwgs = 0;
                 {
                     gat_resident *rs = NULL;
-                    const gat_resident_config rcfg = {sizeof(gat_resident_config), 200000, 60000, 0, res_wgs, res_pollers};
+                    const gat_resident_config rcfg = {sizeof(gat_resident_config), 200000, 60000, 0, res_wgs, res_pollers, res_bell};
                     float r_re[4 * 7], r_im[4 * 7];
                     CHECK(gat_sync(ctx));
                     const int32_t orc = gat_resident_open(ctx, &sig, 1, L, shifts, fs, &rcfg, &rs);

@@ -97,7 +97,7 @@ class LaunchInfo(C.Structure):
 class ResidentConfig(C.Structure):
     """gat_resident_config (include/gat.h)."""
 
-    _fields_ = [(n, C.c_uint32) for n in ("struct_size", "idle_us", "life_ms", "max_calls", "max_workgroups", "host_pollers")]
+    _fields_ = [(n, C.c_uint32) for n in ("struct_size", "idle_us", "life_ms", "max_calls", "max_workgroups", "host_pollers", "doorbell")]
 
 
 class ResidentInfo(C.Structure):

@@ -255,20 +255,20 @@ class ResidentCorrelator:
     """``gat_resident`` (include/gat.h): ONE bounded-lifetime kernel stays on the device for a fixed call geometry; a call
     rings it through pinned host memory (no kernel launch, no stream wait) and returns the correlator outputs as host
     arrays -- the reference's ``@benchmark CUDA.@sync kernel_algorithm(...)`` call (src/benchmarks.jl:120-146) plus the copy
-    of its outputs to the host.  ``config``: idle_us, life_ms, max_calls, max_workgroups, host_pollers (0 / absent: library defaults).
+    of its outputs to the host.  ``config``: idle_us, life_ms, max_calls, max_workgroups, host_pollers, doorbell (0 / absent: library defaults).
 
     The caller makes sure the block's samples are in device memory before ``correlate`` (``torch.cuda.synchronize()`` or
     ``ctx.sync()`` after whatever produced them).  Use as a context manager, or ``close()`` it."""
 
     def __init__(self, ctx: Context, desc: _lib.SignalDesc, num_channels: int, shifts, sampling_frequency: float, **config):
-        unknown = set(config) - {"idle_us", "life_ms", "max_calls", "max_workgroups", "host_pollers"}
+        unknown = set(config) - {"idle_us", "life_ms", "max_calls", "max_workgroups", "host_pollers", "doorbell"}
         if unknown:
             raise TypeError(f"unknown resident option(s): {sorted(unknown)}")
         self.ctx = ctx
         self.lib = ctx.lib
         self._desc = desc  # the buffer it describes must outlive the correlator: the caller keeps the tensors
         sh = np.ascontiguousarray(shifts, dtype=np.int32)
-        cfg = _lib.ResidentConfig(C.sizeof(_lib.ResidentConfig), *(int(config.get(k, 0)) for k in ("idle_us", "life_ms", "max_calls", "max_workgroups", "host_pollers")))
+        cfg = _lib.ResidentConfig(C.sizeof(_lib.ResidentConfig), *(int(config.get(k, 0)) for k in ("idle_us", "life_ms", "max_calls", "max_workgroups", "host_pollers", "doorbell")))
         self._h = C.c_void_p()
         rc = self.lib.gat_resident_open(ctx._h, C.byref(desc), int(num_channels), int(sh.size), sh.ctypes.data_as(C.POINTER(C.c_int32)),
                                         float(sampling_frequency), C.byref(cfg), C.byref(self._h))

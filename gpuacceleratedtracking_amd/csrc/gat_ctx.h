@@ -21,6 +21,8 @@ struct gat_resident {
     unsigned char *h_block = nullptr; // pinned: doorbell lines | state | result lines
     unsigned *h_bell = nullptr, *h_state = nullptr, *h_lines = nullptr, *h_init = nullptr;
     unsigned *d_quit = nullptr;       // device: the master's "I am leaving" word | eight forwarded doorbells
+    unsigned *d_bell = nullptr;       // device (fine-grained, host-writable through the BAR): the doorbell's copies, or null: it is in h_block
+    int bell_copies = 1;
     int wgs = 0, lines_per_wg = 0, nval = 0; // working workgroups, result lines and values of each
     unsigned seq = 0;                 // sequence number of the last call
     bool running = false;             // a kernel was started and has not been seen to end

@@ -126,7 +126,9 @@ constexpr int kResMaxChannels = 16;    // channels (doorbell lines) of a residen
 constexpr unsigned kBellQuit = 0xffffffffu; // never a call's sequence number
 constexpr int kResLinePayload = 14;
 struct ResidentArgs {
-    const unsigned *host_bell; // pinned host (device address): [K][16]
+    const unsigned *host_bell; // the doorbell the HOST writes: [bell_copies][kResMaxChannels][16] -- device memory that the host reaches
+                               // through the PCIe BAR (bell_copies = 8: one per blockIdx % 8), or pinned host memory (1 copy)
+    int bell_copies;
     unsigned *host_lines;      // pinned host: [workgroups][lines per workgroup][16]
     unsigned *host_state;      // pinned host: [0] why the kernel ended (0: it runs), [1] calls the master served
     unsigned *dev_quit;        // device: set by the master when it leaves (every workgroup polls the host: forward == 0)

@@ -6,7 +6,10 @@
 // is the fused correlator of gat_dc.h (the same body, gat_dc_body.inc) inside a loop, and every workgroup of it is on its
 // own:
 //
-//   poll the doorbell (the host's, or -- more than ~20 workgroups -- the master's copy of it in device memory)
+//   poll the doorbell (in DEVICE memory where the host can write there through the PCIe BAR: a ring is then a posted write and
+//   every poll a local read -- 2.10 us there and back, median, against 2.50 with the doorbell in pinned host memory and
+//   a third of the spread, scripts/probes/doorbell_bar_probe.hip --; else in pinned host memory, polled by every
+//   workgroup or, with more than ~20 of them, by the master, which forwards it through device memory)
 //   -> the call's channel records and block offset arrive WITH the ring (one 64-byte line per channel)
 //   -> system-scope acquire (the signal may have been rewritten by a copy engine or another kernel since the last call)
 //   -> correlate this workgroup's share (antenna tile, channel, sample split) -> post its sums to the host as result lines
@@ -92,15 +95,17 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
     long long t_seen_ = 0;
 #endif
     for (;;) {
-        // ---- wait for a ring: wave 0 reads all K lines with ONE load (lane i <-> dword i).  Few workgroups: every one polls
-        // the host's doorbell itself (nothing between the ring and any workgroup).  Many: reads of one host line queue up
+        // ---- wait for a ring: wave 0 reads all K lines with ONE load (lane i <-> dword i).  Doorbell in device memory (the
+        // host writes it through the BAR, eight copies): every workgroup polls its copy, r.forward = 0.  Doorbell in pinned host
+        // memory -- few workgroups: every one polls it itself (nothing between the ring and any workgroup); many: reads of one host line queue up
         // behind each other (~0.15 us apiece: 33 pollers took 10 us to see a ring), so only the master polls the host and
         // copies what it sees -- rings and its decision to leave -- into eight doorbells in device memory (one per
         // blockIdx % 8, on different memory channels) that the others poll.
         if (threadIdx.x < 64) {
             const int ln = (int)threadIdx.x;
             const bool from_host = master || r.forward == 0;
-            const unsigned *src = (from_host ? r.host_bell : r.dev_bell + (blockIdx.x & 7u) * (kResMaxChannels * kBellDwords)) + ln;
+            const unsigned *src = (from_host ? r.host_bell + (blockIdx.x & (unsigned)(r.bell_copies - 1)) * (kResMaxChannels * kBellDwords)
+                                             : r.dev_bell + (blockIdx.x & 7u) * (kResMaxChannels * kBellDwords)) + ln;
             // lane i <-> dword i of the first four lines; channels 4 .. 15 (rare: a receiver's whole constellation in one
             // call) sit in three more 256-byte groups that are read only once line 0 shows a new ring -- one more trip
             const int K0 = K < 4 ? K : 4;

@@ -45,6 +45,18 @@ int32_t validate_params(gat_ctx *c, const gat_channel_params *params_host, size_
     return GAT_OK;
 }
 
+// the doorbell may live behind the PCIe BAR (write-combining): stores are pushed out of the core's buffers before anybody waits
+static inline void bell_flush(const gat_resident *res)
+{
+    if (res->d_bell) __builtin_ia32_sfence();
+}
+// dword 0 of line 0 (the ring's number, or "quit") in every copy of the doorbell
+static void bell_set_seq(gat_resident *res, unsigned v)
+{
+    for (int cp = 0; cp < res->bell_copies; ++cp) __atomic_store_n(&res->h_bell[(size_t)cp * kResMaxChannels * kBellDwords], v, __ATOMIC_RELEASE);
+    bell_flush(res);
+}
+
 // start the kernel: it has served everything up to start_seq; a ring with a newer number is served at once
 static int32_t resident_start(gat_resident *res, unsigned start_seq)
 {
@@ -68,10 +80,9 @@ static int32_t resident_park(gat_resident *res)
 {
     if (!res->running) return GAT_OK;
     gat_ctx *c = res->ctx;
-    if (__atomic_load_n(&res->h_state[0], __ATOMIC_ACQUIRE) == kResidentRuns)
-        __atomic_store_n(&res->h_bell[0], kBellQuit, __ATOMIC_RELEASE);
+    if (__atomic_load_n(&res->h_state[0], __ATOMIC_ACQUIRE) == kResidentRuns) bell_set_seq(res, kBellQuit);
     GAT_HIP(c, hipStreamSynchronize(res->stream));
-    __atomic_store_n(&res->h_bell[0], res->seq, __ATOMIC_RELEASE); // line 0 is the last call's again
+    bell_set_seq(res, res->seq); // line 0 is the last call's again
     res->last_exit = __atomic_load_n(&res->h_state[0], __ATOMIC_ACQUIRE);
     res->running = false;
     return GAT_OK;
@@ -85,6 +96,7 @@ void park_residents(gat_ctx *c)
 void resident_free(gat_resident *res)
 {
     if (res->d_quit) (void)hipFree(res->d_quit);
+    if (res->d_bell) (void)hipFree(res->d_bell);
     if (res->h_block) (void)hipHostFree(res->h_block);
     if (res->stream) (void)hipStreamDestroy(res->stream);
     delete res;
@@ -165,7 +177,23 @@ GAT_API int32_t gat_resident_open(gat_ctx *c, const gat_signal_desc *sig, int32_
     if ((e = hipMalloc(reinterpret_cast<void **>(&res->d_quit), kResDevBytes)) != hipSuccess) return bail(hipfail(c, e, "hipMalloc"));
     res->r.dev_quit = res->d_quit;
     res->r.dev_bell = res->d_quit + 16;
-    res->r.forward = res->wgs > (cf.host_pollers ? (int)cf.host_pollers : kResHostPollers) ? 1 : 0;
+    // the doorbell: device memory the host writes through the BAR (a ring is a posted write, every poll a local read), or the
+    // pinned block above
+    int large_bar = 0;
+    if (cf.doorbell > 2) return bail(fail(c, GAT_ERR_ARG, "gat_resident_config.doorbell: 0, 1 or 2"));
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device) != hipSuccess) large_bar = 0;
+    (void)hipGetLastError();
+    if (cf.doorbell == 2 || (cf.doorbell == 0 && large_bar)) {
+        if (!large_bar) return bail(fail(c, GAT_ERR_UNSUPPORTED, "resident correlator: the host cannot write device memory here (no large BAR)"));
+        res->bell_copies = 8;
+        if ((e = hipExtMallocWithFlags(reinterpret_cast<void **>(&res->d_bell), 8 * kResBellBytes, hipDeviceMallocFinegrained)) != hipSuccess)
+            return bail(hipfail(c, e, "hipExtMallocWithFlags"));
+        res->h_bell = res->d_bell; // the host's view of it IS the device address
+        res->r.host_bell = res->d_bell;
+        for (size_t i = 0; i < 8 * kResBellBytes / sizeof(unsigned); ++i) res->h_bell[i] = 0u;
+    }
+    res->r.bell_copies = res->bell_copies;
+    res->r.forward = !res->d_bell && res->wgs > (cf.host_pollers ? (int)cf.host_pollers : kResHostPollers) ? 1 : 0;
     // the body posts its sums through LDS: it stores nothing to device or host memory itself
     res->a.partial = nullptr;
     res->a.out_re = nullptr;
@@ -177,7 +205,7 @@ GAT_API int32_t gat_resident_open(gat_ctx *c, const gat_signal_desc *sig, int32_
     res->r.life_ticks = (long long)res->life_ms * 1000ll * res->ticks_per_us;
     if ((e = hipStreamCreateWithFlags(&res->stream, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreateWithFlags"));
     res->seq = 1; // "the last call": nothing is pending when the kernel starts
-    res->h_bell[0] = res->seq;
+    bell_set_seq(res, res->seq);
     rc = resident_start(res, res->seq);
     if (rc != GAT_OK) return bail(rc);
     c->residents.push_back(res);
@@ -211,11 +239,18 @@ GAT_API int32_t gat_resident_correlate(gat_resident *res, const gat_channel_para
         for (int i = 0; i < 14; ++i) x ^= w[i];
         w[14] = x;
         w[15] = seq;
-        unsigned *line = res->h_bell + (size_t)k * kBellDwords;
-        for (int i = 1; i < 15; ++i) line[i] = w[i];
-        __atomic_store_n(&line[15], seq, __ATOMIC_RELEASE);
-        __atomic_store_n(&line[0], seq, __ATOMIC_RELEASE);
+        for (int cp = 0; cp < res->bell_copies; ++cp) { // (device doorbell: one copy per blockIdx % 8, whole 64-byte lines: write-combined)
+            unsigned *line = res->h_bell + ((size_t)cp * kResMaxChannels + k) * kBellDwords;
+            if (res->d_bell) {
+                for (int i = 0; i < kBellDwords; ++i) line[i] = w[i];
+            } else {
+                for (int i = 1; i < 15; ++i) line[i] = w[i];
+                __atomic_store_n(&line[15], seq, __ATOMIC_RELEASE);
+                __atomic_store_n(&line[0], seq, __ATOMIC_RELEASE);
+            }
+        }
     }
+    bell_flush(res);
     res->seq = seq;
     if (!res->running || __atomic_load_n(&res->h_state[0], __ATOMIC_ACQUIRE) != kResidentRuns) {
         if (res->running) res->last_exit = res->h_state[0];

@@ -400,8 +400,10 @@ typedef struct gat_resident_config {
     uint32_t max_calls;      /* ... and after this many calls                           (0: no limit)            */
     uint32_t max_workgroups; /* workgroups one block's samples may be split over        (0: default, 64; at most */
                              /* the device's compute units: all of them have to be on the device at once)        */
-    uint32_t host_pollers;   /* up to this many workgroups poll the host's doorbell themselves; with more, one does and    */
-                             /* forwards the ring through device memory                 (0: default, 20)         */
+    uint32_t host_pollers;   /* doorbell in host memory: up to this many workgroups poll it themselves; with more, one     */
+                             /* does and forwards the ring through device memory        (0: default, 20)         */
+    uint32_t doorbell;       /* where the doorbell lives: 0 device memory written through the PCIe BAR where the device   */
+                             /* has a large BAR, else pinned host memory; 1 pinned host memory; 2 device memory          */
 } gat_resident_config;
 typedef struct gat_resident_info {
     int32_t workgroups;  /* workgroups of the resident kernel (sample splits x antenna tiles x channels)          */

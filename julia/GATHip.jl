@@ -100,7 +100,7 @@ struct LaunchInfo
     prefetch_depth::Int32
 end
 
-# struct gat_resident_config (24 bytes) / gat_resident_info (32 bytes): the resident correlator (single-block calls
+# struct gat_resident_config (28 bytes) / gat_resident_info (32 bytes): the resident correlator (single-block calls
 # without a kernel launch, include/gat.h)
 struct ResidentConfig
     struct_size::UInt32
@@ -109,6 +109,7 @@ struct ResidentConfig
     max_calls::UInt32
     max_workgroups::UInt32
     host_pollers::UInt32
+    doorbell::UInt32
 end
 struct ResidentInfo
     workgroups::Int32
@@ -563,8 +564,8 @@ mutable struct Resident
     prm::Vector{ChannelParams}
 end
 function Resident(ctx::Context, desc::SignalDesc, num_channels::Integer, shifts::Vector{Int32}, sampling_frequency_hz::Float64;
-                  idle_us = 0, life_ms = 0, max_calls = 0, max_workgroups = 0, host_pollers = 0)
-    cfg = Ref(ResidentConfig(sizeof(ResidentConfig), idle_us, life_ms, max_calls, max_workgroups, host_pollers))
+                  idle_us = 0, life_ms = 0, max_calls = 0, max_workgroups = 0, host_pollers = 0, doorbell = 0)
+    cfg = Ref(ResidentConfig(sizeof(ResidentConfig), idle_us, life_ms, max_calls, max_workgroups, host_pollers, doorbell))
     h = Ref{Ptr{Cvoid}}(C_NULL)
     check(ctx, ccall((:gat_resident_open, libgat), Int32,
                      (Ptr{Cvoid}, Ref{SignalDesc}, Int32, Int32, Ptr{Int32}, Float64, Ref{ResidentConfig}, Ref{Ptr{Cvoid}}),

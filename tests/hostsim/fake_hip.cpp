@@ -50,7 +50,7 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t *prop, int)
 }
 hipError_t hipDeviceGetAttribute(int *pi, hipDeviceAttribute_t attr, int)
 {
-    *pi = attr == hipDeviceAttributeWallClockRate ? 100000 : 0;
+    *pi = attr == hipDeviceAttributeWallClockRate ? 100000 : attr == hipDeviceAttributeIsLargeBar ? 1 : 0;
     return hipSuccess;
 }
 hipError_t hipRuntimeGetVersion(int *v) { *v = 70200000; return hipSuccess; }
@@ -58,6 +58,7 @@ const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error
 hipError_t hipGetLastError(void) { return hipSuccess; }
 
 hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); ++hostsim::counters.mallocs; return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipExtMallocWithFlags(void **p, size_t n, unsigned) { return hipMalloc(p, n); }
 hipError_t hipFree(void *p) { std::free(p); if (p) ++hostsim::counters.frees; return hipSuccess; }
 hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return posix_memalign(p, 64, (n + 63) & ~size_t(63)) == 0 ? hipSuccess : hipErrorOutOfMemory; }
 hipError_t hipHostFree(void *p) { std::free(p); return hipSuccess; }

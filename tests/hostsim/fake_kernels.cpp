@@ -198,13 +198,15 @@ static void resident_device(DcArgs a, DcLaunch cfg, ResidentArgs r)
     const auto t_start = clk::now();
     auto t_last = t_start;
     auto ticks = [](clk::duration d) { return std::chrono::duration_cast<std::chrono::nanoseconds>(d).count() / 10; }; // 100 MHz
+    unsigned poll = 0;
     for (;;) {
-        const unsigned seq = ld(r.host_bell);
+        const unsigned *bell = r.host_bell + (size_t)(poll++ % (unsigned)r.bell_copies) * kResMaxChannels * kBellDwords; // (a copy per workgroup: all must ring)
+        const unsigned seq = ld(bell);
         if (seq == kBellQuit) { why = kResidentQuit; break; }
         if (seq != last) {
             bool ok = true;
             for (int k = 0; k < a.K && ok; ++k) {
-                const unsigned *ln = r.host_bell + k * kBellDwords;
+                const unsigned *ln = bell + k * kBellDwords;
                 unsigned x = 0, w[kBellDwords];
                 for (int i = 0; i < kBellDwords; ++i) w[i] = ld(ln + i);
                 for (int i = 0; i < 14; ++i) x ^= w[i];
@@ -256,6 +258,7 @@ hipError_t launch_dc_resident(const DcArgs &a, const DcLaunch &cfg, const Reside
 {
     ++counters.resident_starts;
     check_dc(a, cfg, true);
+    REQUIRE((r.bell_copies == 1 || r.bell_copies == 8) && (r.bell_copies == 1 || r.forward == 0), "resident: %d doorbell copies, forward %d", r.bell_copies, r.forward);
     REQUIRE(r.host_bell && r.host_lines && r.host_state && r.dev_quit && r.dev_bell && r.idle_ticks > 0 && r.life_ticks > 0 && r.max_calls > 0, "resident: arguments");
     REQUIRE(s != nullptr, "resident: launched on the default stream");
     hostsim::attach_worker(s, std::thread(resident_device, a, cfg, r));

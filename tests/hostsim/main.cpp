@@ -248,7 +248,7 @@ int main(int argc, char **argv)
         const uintptr_t mis = pick<long long>({0, 0, 0, 0, 8});
         gat_signal_desc sig = {(void *)(uintptr_t)(0x10000000 + mis), fmt == 0 ? (void *)(uintptr_t)(0x50000000 + mis) : nullptr, fmt, M, N, N * 4, N, 0};
         gat_resident_config cfg = {sizeof cfg, (uint32_t)pick<long long>({150, 400, 100000}), (uint32_t)pick<long long>({5, 50, 2000}), (uint32_t)pick<long long>({0, 5, 17}),
-                                   (uint32_t)pick<long long>({0, 1, 8, 200}), (uint32_t)pick<long long>({0, 1, 64})};
+                                   (uint32_t)pick<long long>({0, 1, 8, 200}), (uint32_t)pick<long long>({0, 1, 64}), (uint32_t)pick<long long>({0, 1, 2})};
         gat_resident *res = nullptr;
         const int32_t rc = gat_resident_open(ctx, &sig, K, L, sh.data(), N / 1e-3, uni(0, 4) ? &cfg : nullptr, &res);
         std::vector<int32_t> sorted(sh);
