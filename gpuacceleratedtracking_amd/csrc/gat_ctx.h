@@ -24,6 +24,7 @@ struct gat_resident {
     unsigned *d_bell = nullptr;       // device (fine-grained, host-writable through the BAR): the doorbell's copies, or null: it is in h_block
     int bell_copies = 1;
     int wgs = 0, lines_per_wg = 0, nval = 0; // working workgroups, result lines and values of each
+    std::vector<int> val_src, val_dst; // value pair (re, im) i of a workgroup: word of its lines holding re | tap * M + antenna of the tile it adds to
     unsigned seq = 0;                 // sequence number of the last call
     bool running = false;             // a kernel was started and has not been seen to end
     bool stale = false;               // the code table changed: the correlator has to be opened again
@@ -34,6 +35,9 @@ struct gat_resident {
     long long ticks_per_us = 100;
     unsigned last_exit = 0;
     uint64_t launches = 0, calls = 0;
+#ifdef GAT_RES_STAMPS
+    double host_us[2] = {}; // sums over the calls: ring written -> first workgroup taken -> every workgroup taken
+#endif
 };
 
 struct gat_ctx {

@@ -184,9 +184,14 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
         const unsigned seq = uni(s_ctl[0]);
         if (seq == kBellQuit) break;
         last = seq;
-        // the signal of this call was written by somebody else (copy engine, another kernel, the host) before the ring:
-        // nothing of it may come from this XCD's caches
+        // The signal of this call was written by somebody else (copy engine, another kernel, the host) since the last call:
+        // nothing of it may come from this XCD's caches.  The body's sample loads are system-scope loads for that -- a cache
+        // invalidate here (a system-scope acquire fence) costs every workgroup ~0.3 us and the invalidates of an XCD's workgroups
+        // queue up behind each other: 1.8 us from the ring to the first loads with 20 workgroups, 8.3 us with 240
+        // (profiles/r04/resident/v10_*; -DGAT_RES_FENCE builds that form).
+#ifdef GAT_RES_FENCE
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+#endif
 
 #ifdef GAT_RES_STAMPS // development builds: where a call's time goes (100 MHz clock), read back by gat_resident_close
         long long st_[10] = {};

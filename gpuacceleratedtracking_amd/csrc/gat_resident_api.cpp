@@ -132,9 +132,19 @@ GAT_API int32_t gat_resident_open(gat_ctx *c, const gat_signal_desc *sig, int32_
         resident_free(res);
         return rc;
     };
-    // geometry: the planner's, restricted to the resident instances
+    // the doorbell: device memory the host writes through the BAR (a ring is a posted write, every poll a local read), or the
+    // pinned block below
+    int large_bar = 0;
+    if (cf.doorbell > 2) return bail(fail(c, GAT_ERR_ARG, "gat_resident_config.doorbell: 0, 1 or 2"));
+    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device) != hipSuccess) large_bar = 0;
+    (void)hipGetLastError();
+    const bool bell_on_device = cf.doorbell == 2 || (cf.doorbell == 0 && large_bar);
+    if (bell_on_device && !large_bar) return bail(fail(c, GAT_ERR_UNSUPPORTED, "resident correlator: the host cannot write device memory here (no large BAR)"));
+    // geometry: the planner's, restricted to the resident instances.  More workgroups shorten every workgroup's walk and
+    // lengthen the host's (two or three result lines each): best around 128 (profiles/r04/resident/v10_*); behind a
+    // forwarded host doorbell 64
     DcPlan plan;
-    plan.max_wgs = cf.max_workgroups ? cf.max_workgroups : 64;
+    plan.max_wgs = cf.max_workgroups ? cf.max_workgroups : std::min(c->num_cus, bell_on_device ? 128 : 64);
     const gat_channel_params dummy[kResMaxChannels] = {};
     float *const nonnull = reinterpret_cast<float *>(uintptr_t(64));
     int32_t rc = correlate_impl(c, sig, nullptr, 1, K, L, shifts, fs, nonnull, nonnull, 0, dummy, &plan);
@@ -161,6 +171,11 @@ GAT_API int32_t gat_resident_open(gat_ctx *c, const gat_signal_desc *sig, int32_
     res->wgs = (int)plan.a.total_wgs;
     res->nval = 2 * plan.cfg.ant_tile * plan.cfg.taps;
     res->lines_per_wg = (res->nval + kResLinePayload - 1) / kResLinePayload;
+    for (int o = 0; o < res->nval; ++o) { // where the host's second stage finds a workgroup's values and where they go
+        res->val_src.push_back((o / kResLinePayload) * 16 + o % kResLinePayload);
+        const int ml = o >> 1;
+        if (!(o & 1)) res->val_dst.push_back(plan.a.tap_index[ml / plan.cfg.ant_tile] * sig->num_ants + ml % plan.cfg.ant_tile);
+    }
     const size_t host_bytes = kResBellBytes + 64 + kResDevBytes + (size_t)res->wgs * res->lines_per_wg * 64;
     hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&res->h_block), host_bytes, hipHostMallocCoherent | hipHostMallocMapped);
     if (e != hipSuccess) return bail(hipfail(c, e, "hipHostMalloc"));
@@ -177,14 +192,7 @@ GAT_API int32_t gat_resident_open(gat_ctx *c, const gat_signal_desc *sig, int32_
     if ((e = hipMalloc(reinterpret_cast<void **>(&res->d_quit), kResDevBytes)) != hipSuccess) return bail(hipfail(c, e, "hipMalloc"));
     res->r.dev_quit = res->d_quit;
     res->r.dev_bell = res->d_quit + 16;
-    // the doorbell: device memory the host writes through the BAR (a ring is a posted write, every poll a local read), or the
-    // pinned block above
-    int large_bar = 0;
-    if (cf.doorbell > 2) return bail(fail(c, GAT_ERR_ARG, "gat_resident_config.doorbell: 0, 1 or 2"));
-    if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, c->device) != hipSuccess) large_bar = 0;
-    (void)hipGetLastError();
-    if (cf.doorbell == 2 || (cf.doorbell == 0 && large_bar)) {
-        if (!large_bar) return bail(fail(c, GAT_ERR_UNSUPPORTED, "resident correlator: the host cannot write device memory here (no large BAR)"));
+    if (bell_on_device) {
         res->bell_copies = 8;
         if ((e = hipExtMallocWithFlags(reinterpret_cast<void **>(&res->d_bell), 8 * kResBellBytes, hipDeviceMallocFinegrained)) != hipSuccess)
             return bail(hipfail(c, e, "hipExtMallocWithFlags"));
@@ -257,22 +265,54 @@ GAT_API int32_t gat_resident_correlate(gat_resident *res, const gat_channel_para
         GAT_HIP(c, hipSetDevice(c->device));
         if ((rc = resident_start(res, prev)) != GAT_OK) return rc;
     }
-    // wait: every result line of every workgroup carries the call's number and passes its check
-    const int nlines = res->wgs * res->lines_per_wg;
+    // Wait + second stage in one walk over the workgroups' result lines, in slot order: a workgroup whose lines all carry the
+    // call's number and pass their check is added to the outputs and never looked at again (its lines stay as they are until
+    // the next ring; a restarted kernel posts the same values) -- what is left to do when the last line lands is the last
+    // workgroup.  Slot = (antenna group * splits + split) * channels + channel: every output receives its splits in rising
+    // order whatever the order of arrival (deterministic, the order of the device's second stage).  The lines are misses
+    // in the host's caches once the device has written them: fetched ahead.
+    const int lw = res->lines_per_wg, pairs = res->nval / 2, nlines = res->wgs * lw;
+    const int MT = res->cfg.ant_tile, KG = res->a.KG, SP = res->a.splits;
+    const size_t n = (size_t)res->K * res->L * res->M;
+    std::memset(out_re_host, 0, n * sizeof(float));
+    std::memset(out_im_host, 0, n * sizeof(float));
+    const int *src = res->val_src.data(), *dst = res->val_dst.data();
+    int slot = 0, kg = 0, ag = 0, sp = 0; // the next workgroup to take and its place in the call
+    constexpr int kAhead = 12;
     auto answered = [&]() {
-        const unsigned *ln = res->h_lines;
-        for (int j = nlines - 1; j >= 0; --j) { // (the last line first: the first workgroups tend to be done first)
-            if (__atomic_load_n(&ln[(size_t)j * 16 + 15], __ATOMIC_RELAXED) != seq) return false;
-            unsigned x = seq;
-            for (int i = 0; i < kResLinePayload; ++i) x ^= __atomic_load_n(&ln[(size_t)j * 16 + i], __ATOMIC_RELAXED);
-            if (__atomic_load_n(&ln[(size_t)j * 16 + 14], __ATOMIC_RELAXED) != x) return false;
+        const unsigned long long *ln = reinterpret_cast<const unsigned long long *>(res->h_lines);
+        for (; slot < res->wgs; ++slot) {
+            const unsigned long long *q = ln + (size_t)slot * lw * 8;
+            for (int j = 0; j < lw; ++j, q += 8) {
+                if (slot * lw + j + kAhead < nlines) __builtin_prefetch(q + kAhead * 8);
+                unsigned long long x = 0, last = 0;
+                for (int i = 0; i < 8; ++i) x ^= (last = __atomic_load_n(&q[i], __ATOMIC_RELAXED));
+                // words 0..13 payload, 14 = seq ^ xor(payload), 15 = seq: the sixteen words of a whole line of this call xor to zero
+                if ((unsigned)(last >> 32) != seq || (unsigned)(x >> 32) != (unsigned)x) return false;
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            const float *w = reinterpret_cast<const float *>(res->h_lines) + (size_t)slot * lw * 16;
+            float *o_re = out_re_host + (size_t)kg * res->L * res->M + ag * MT, *o_im = out_im_host + (size_t)kg * res->L * res->M + ag * MT;
+            for (int i = 0; i < pairs; ++i) {
+                o_re[dst[i]] += w[src[2 * i]];
+                o_im[dst[i]] += w[src[2 * i + 1]];
+            }
+            if (++kg == KG) {
+                kg = 0;
+                if (++sp == SP) { sp = 0; ++ag; }
+            }
         }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
         return true;
     };
     const double t0 = mono_us(), deadline = (double)res->life_ms * 1000.0 + 1.0e6;
+#ifdef GAT_RES_STAMPS
+    double t_first = 0.0;
+#endif
     for (unsigned spins = 0;; ++spins) {
         if (answered()) break;
+#ifdef GAT_RES_STAMPS
+        if (t_first == 0.0 && slot > 0) t_first = mono_us();
+#endif
         if ((spins & 15u) != 15u) continue;
         if (__atomic_load_n(&res->h_state[0], __ATOMIC_ACQUIRE) != kResidentRuns) {
             // the kernel has left (idle, lifetime, call budget) -- with this call served or not
@@ -286,24 +326,12 @@ GAT_API int32_t gat_resident_correlate(gat_resident *res, const gat_channel_para
             return fail(c, GAT_ERR_STATE, "resident correlator: no answer from the device");
         }
     }
-    // second stage on the host: the workgroups' sums added split by split in fixed order (deterministic)
-    const size_t n = (size_t)res->K * res->L * res->M;
-    std::memset(out_re_host, 0, n * sizeof(float));
-    std::memset(out_im_host, 0, n * sizeof(float));
-    const int MT = res->cfg.ant_tile, KG = res->a.KG, AG = res->a.ant_groups, SP = res->a.splits;
-    const float *lines = reinterpret_cast<const float *>(res->h_lines);
-    for (int sp = 0; sp < SP; ++sp)
-        for (int ag = 0; ag < AG; ++ag)
-            for (int kg = 0; kg < KG; ++kg) {
-                const size_t slot = ((size_t)ag * SP + sp) * KG + kg; // the kernel's: tile * KG + kg, tile = ag * splits + split
-                const float *w = lines + slot * res->lines_per_wg * 16;
-                for (int o = 0; o < res->nval; ++o) {
-                    const float v = w[(o / kResLinePayload) * 16 + o % kResLinePayload];
-                    const int ml = o >> 1, m = ag * MT + ml % MT, l = res->a.tap_index[ml / MT];
-                    float *dst = (o & 1) ? out_im_host : out_re_host;
-                    dst[((size_t)kg * res->L + l) * res->M + m] += v;
-                }
-            }
+#ifdef GAT_RES_STAMPS
+    const double t_all = mono_us();
+    if (t_first == 0.0) t_first = t_all;
+    res->host_us[0] += t_first - t0;
+    res->host_us[1] += t_all - t_first;
+#endif
     ++res->calls;
     return GAT_OK;
 }
@@ -339,6 +367,9 @@ GAT_API int32_t gat_resident_close(gat_resident *res)
 #ifdef GAT_RES_STAMPS
     std::fprintf(stderr, "resident stamps of the last call (10 ns ticks): ring seen -> barrier + acquire %u; then tile decode %u, first loads issued %u, parameters %u, setup (barrier) %u, first segment %u, steps %u, reduction %u, result lines %u (= %u counts of clock64)\n",
                  res->h_state[11], res->h_state[4 + 1], res->h_state[12], res->h_state[13], res->h_state[4 + 2], res->h_state[4 + 3], res->h_state[4 + 4], res->h_state[4 + 5], res->h_state[4 + 6], res->h_state[14]);
+    if (res->calls)
+        std::fprintf(stderr, "host side, mean over %llu calls (us): ring written -> first workgroup's result lines whole and added %.2f, -> all %d lines of %d workgroups %.2f\n",
+                     (unsigned long long)res->calls, res->host_us[0] / (double)res->calls, res->wgs * res->lines_per_wg, res->wgs, res->host_us[1] / (double)res->calls);
 #endif
     c->residents.erase(std::remove(c->residents.begin(), c->residents.end(), res), c->residents.end());
     resident_free(res);

@@ -369,16 +369,16 @@ GAT_API int32_t gat_last_launch_info(const gat_ctx *ctx, gat_launch_info *out, s
  * src/benchmarks.jl:120-146), and its receiver loop consumes every block's correlator outputs on the host
  * (Tracking.jl's discriminators).  Through gat_downconvert_and_correlate + gat_sync such a call costs a kernel launch and
  * the wait for its end: 7 us on this platform before the kernel has done anything.  A resident correlator keeps ONE
- * kernel on the device for a fixed call geometry; a call rings a doorbell in pinned host memory (the channel records
- * and the block's position travel with the ring), every workgroup of the kernel correlates its share and posts its
- * sums to pinned host memory stamped with the call's number, the host adds them in a fixed order: no launch, no stream
- * wait, outputs already on the host (2 MHz .. 8 MHz blocks: 5-6 us instead of 10.5-13.5; it pays for up to four
- * channels per call, is on a par at eight and loses beyond -- DESIGN.md 4.2b).
+ * kernel on the device for a fixed call geometry; a call rings a doorbell (the channel records and the block's position
+ * travel with the ring), every workgroup of the kernel correlates its share and posts its sums to pinned host memory
+ * stamped with the call's number, the host adds them in a fixed order: no launch, no stream wait, outputs already on
+ * the host (2 MHz .. 8 MHz blocks: 5-6 us instead of 10.5-13.5; a 20 MHz block of four antennas and twelve channels:
+ * 10 us instead of 17 -- DESIGN.md 4.2b).
  *
  * Lifetime is bounded on the DEVICE side, whatever the host does: the kernel ends by itself after `idle_us` without a
  * call, after `life_ms` in total, or after `max_calls` calls; the next call starts it again (that call then costs a
  * launch).  It occupies one workgroup slot per workgroup it uses (info.workgroups: about max_workgroups at most) and polls
- * host memory from up to `host_pollers` of them while it waits.  Other work of the process runs next to it on other streams; calls that
+ * its doorbell while it waits (in host memory: from up to `host_pollers` of them).  Other work of the process runs next to it on other streams; calls that
  * synchronise the whole device (hipDeviceSynchronize, hipFree) wait until it has ended: gat_free, gat_set_codes and
  * gat_destroy therefore ask every resident correlator of the context to leave first (gat_set_codes: for good -- the
  * correlator answers GAT_ERR_STATE afterwards and has to be opened again).
@@ -398,8 +398,9 @@ typedef struct gat_resident_config {
     uint32_t idle_us;        /* the kernel ends after this long without a call          (0: default, 5 000 us)   */
     uint32_t life_ms;        /* ... and after this long whatever happens                (0: default, 2 000 ms)   */
     uint32_t max_calls;      /* ... and after this many calls                           (0: no limit)            */
-    uint32_t max_workgroups; /* workgroups one block's samples may be split over        (0: default, 64; at most */
-                             /* the device's compute units: all of them have to be on the device at once)        */
+    uint32_t max_workgroups; /* workgroups one block's samples may be split over   (0: default, 128 -- 64 with the    */
+                             /* doorbell in host memory; at most the device's compute units: all of them have to be  */
+                             /* on the device at once)                                                           */
     uint32_t host_pollers;   /* doorbell in host memory: up to this many workgroups poll it themselves; with more, one     */
                              /* does and forwards the ring through device memory        (0: default, 20)         */
     uint32_t doorbell;       /* where the doorbell lives: 0 device memory written through the PCIe BAR where the device   */

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One 1 ms block of a whole constellation per call (K channels, what a receiver's loop asks for every millisecond): the
-ordinary call + wait against the resident correlator's call, Python host layer, same box.  Prints min / median in us."""
+ordinary call + wait against the resident correlator's call, Python host layer, same box.  Prints min / median in us.
+Usage: r04_resident_constellation.py [max_workgroups [max_workgroups ...]]  (default: the library's default, 64)."""
 import os
 import sys
 import time
@@ -13,6 +14,7 @@ import torch  # noqa: E402
 import gpuacceleratedtracking_amd as g  # noqa: E402
 from tests.helpers import check_close, make_case, oracle_result  # noqa: E402
 
+WGS = [int(a) for a in sys.argv[1:]] or [0]
 ctx = g.get_context(own_stream=True)
 print(g.load_library().gat_version().decode())
 for system, N, M, L, K in (("GPSL1", 20000, 4, 3, 1), ("GPSL1", 20000, 4, 3, 4), ("GPSL1", 20000, 4, 3, 8), ("GPSL1", 20000, 4, 3, 12),
@@ -37,15 +39,18 @@ for system, N, M, L, K in (("GPSL1", 20000, 4, 3, 1), ("GPSL1", 20000, 4, 3, 4),
         ctx.sync()
         t_ord.append(time.perf_counter() - t0)
     info = ctx.last_launch_info()
-    with ctx.open_resident(desc, K, case["shifts"], case["fs"], idle_us=200000) as res:
-        t_res = []
-        for _ in range(1200):
-            t0 = time.perf_counter()
-            res.correlate(prm)
-            t_res.append(time.perf_counter() - t0)
-        a, b = res.correlate(prm)
-        check_close((a + 1j * b)[None], ref[0:1])
-        rinfo = res.info()
-    o, r = np.sort(t_ord[200:]) * 1e6, np.sort(t_res[200:]) * 1e6
-    print(f"{system} N={N} M={M} L={L} K={K}: launch + wait {o[0]:.1f} / {o[len(o) // 2]:.1f} us ({info['workgroups']} workgroups"
-          f"{', second stage' if info['finalize_launched'] else ''}) | resident call {r[0]:.1f} / {r[len(r) // 2]:.1f} us ({rinfo['workgroups']} workgroups)", flush=True)
+    o = np.sort(t_ord[200:]) * 1e6
+    line = f"{system} N={N} M={M} L={L} K={K}: launch + wait {o[0]:.1f} / {o[len(o) // 2]:.1f} us ({info['workgroups']} workgroups{', second stage' if info['finalize_launched'] else ''}) | resident call"
+    for wgs in WGS:
+        with ctx.open_resident(desc, K, case["shifts"], case["fs"], idle_us=200000, max_workgroups=wgs) as res:
+            t_res = []
+            for _ in range(1200):
+                t0 = time.perf_counter()
+                res.correlate(prm)
+                t_res.append(time.perf_counter() - t0)
+            a, b = res.correlate(prm)
+            check_close((a + 1j * b)[None], ref[0:1])
+            rinfo = res.info()
+        r = np.sort(t_res[200:]) * 1e6
+        line += f" {r[0]:.1f} / {r[len(r) // 2]:.1f} us ({rinfo['workgroups']} workgroups)"
+    print(line, flush=True)

@@ -155,7 +155,8 @@ def test_resident_calls_are_bit_identical_and_agree_with_the_ordinary_call(gat):
 
 def test_resident_sees_a_signal_rewritten_between_calls(gat):
     """The kernel that serves call n+1 is the one that read the buffer for call n: nothing of the old samples may come
-    from its caches (system-scope acquire after every ring)."""
+    from its caches (its sample loads are system-scope loads) -- whoever rewrote the buffer: a copy from the host, a copy
+    from another device buffer, a kernel that works in place."""
     g = gat
     import torch
     a = make_case(11, N=8192, M=4, L=3, K=1, B=1)
@@ -164,10 +165,20 @@ def test_resident_sees_a_signal_rewritten_between_calls(gat):
     ctx, res = _open(g, a, idle_us=500000, life_ms=5000)
     try:
         re_t, im_t = res._keep
-        for rnd in range(6):
+        dev = {id(c): (torch.from_numpy(c["re"]).to(re_t.device), torch.from_numpy(c["im"]).to(re_t.device)) for c in (a, b)}
+        torch.cuda.current_stream().synchronize()
+        for rnd in range(18):
             cur = a if rnd % 2 == 0 else b
-            re_t.copy_(torch.from_numpy(cur["re"]))
-            im_t.copy_(torch.from_numpy(cur["im"]))
+            how = rnd % 3
+            if how == 0:  # host -> device copy
+                re_t.copy_(torch.from_numpy(cur["re"]))
+                im_t.copy_(torch.from_numpy(cur["im"]))
+            elif how == 1:  # device -> device copy
+                re_t.copy_(dev[id(cur)][0])
+                im_t.copy_(dev[id(cur)][1])
+            else:  # a kernel that writes the buffer in place
+                re_t.mul_(0.0).add_(dev[id(cur)][0])
+                im_t.mul_(0.0).add_(dev[id(cur)][1])
             torch.cuda.current_stream().synchronize()  # (a device-wide wait would sit out the kernel's idle limit)
             re, im = res.correlate(_params(g, cur, 0))
             check_close((re + 1j * im)[None], want[id(cur)], what=f"round {rnd}")
