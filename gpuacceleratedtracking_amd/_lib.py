@@ -38,7 +38,7 @@ EXPORTS = [
     "gat_group_gather", "gat_group_sync",
     # resident correlator: single-block calls without a kernel launch
     "gat_resident_open", "gat_resident_correlate", "gat_resident_info_get", "gat_resident_park", "gat_resident_close",
-    "gat_tracking_update_host",
+    "gat_tracking_update_host", "gat_resident_tracking_run",
 ]
 
 
@@ -187,6 +187,7 @@ def load(build_if_missing: bool = True):
         "gat_resident_park": (i32, [vp]),
         "gat_resident_close": (i32, [vp]),
         "gat_tracking_update_host": (i32, [vp, vp, i32, i32, C.POINTER(LoopConfig), vp, vp, vp]),
+        "gat_resident_tracking_run": (i32, [vp, i32, i64, i64, C.POINTER(LoopConfig), vp, vp, vp, vp, i64]),
     }
     assert sorted(sigs) == sorted(EXPORTS)
     for name, (res, args) in sigs.items():

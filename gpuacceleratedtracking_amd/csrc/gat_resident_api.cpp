@@ -336,6 +336,27 @@ GAT_API int32_t gat_resident_correlate(gat_resident *res, const gat_channel_para
     return GAT_OK;
 }
 
+GAT_API int32_t gat_resident_tracking_run(gat_resident *res, int32_t num_blocks, int64_t first_block_offset, int64_t block_stride,
+                                          const gat_loop_config *cfg, gat_loop_state *state_host, gat_channel_params *params_host,
+                                          float *acc_re_host, float *acc_im_host, int64_t acc_block_stride)
+{
+    if (!res) return GAT_ERR_ARG;
+    gat_ctx *c = res->ctx;
+    if (!cfg || !state_host || !params_host || !acc_re_host || !acc_im_host) return fail(c, GAT_ERR_ARG, "null argument");
+    if (num_blocks < 0 || first_block_offset < 0 || block_stride < 0 || acc_block_stride < 0) return fail(c, GAT_ERR_ARG, "negative count, offset or stride");
+    const int64_t n = (int64_t)res->K * res->L * res->M;
+    if (acc_block_stride != 0 && acc_block_stride < n) return fail(c, GAT_ERR_ARG, "acc_block_stride below one block's M x L x K accumulators");
+    if (cfg->num_taps != res->L) return fail(c, GAT_ERR_ARG, "loop configuration: num_taps differs from the correlator's");
+    for (int32_t b = 0; b < num_blocks; ++b) {
+        float *re = acc_re_host + (size_t)b * acc_block_stride, *im = acc_im_host + (size_t)b * acc_block_stride;
+        int32_t rc = gat_resident_correlate(res, params_host, first_block_offset + (int64_t)b * block_stride, re, im);
+        if (rc != GAT_OK) return rc;
+        rc = gat_tracking_update_host(re, im, res->K, res->M, cfg, state_host, params_host, params_host);
+        if (rc != GAT_OK) return fail(c, rc, "gat_tracking_update_host: loop configuration");
+    }
+    return GAT_OK;
+}
+
 GAT_API int32_t gat_resident_info_get(const gat_resident *res, gat_resident_info *out, size_t struct_size)
 {
     if (!res || !out || struct_size == 0) return GAT_ERR_ARG;

@@ -165,9 +165,24 @@ class ResidentTrackingLoop:
         self.acc_re, self.acc_im = re, im
         self.blocks_done += 1
 
-    def run(self, num_blocks: int, start: int = 0):
-        for b in range(int(num_blocks)):
-            self.step(start + b * self.N)
+    def run(self, num_blocks: int, start: int = 0, block_stride: int | None = None, keep_all: bool = False):
+        """``num_blocks`` consecutive blocks from native code (``gat_resident_tracking_run``: {resident call, host update} per
+        block without a trip through Python).  The blocks are ``block_stride`` samples apart (default: back to back) and all
+        of them are on the device already.  ``keep_all``: returns complex64 [num_blocks, K, L, M] of every block's
+        accumulators; otherwise only the last block's are kept (``accumulators()``)."""
+        nb = int(num_blocks)
+        if nb <= 0:
+            return None
+        n = self.K * self.L * self.M
+        re = np.empty((nb if keep_all else 1, self.K, self.L, self.M), np.float32)
+        im = np.empty_like(re)
+        stride = self.N if block_stride is None else int(block_stride)
+        rc = self._lib.gat_resident_tracking_run(self.resident._h, nb, int(start), stride, C.byref(self.config), C.c_void_p(self._state.ctypes.data),
+                                                 C.c_void_p(self._cur.ctypes.data), C.c_void_p(re.ctypes.data), C.c_void_p(im.ctypes.data), n if keep_all else 0)
+        self.ctx.check(rc, "gat_resident_tracking_run")
+        self.acc_re, self.acc_im = re[-1], im[-1]
+        self.blocks_done += nb
+        return (re + 1j * im).astype(np.complex64) if keep_all else None
 
     def params(self) -> np.ndarray:
         return self._cur.copy()

@@ -422,6 +422,17 @@ GAT_API int32_t gat_resident_open(gat_ctx *ctx, const gat_signal_desc *signal, i
  * the samples one 16-byte load holds.  Blocks until the results are in out_re_host / out_im_host. */
 GAT_API int32_t gat_resident_correlate(gat_resident *resident, const gat_channel_params *params_host,
                                        int64_t block_offset_samples, float *out_re_host, float *out_im_host);
+/* The receiver loop with the host in it, from native code: num_blocks consecutive integration blocks (block b starts
+ * first_block_offset + b * block_stride_samples samples into the correlator's buffer; the caller has put all of them on
+ * the device) through {gat_resident_correlate, gat_tracking_update_host} -- Tracking.jl's structure: correlate on the
+ * accelerator, discriminators and loop filters on the CPU -- without a trip through the scripting host per block.
+ * params_host[K]: in the first block's parameters, out those for the block after the last; state_host[K] as for
+ * gat_tracking_update_host.  Block b's accumulators go to acc_re/acc_im_host + b * acc_block_stride floats ([M x L x K]
+ * each; stride 0 keeps only the last block's). */
+GAT_API int32_t gat_resident_tracking_run(gat_resident *resident, int32_t num_blocks, int64_t first_block_offset,
+                                          int64_t block_stride_samples, const gat_loop_config *config_host,
+                                          gat_loop_state *state_host, gat_channel_params *params_host,
+                                          float *acc_re_host, float *acc_im_host, int64_t acc_block_stride);
 GAT_API int32_t gat_resident_info_get(const gat_resident *resident, gat_resident_info *out, size_t struct_size);
 /* asks the kernel to leave and waits until it has (bounded by the kernel's own limits); the next call starts it again */
 GAT_API int32_t gat_resident_park(gat_resident *resident);

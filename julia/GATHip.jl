@@ -589,6 +589,17 @@ function info(r::Resident)
     i[]
 end
 park!(r::Resident) = check(r.ctx, ccall((:gat_resident_park, libgat), Int32, (Ptr{Cvoid},), r.handle))
+# the receiver loop with the host in it, from native code: num_blocks blocks (block b at first_block_offset + b * block_stride
+# samples of the buffer) through {resident call, gat_tracking_update_host}; r.prm: in the first block's records, out the next
+# ones; acc_re / acc_im: host arrays of at least max(1, acc_block_stride > 0 ? num_blocks : 1) * M * L * K floats
+function tracking_run!(r::Resident, num_blocks::Integer, first_block_offset::Integer, block_stride::Integer, cfg::LoopConfig,
+                       state::Vector{LoopState}, acc_re::Array{Float32}, acc_im::Array{Float32}, acc_block_stride::Integer = 0)
+    check(r.ctx, ccall((:gat_resident_tracking_run, libgat), Int32,
+                       (Ptr{Cvoid}, Int32, Int64, Int64, Ref{LoopConfig}, Ptr{LoopState}, Ptr{ChannelParams}, Ptr{Cfloat}, Ptr{Cfloat}, Int64),
+                       r.handle, Int32(num_blocks), Int64(first_block_offset), Int64(block_stride), Ref(cfg), state, r.prm, acc_re, acc_im,
+                       Int64(acc_block_stride)))
+    r
+end
 function Base.close(r::Resident)
     r.handle == C_NULL && return nothing
     rc = ccall((:gat_resident_close, libgat), Int32, (Ptr{Cvoid},), r.handle)

@@ -304,7 +304,27 @@ int main(int argc, char **argv)
                 gat_free(ctx, p);
             }
         }
-        EXPECT(gat_resident_info_get(res, &info, sizeof info) == GAT_OK && info.calls == (uint64_t)n_calls, "resident: %llu calls counted", (unsigned long long)info.calls);
+        int loop_calls = 0;
+        if (it % 3 == 0) { // the host-closed loop from native code: {resident call, host update} per block
+            gat_loop_config lc_cfg = {};
+            lc_cfg.block_seconds = 1e-3; lc_cfg.pll_bandwidth_hz = 18.0; lc_cfg.dll_bandwidth_hz = 1.0; lc_cfg.code_freq_nominal_hz = 1.023e6;
+            lc_cfg.carrier_center_hz = 1575.42e6; lc_cfg.early_late_spacing_chips = 1.0; lc_cfg.code_length = lc; lc_cfg.num_taps = L;
+            lc_cfg.early_index = 0; lc_cfg.prompt_index = L / 2; lc_cfg.late_index = L - 1;
+            std::vector<gat_loop_state> st((size_t)K);
+            std::vector<gat_channel_params> lp(prm);
+            const int nb = uni(1, 5);
+            std::vector<float> a_re(want_re.size() * (size_t)nb, -1.f), a_im(a_re.size(), -1.f);
+            const int32_t rl = gat_resident_tracking_run(res, nb, 0, N, &lc_cfg, st.data(), lp.data(), a_re.data(), a_im.data(), (int64_t)want_re.size());
+            EXPECT(rl == GAT_OK, "resident tracking run: %d (%s)", rl, gat_last_error(ctx));
+            for (int b = 0; b < nb && rl == GAT_OK; ++b)
+                EXPECT(std::equal(want_re.begin(), want_re.end(), a_re.begin() + (size_t)b * want_re.size()) &&
+                       std::equal(want_im.begin(), want_im.end(), a_im.begin() + (size_t)b * want_im.size()), "resident tracking run: block %d's accumulators", b);
+            if (rl == GAT_OK) loop_calls = nb;
+            lc_cfg.num_taps = L + 1;
+            EXPECT(gat_resident_tracking_run(res, 1, 0, N, &lc_cfg, st.data(), lp.data(), a_re.data(), a_im.data(), 0) == GAT_ERR_ARG, "resident tracking run: tap count");
+            res_calls += loop_calls;
+        }
+        EXPECT(gat_resident_info_get(res, &info, sizeof info) == GAT_OK && info.calls == (uint64_t)(n_calls + loop_calls), "resident: %llu calls counted", (unsigned long long)info.calls);
         if (it % 9 == 4) { // a new code table invalidates it
             EXPECT(gat_set_codes(ctx, codes.data(), lc, 32) == GAT_OK, "rebind");
             EXPECT(gat_resident_correlate(res, prm.data(), 0, r_re.data(), r_im.data()) == GAT_ERR_STATE, "stale correlator");

@@ -310,3 +310,51 @@ def test_host_closed_loop_through_the_resident_correlator(g):
     assert np.abs(hp["code_phase_chips"] - dp["code_phase_chips"]).max() < 1e-4
     assert np.abs(hp["carrier_freq_hz"] - dp["carrier_freq_hz"]).max() < 1e-3
     assert (np.abs(hacc[:, 1, :]) > 0.85 * N).all()  # prompt ~ N on every antenna of every channel
+
+
+def test_native_host_closed_loop_equals_block_by_block_stepping(g):
+    """gat_resident_tracking_run (the {resident call, host update} loop from native code) against the same loop stepped block by
+    block from Python: same calls in the same order -- parameters, loop state and every block's accumulators bit-identical;
+    argument errors named."""
+    import ctypes as C
+    system = g.GPSL1()
+    N, M, fs, fc, nblk = 4000, 4, 4e6, 1.023e6, 120
+    prns = np.array([5, 17])
+    true_dop = np.array([900.0, -2100.0])
+    tau0, phi0 = np.array([11.7, 512.3]), np.array([0.1, 0.6])
+    fcode = fc * (1 + true_dop / 1575.42e6)
+    b = np.arange(nblk, dtype=np.float64)[:, None]
+    prm_sig = g.make_params(prns - 1, fcode, true_dop, np.mod(tau0[None, :] + fcode[None, :] * (N / fs) * b, 1023.0),
+                            2 * np.pi * np.mod(phi0[None, :] + true_dop[None, :] * (N / fs) * b, 1.0), shape=(nblk, prns.size))
+    re, im = g.gen_signal_stream(system, prm_sig, fs, N, M)
+    shifts = g.get_correlator_sample_shifts(system, g.EarlyPromptLateCorrelator(M, 3), fs, 0.5)
+    kw = dict(init_carrier_doppler=true_dop + 5.0, init_code_phase=tau0 + 0.05, init_carrier_phase=0.0, dll_bandwidth_hz=4.0)
+    import torch
+    torch.cuda.synchronize()
+    with g.ResidentTrackingLoop(system, prns, N, M, fs, shifts, re=re, im=im, idle_us=200000, **kw) as a:
+        accs = []
+        for blk in range(nblk):
+            a.step(blk * N)
+            accs.append(a.accumulators().copy())
+        sa, pa = a.state(), a.params()
+    with g.ResidentTrackingLoop(system, prns, N, M, fs, shifts, re=re, im=im, idle_us=200000, **kw) as n:
+        first = n.run(50, keep_all=True)          # every block's accumulators
+        assert n.run(nblk - 50, start=50 * N) is None and n.blocks_done == nblk  # only the last block's kept
+        sn, pn, last = n.state(), n.params(), n.accumulators()
+        assert n.resident.info()["calls"] == nblk
+        # argument errors
+        lib, h = n._lib, n.resident._h
+        buf = np.zeros(2 * prns.size * 3 * M, np.float32)
+        args = lambda **o: [o.get("h", h), o.get("nb", 1), o.get("off", 0), N, C.byref(o.get("cfg", n.config)), C.c_void_p(n._state.ctypes.data),
+                            C.c_void_p(n._cur.ctypes.data), C.c_void_p(buf.ctypes.data), C.c_void_p(buf.ctypes.data), o.get("stride", 0)]
+        assert lib.gat_resident_tracking_run(*args(nb=-1)) == 1  # GAT_ERR_ARG
+        assert lib.gat_resident_tracking_run(*args(stride=3)) == 1  # GAT_ERR_ARG
+        assert lib.gat_resident_tracking_run(*args(off=1)) == 1  # GAT_ERR_ARG
+        assert lib.gat_resident_tracking_run(*args(h=None)) == 1  # GAT_ERR_ARG
+        bad = type(n.config).from_buffer_copy(n.config)
+        bad.num_taps = 5
+        assert lib.gat_resident_tracking_run(*args(cfg=bad)) == 1  # GAT_ERR_ARG
+        assert lib.gat_resident_tracking_run(*args(nb=0)) == 0
+    assert first.shape == (50, prns.size, 3, M)
+    assert np.array_equal(first, np.stack(accs[:50])) and np.array_equal(last, accs[-1])
+    assert sa.tobytes() == sn.tobytes() and pa.tobytes() == pn.tobytes()
