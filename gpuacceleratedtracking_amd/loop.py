@@ -131,7 +131,7 @@ class ResidentTrackingLoop:
     the CPU): one step = one call rung into a resident correlator (``gat_resident_correlate``: no kernel launch, outputs
     arrive on the host) + ``gat_tracking_update_host`` (the arithmetic of the device's ``gat_tracking_update``, csrc/gat_loop.h)
     that turns the accumulators into the next block's parameters.  Same constructor as ``TrackingLoop`` plus the signal
-    buffer the blocks live in; up to 16 channels (it pays for up to four)."""
+    buffer the blocks live in; up to 16 channels.  ``run`` is the native loop (gat_resident_tracking_run)."""
 
     def __init__(self, system: GNSSSystem, prns, num_samples: int, num_ants: int, sampling_frequency: float,
                  correlator_sample_shifts, init_carrier_doppler, init_code_phase, re: torch.Tensor, im: torch.Tensor | None = None,
