@@ -11,12 +11,13 @@
 //   a third of the spread, scripts/probes/doorbell_bar_probe.hip --; else in pinned host memory, polled by every
 //   workgroup or, with more than ~20 of them, by the master, which forwards it through device memory)
 //   -> the call's channel records and block offset arrive WITH the ring (one 64-byte line per channel)
-//   -> system-scope acquire (the signal may have been rewritten by a copy engine or another kernel since the last call)
-//   -> correlate this workgroup's share (antenna tile, channel, sample split) -> post its sums to the host as result lines
+//   -> correlate this workgroup's share (antenna tile, channel, sample split) with system-scope sample loads (the signal may
+//   have been rewritten by a copy engine or another kernel since the last call; no cache invalidate) -> post its sums to the
+//   host as result lines
 //   (64 bytes: 14 values | check | the call's number; plain stores, no fence, nothing to wait for) -> poll again.
 //
-// The host takes a call's results when every line of every workgroup carries the call's number and passes its check, and
-// adds the sample splits in fixed order (the second stage of the ordinary call, on ~100 floats).  No workgroup exchanges
+// The host walks the workgroups' lines in slot order while it waits: a workgroup whose lines carry the call's number and pass
+// their check is added to the outputs (the second stage of the ordinary call, splits in rising order: deterministic).  No workgroup exchanges
 // anything with another one: no arrival counter, no release / acquire pair, no partial sums in device memory -- each of
 // those was a trip through the memory system on the critical path (0.5-1.2 us apiece, profiles/r04/resident/).
 // Chip tables stay staged in LDS from call to call; the kernel's arguments are read once.

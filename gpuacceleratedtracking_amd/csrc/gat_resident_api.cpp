@@ -1,6 +1,7 @@
 // gat_resident_api.cpp -- the resident correlator's host side (include/gat.h gat_resident_*; kernel: gat_resident.h): geometry
-// from the planner, the doorbell and result lines in pinned host memory, ring / wait / second stage, restart after the
-// kernel has left, park before anything that waits for the whole device.
+// from the planner, the doorbell (device memory behind the PCIe BAR, or pinned host memory) and the result lines in pinned
+// host memory, ring / wait + second stage, restart after the kernel has left, park before anything that waits for the whole
+// device, the host-closed tracking loop.
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
