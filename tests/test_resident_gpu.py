@@ -42,7 +42,12 @@ def _open(g, case, layout=0, **config):
         keep = (x,)
         desc = g._lib.SignalDesc(x.data_ptr(), None, g.GAT_LAYOUT_INTERLEAVED, M, N, B * N, N, 0)
     torch.cuda.synchronize()
-    res = ctx.open_resident(desc, case["K"], case["shifts"], case["fs"], **config)
+    try:
+        res = ctx.open_resident(desc, case["K"], case["shifts"], case["fs"], **config)
+    except g.GatError as e:
+        if config.get("doorbell") == 2 and e.status == 4:  # GAT_ERR_UNSUPPORTED: the host cannot write device memory here
+            pytest.skip("no large BAR: the doorbell cannot live in device memory on this box")
+        raise
     res._keep = keep
     return ctx, res
 
@@ -68,11 +73,12 @@ def _open(g, case, layout=0, **config):
     (20004, 3, 5, 2, 0, 0, 0),
     (6146, 2, 3, 1, 1, 0, 0),     # ComplexF32 pairs, block starts 16 bytes off the line
 ])
-def test_resident_matches_oracle(gat, N, M, L, K, layout, max_wgs, pollers):
+@pytest.mark.parametrize("bell", [2, 1])  # the doorbell in device memory behind the PCIe BAR | in pinned host memory (polled directly or forwarded)
+def test_resident_matches_oracle(gat, N, M, L, K, layout, max_wgs, pollers, bell):
     g = gat
     case = make_case(900 + N % 97 + M + K, N=N, M=M, L=L, K=K, B=3)
     ref = oracle_result(case)
-    ctx, res = _open(g, case, layout, max_workgroups=max_wgs, host_pollers=pollers, idle_us=200000)
+    ctx, res = _open(g, case, layout, max_workgroups=max_wgs, host_pollers=pollers, idle_us=200000, doorbell=bell)
     try:
         info = res.info()
         assert info["running"] == 1 and info["launches"] == 1
@@ -223,15 +229,16 @@ def test_resident_lifetime_is_bounded_on_the_device(gat):
         res.close()
 
 
+@pytest.mark.parametrize("bell", [2, 1])
 @pytest.mark.parametrize("N,pollers", [(2048, 0), (16384, 0), (16384, 1), (65536, 0)])
-def test_resident_survives_rings_that_race_with_its_exit(gat, N, pollers):
+def test_resident_survives_rings_that_race_with_its_exit(gat, N, pollers, bell):
     """Calls at random distances around the kernel's idle limit (and a small call budget): some rings arrive while the
     master is leaving -- served by some workgroups, by none, or by a kernel that is started for them.  Every call must
     return the same bits, none may hang (the host's own deadline would turn a lost ring into an error)."""
     g = gat
     rng = np.random.default_rng(N + pollers)
     case = make_case(21, N=N, M=4, L=3, K=1, B=1)
-    ctx, res = _open(g, case, idle_us=300, life_ms=50, max_calls=37, host_pollers=pollers)
+    ctx, res = _open(g, case, idle_us=300, life_ms=50, max_calls=37, host_pollers=pollers, doorbell=bell)
     try:
         prm = _params(g, case, 0)
         first = tuple(a.copy() for a in res.correlate(prm))
