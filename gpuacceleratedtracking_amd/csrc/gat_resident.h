@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
     constexpr bool KEEP = false;
     constexpr int NVAL = 2 * MT * L;                                          // sums one workgroup posts per call
     constexpr int LW = (NVAL + kResLinePayload - 1) / kResLinePayload;        // its result lines
-    __shared__ unsigned s_bell[kResMaxChannels * kBellDwords];
+    __shared__ __attribute__((aligned(16))) unsigned s_bell[kResMaxChannels * kBellDwords];
     __shared__ unsigned s_ctl[1]; // the call's sequence number or kBellQuit
     __shared__ float s_out[64];
 
@@ -96,50 +96,52 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
     long long t_seen_ = 0;
 #endif
     for (;;) {
-        // ---- wait for a ring: wave 0 reads all K lines with ONE load (lane i <-> dword i).  Doorbell in device memory (the
+        // ---- wait for a ring: wave 0 reads all K lines with ONE 16-byte load per lane (lane i <-> dwords 4i .. 4i+3: a line is
+        // four lanes; sixteen channels are one load -- K > 4 used to cost a second trip, ~1 us).  Doorbell in device memory (the
         // host writes it through the BAR, eight copies): every workgroup polls its copy, r.forward = 0.  Doorbell in pinned host
         // memory -- few workgroups: every one polls it itself (nothing between the ring and any workgroup); many: reads of one host line queue up
         // behind each other (~0.15 us apiece: 33 pollers took 10 us to see a ring), so only the master polls the host and
         // copies what it sees -- rings and its decision to leave -- into eight doorbells in device memory (one per
-        // blockIdx % 8, on different memory channels) that the others poll.
+        // blockIdx % 8, on different memory channels) that the others poll.  Every line proves itself (number | check | number):
+        // no order among the lines of a ring is needed, on either hop.
         if (threadIdx.x < 64) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const int ln = (int)threadIdx.x;
             const bool from_host = master || r.forward == 0;
             const unsigned *src = (from_host ? r.host_bell + (blockIdx.x & (unsigned)(r.bell_copies - 1)) * (kResMaxChannels * kBellDwords)
-                                             : r.dev_bell + (blockIdx.x & 7u) * (kResMaxChannels * kBellDwords)) + ln;
-            // lane i <-> dword i of the first four lines; channels 4 .. 15 (rare: a receiver's whole constellation in one
-            // call) sit in three more 256-byte groups that are read only once line 0 shows a new ring -- one more trip
-            const int K0 = K < 4 ? K : 4;
-            const bool mine = ln < K0 * kBellDwords;
-            unsigned v = 0, vx[3] = {0u, 0u, 0u}, seq = last;
-            auto whole = [&](unsigned w, bool have, unsigned want) { // every line of a 256-byte group is whole and of ring `want`
-                unsigned x = (ln & 15) < 14 ? w : 0u;
-                x ^= __shfl_xor(x, 8, 64); x ^= __shfl_xor(x, 4, 64); x ^= __shfl_xor(x, 2, 64); x ^= __shfl_xor(x, 1, 64);
-                const unsigned chk = __shfl(w, (ln & ~15) + 14, 64), head = __shfl(w, ln & ~15, 64), tail = __shfl(w, (ln & ~15) + 15, 64);
-                const bool ok = !have || (x == chk && head == want && tail == want);
+                                             : r.dev_bell + (blockIdx.x & 7u) * (kResMaxChannels * kBellDwords)) + 4 * ln;
+            const bool mine = ln < 4 * K;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            unsigned seq = last;
+            // (one load of the doorbell in flight: several loads of one uncached line queue up behind each other and the oldest
+            // sees the ring.  Direct polling: the master's word in device memory is read with every poll, both loads in flight
+            // together -- one asm statement, or the compiler waits for the first before it issues the second)
+            const bool ask_leave = !(master || r.forward != 0);
+            unsigned leave_w = 0u;
+            auto load16 = [&]() {
+                u32x4 w;
+                if (ask_leave)
+                    asm volatile("global_load_dword %1, %3, off sc1\n\tglobal_load_dwordx4 %0, %2, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(w), "=&v"(leave_w) : "v"(src), "v"(r.dev_quit) : "memory");
+                else if (from_host) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(src) : "memory");
+                else asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(src) : "memory");
+                return w;
+            };
+            // every line whole and of ring `want`: first and last dword = want, XOR of dwords 0 .. 13 = dword 14
+            auto whole = [&](u32x4 w, unsigned want) {
+                unsigned x = w.x ^ w.y ^ ((ln & 3) == 3 ? 0u : (w.z ^ w.w));
+                x ^= __shfl_xor(x, 1, 64); x ^= __shfl_xor(x, 2, 64);
+                const unsigned head = __shfl(w.x, ln & ~3, 64), chk = __shfl(w.z, ln | 3, 64), tail = __shfl(w.w, ln | 3, 64);
+                const bool ok = !mine || (x == chk && head == want && tail == want);
                 return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
             };
             for (;;) {
-                if (mine) v = from_host ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                                        : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // (direct polling: the master's word in device memory is read with the same poll, both loads in flight together)
-                const unsigned leave = (master || r.forward != 0) ? 0u : __hip_atomic_load(r.dev_quit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                seq = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+                if (mine) v = load16();
+                const unsigned leave = (unsigned)__builtin_amdgcn_readlane((int)leave_w, 0); // (lane 0 always loads)
+                seq = (unsigned)__builtin_amdgcn_readlane((int)v.x, 0);
                 if (seq == kBellQuit || leave != 0u) { why = kResidentQuit; seq = kBellQuit; break; }
                 if (seq != last) {
-                    // every line whole and of this ring: first and last dword = seq, XOR of dwords 0..13 = dword 14
-                    bool ok = whole(v, mine, seq);
-                    if (ok && K > 4) {
-#pragma unroll
-                        for (int g = 0; g < 3; ++g) {
-                            const bool have = ln < (K - 4 * (g + 1)) * kBellDwords;
-                            if (have) vx[g] = from_host ? __hip_atomic_load(src + 64 * (g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                                                        : __hip_atomic_load(src + 64 * (g + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-#pragma unroll
-                        for (int g = 0; g < 3; ++g) ok = whole(vx[g], ln < (K - 4 * (g + 1)) * kBellDwords, seq) && ok;
-                    }
-                    if (ok) break;
+                    if (whole(v, seq)) break;
                     seq = last; // a line caught half-written (or the host has not reached line 0's siblings yet): read again
                 }
                 const long long now = wall_clock64();
@@ -157,25 +159,19 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
                 __builtin_amdgcn_s_sleep(2);
             }
             if (master) {
-                if (r.forward != 0) { // the ring, or the decision to leave, to the eight device doorbells (line 0's group last)
-                    const unsigned fwd = (seq == kBellQuit && ln == 0) ? kBellQuit : v;
-                    for (int c8 = 0; c8 < 8; ++c8) {
-                        unsigned *dst = r.dev_bell + c8 * (kResMaxChannels * kBellDwords) + ln;
-#pragma unroll
-                        for (int g = 0; g < 3; ++g)
-                            if (ln < (K - 4 * (g + 1)) * kBellDwords) __hip_atomic_store(dst + 64 * (g + 1), vx[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (K > 4) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // a poller that sees line 0 new finds the other groups new
+                if (r.forward != 0) { // the ring, or the decision to leave, to the eight device doorbells
+                    u32x4 fwd = v;
+                    if (seq == kBellQuit && ln == 0) fwd.x = kBellQuit;
                     if (mine)
-                        for (int c8 = 0; c8 < 8; ++c8)
-                            __hip_atomic_store(r.dev_bell + c8 * (kResMaxChannels * kBellDwords) + ln, fwd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int c8 = 0; c8 < 8; ++c8) {
+                            unsigned *dst = r.dev_bell + c8 * (kResMaxChannels * kBellDwords) + 4 * ln;
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(fwd) : "memory");
+                        }
                 } else if (seq == kBellQuit && ln == 0) {
                     __hip_atomic_store(r.dev_quit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            s_bell[ln] = v;
-#pragma unroll
-            for (int g = 0; g < 3; ++g) s_bell[64 * (g + 1) + ln] = vx[g];
+            *reinterpret_cast<u32x4 *>(&s_bell[4 * ln]) = v;
             if (ln == 0) s_ctl[0] = seq;
 #ifdef GAT_RES_STAMPS
             t_seen_ = wall_clock64();
