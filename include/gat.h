@@ -373,7 +373,7 @@ GAT_API int32_t gat_last_launch_info(const gat_ctx *ctx, gat_launch_info *out, s
  * travel with the ring), every workgroup of the kernel correlates its share and posts its sums to pinned host memory
  * stamped with the call's number, the host adds them in a fixed order: no launch, no stream wait, outputs already on
  * the host (2 MHz .. 8 MHz blocks: 5-6 us instead of 10.5-13.5; a 20 MHz block of four antennas and twelve channels:
- * 10 us instead of 17 -- DESIGN.md 4.2b).
+ * 9 us instead of 16 -- DESIGN.md 4.2b).
  *
  * Lifetime is bounded on the DEVICE side, whatever the host does: the kernel ends by itself after `idle_us` without a
  * call, after `life_ms` in total, or after `max_calls` calls; the next call starts it again (that call then costs a
