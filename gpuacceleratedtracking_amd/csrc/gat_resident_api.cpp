@@ -280,7 +280,7 @@ GAT_API int32_t gat_resident_correlate(gat_resident *res, const gat_channel_para
     const int *src = res->val_src.data(), *dst = res->val_dst.data();
     int slot = 0, kg = 0, ag = 0, sp = 0; // the next workgroup to take and its place in the call
     constexpr int kAhead = 12;
-    auto answered = [&]() {
+    auto take_arrived = [&]() { // true once every workgroup has been taken
         const unsigned long long *ln = reinterpret_cast<const unsigned long long *>(res->h_lines);
         for (; slot < res->wgs; ++slot) {
             const unsigned long long *q = ln + (size_t)slot * lw * 8;
@@ -310,14 +310,14 @@ GAT_API int32_t gat_resident_correlate(gat_resident *res, const gat_channel_para
     double t_first = 0.0;
 #endif
     for (unsigned spins = 0;; ++spins) {
-        if (answered()) break;
+        if (take_arrived()) break;
 #ifdef GAT_RES_STAMPS
         if (t_first == 0.0 && slot > 0) t_first = mono_us();
 #endif
         if ((spins & 15u) != 15u) continue;
         if (__atomic_load_n(&res->h_state[0], __ATOMIC_ACQUIRE) != kResidentRuns) {
             // the kernel has left (idle, lifetime, call budget) -- with this call served or not
-            if (answered()) break;
+            if (take_arrived()) break;
             res->last_exit = res->h_state[0];
             GAT_HIP(c, hipSetDevice(c->device));
             if ((rc = resident_start(res, prev)) != GAT_OK) return rc;

@@ -428,7 +428,8 @@ GAT_API int32_t gat_resident_correlate(gat_resident *resident, const gat_channel
  * accelerator, discriminators and loop filters on the CPU -- without a trip through the scripting host per block.
  * params_host[K]: in the first block's parameters, out those for the block after the last; state_host[K] as for
  * gat_tracking_update_host.  Block b's accumulators go to acc_re/acc_im_host + b * acc_block_stride floats ([M x L x K]
- * each; stride 0 keeps only the last block's). */
+ * each; stride 0 keeps only the last block's).  An error ends the run at the block it occurred in: params_host and
+ * state_host then hold the loop's state in front of that block. */
 GAT_API int32_t gat_resident_tracking_run(gat_resident *resident, int32_t num_blocks, int64_t first_block_offset,
                                           int64_t block_stride_samples, const gat_loop_config *config_host,
                                           gat_loop_state *state_host, gat_channel_params *params_host,
