@@ -467,9 +467,42 @@ def single_block(g, args) -> dict:
                 rec["resident_call"]["workgroups"] = op.resident_info["workgroups"]
         a, b = res["hip_fused"], res["hip_resident"]
         rec["resident_vs_launch_max_rel_diff"] = float(np.abs(a - b).max() / np.abs(a).max())
+        try:  # the receiver loop with the host in it (gat_resident_tracking_run: resident call + loop filters on the CPU per block)
+            rec["host_closed_loop"] = host_closed_loop(g, args)
+        except Exception as exc:  # noqa: BLE001
+            rec["host_closed_loop"] = {"error": f"{type(exc).__name__}: {exc}"}
         return rec
     except Exception as exc:  # noqa: BLE001
         return {"error": f"{type(exc).__name__}: {exc}"}
+
+
+def host_closed_loop(g, args, blocks: int = 400) -> dict:
+    """`blocks` consecutive 1 ms blocks of the headline shape (one satellite on every antenna) through the native host-closed
+    tracking loop: every block's correlator outputs and parameters are on the host.  Microseconds per block and real-time factor."""
+    import time
+
+    import torch
+    system = g.GNSSDICT[args.gnss]()
+    N, M, L = args.num_samples, args.num_ants, args.num_taps
+    fs = N / 1e-3
+    fc, dop, tau0 = g.get_code_frequency(system), 1200.0, 100.25
+    fcode = fc * (1 + dop / 1575.42e6)
+    b = np.arange(blocks, dtype=np.float64)[:, None]
+    lc = g.get_code_length(system)
+    prm = g.make_params(np.array([0]), np.array([fcode]), np.array([dop]), np.mod(tau0 + fcode * 1e-3 * b, lc), 2 * np.pi * np.mod(dop * 1e-3 * b, 1.0),
+                        shape=(blocks, 1))
+    re, im = g.gen_signal_stream(system, prm, fs, N, M)
+    shifts = g.get_correlator_sample_shifts(system, g.EarlyPromptLateCorrelator(M, L), fs, 0.5)
+    torch.cuda.synchronize()
+    with g.ResidentTrackingLoop(system, np.array([1]), N, M, fs, shifts, np.array([dop + 5.0]), np.array([tau0 + 0.05]), re=re, im=im, idle_us=200000) as loop:
+        loop.run(50)
+        t0 = time.perf_counter()
+        loop.run(blocks - 50, start=50 * N)
+        dt = (time.perf_counter() - t0) / (blocks - 50)
+        st, acc = loop.state(), loop.accumulators()
+    prompt = float(np.abs(acc[0, L // 2, :]).min()) / N
+    return {"us_per_block": round(dt * 1e6, 2), "real_time_factor": round(1e-3 / dt, 1), "blocks": blocks - 50, "workgroups": loop.resident_workgroups,
+            "doppler_error_hz": round(float(abs(st["carrier_doppler_hz"][0] - dop)), 3), "prompt_over_N": round(prompt, 3)}
 
 
 def main():

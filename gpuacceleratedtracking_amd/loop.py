@@ -149,6 +149,7 @@ class ResidentTrackingLoop:
         desc = _signal_desc(re, im, self.N, start=0)
         torch.cuda.current_stream(self.ctx.device).synchronize()  # the signal is on the device before the first ring
         self.resident = self.ctx.open_resident(desc, self.K, self.shifts, self.fs, **resident_config)
+        self.resident_workgroups = self.resident.info()["workgroups"]
         self._lib = self.ctx.lib
         self._fn = self._lib.gat_tracking_update_host
         self.acc_re = self.acc_im = None
