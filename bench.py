@@ -16,12 +16,20 @@ Infinity Cache).  One "step" = one pass of the fused kernel 
 Prints ONE JSON line on rank 0:
   value      = total samples x channels correlated per second over all ranks [Msamples/s]
                (inputs resident in HBM when the timed region starts; sync-inclusive)
-  roofline   = max(algorithmic bytes / 8 TB/s, algorithmic flops / 157.3 TFLOP/s) against the mean launch
-               duration (HIP events on the launch stream); `bound` names the winning term
+  step_ms    = {min, median, mean, sigma, max, n}: every timed step's duration, one HIP event per step on the launch
+               stream (the reference keeps every sample's time: BenchmarkTools Minimum / Median / Mean / sigma / Maximum,
+               src/benchmarks.jl:1-9)
+  roofline   = max(algorithmic bytes / 8 TB/s, algorithmic flops / 157.3 TFLOP/s) against the MEDIAN step duration
+               (frac_mean: against the mean of the same steps); `bound` names the winning term; read_ceiling_GBps = what
+               a kernel that only reads reaches over the same stream in this process (frac_of_ceiling); terms_ms.valu_issue
+               = the kernel's vector instructions (stored PMC count) at one wave-instruction per 2 cycles and SIMD
   cpu_baseline = the oracle's FP32 4-pass CPU restatement ("port") timed on this host on a bounded
                sample of the same stream (the reference's Julia CPU path cannot run here)
   shard_config3 (N > 1 only) = the same measurement, same settle / warm-up / steps, on BASELINE configs[3]'s per-GPU
                shard (16 antennas, 4 of the 32 PRNs per GPU, 1 ms @ 50 MHz)
+  constellation_config3 (--constellation, and by default for N > 1) = STRONG scaling of BASELINE configs[3] as a whole:
+               32 PRNs x 16 antennas @ 50 MHz, ShardPlan(32, N, rank) -> 32 / 16 / 8 / 4 PRNs per GPU at N = 1 / 2 / 4 / 8,
+               same protocol; value and real-time factor are the whole receiver's
   group_check (N > 1 only) = build/gat_multi_gpu run in a FRESH process after the ranks have finished: every visible
                device as one device group from one host thread -- peer replication of the signal (hipMemcpyPeerAsync
                between distinct devices), sharded launch, gather; bit_identical vs shard-by-shard on device 0, peer_copy_GBps
@@ -48,6 +56,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 F32_PEAK_TFLOPS = 157.3   # vector FP32 == f32-input MFMA peak (spec)
 BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (spec)
+NUM_SIMDS, PEAK_CLOCK_HZ, VALU_CYCLES = 1024, 2.4e9, 2.0  # 256 CUs x 4 SIMD-32; a wave64 vector instruction issues over 2 cycles
+
+CONSTELLATION_PRNS = 32  # BASELINE configs[3]: the whole constellation of the strong-scaling leg
 
 PRESETS = {
     1: {},
@@ -76,6 +87,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-block", action="store_true", help="skip the one-block-per-call latency figures")
     ap.add_argument("--no-shard-config3", action="store_true", help="N > 1: skip the configs[3] shard measurement")
+    ap.add_argument("--constellation", action="store_true",
+                    help="also measure BASELINE configs[3] as a whole (32 PRNs x 16 antennas @ 50 MHz, the PRNs sharded over the "
+                         "ranks: strong scaling); on by default for N > 1")
+    ap.add_argument("--no-constellation", action="store_true", help="N > 1: skip the strong-scaling constellation measurement")
+    ap.add_argument("--no-read-ceiling", action="store_true", help="skip the in-run read-ceiling probe (roofline.read_ceiling_GBps)")
     ap.add_argument("--no-group-check", action="store_true",
                     help="N > 1: skip the device-group self-check (build/gat_multi_gpu in a fresh process after the ranks are done)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
@@ -311,8 +327,19 @@ def algorithmic_flops(B, N, M, L, K) -> float:
     return float(B) * N * K * (30.0 + M * (8.0 + 4.0 * L))
 
 
-def roofline(shape, launch_s, matrix_core, traffic_and_source):
-    """max(bytes / HBM peak, flops / compute peak) vs the measured launch duration; names the winning term."""
+def step_stats(laps_ms) -> dict:
+    """min / median / mean / sigma / max of the timed steps (BenchmarkTools' estimators, src/benchmarks.jl:1-9), in ms."""
+    t = np.asarray(laps_ms, dtype=np.float64)
+    if t.size == 0:
+        return {"n": 0}
+    return {"min": round(float(t.min()), 6), "median": round(float(np.median(t)), 6), "mean": round(float(t.mean()), 6),
+            "sigma": round(float(t.std(ddof=1)) if t.size > 1 else 0.0, 6), "max": round(float(t.max()), 6), "n": int(t.size)}
+
+
+def roofline(shape, launch_s, matrix_core, stored, mean_s=None, ceiling=None):
+    """max(bytes / HBM peak, flops / compute peak) vs the measured launch duration (the MEDIAN step; `mean_s`: the mean of
+    the same steps beside it); names the winning term.  `stored`: (HBM bytes per launch, vector instructions per launch,
+    where they come from) of the committed PMC passes; `ceiling`: the in-run read-ceiling record."""
     import gpuacceleratedtracking_amd as g
 
     B, N, M, L, K, layout = shape
@@ -320,11 +347,20 @@ def roofline(shape, launch_s, matrix_core, traffic_and_source):
     flops = algorithmic_flops(B, N, M, L, K)
     t_hbm = alg_bytes / (HBM_PEAK_GBS * 1e9)
     t_f32 = flops / (F32_PEAK_TFLOPS * 1e12)
-    traffic, traffic_source = traffic_and_source
+    traffic, valu, traffic_source = stored
+    terms = {"hbm": round(t_hbm * 1e3, 6), "f32_flops": round(t_f32 * 1e3, 6)}
+    if valu and not matrix_core:
+        # issue-rate term: a SIMD issues one wave64 vector instruction per 2 cycles (MI355X_MICROARCH.md: SIMD-32); the
+        # launch's SQ_INSTS_VALU (stored PMC pass of this workload) over 1024 SIMDs at the 2.4 GHz the flop roof assumes
+        terms["valu_issue"] = round(valu * VALU_CYCLES / (NUM_SIMDS * PEAK_CLOCK_HZ) * 1e3, 6)
     out = {"algorithmic_bytes_per_launch": alg_bytes, "algorithmic_flops_per_launch": flops,
-           "kernel_ms_per_launch": round(launch_s * 1e3, 6), "traffic": traffic, "traffic_source": traffic_source,
-           "terms_ms": {"hbm": round(t_hbm * 1e3, 6), "f32_flops": round(t_f32 * 1e3, 6)},
+           "kernel_ms_per_launch": round(launch_s * 1e3, 6), "kernel_ms_statistic": "median of the timed steps",
+           "traffic": traffic, "traffic_source": traffic_source,
+           "terms_ms": terms, "limiting_term": max(terms, key=terms.get),
            "kernel": {0: "dc_kernel (vector)", 1: "mfma_kernel (f32 MFMA)", 2: "mfma_bf16_kernel (split-bf16 MFMA)"}.get(matrix_core, "?")}
+    if valu and not matrix_core:
+        out["valu_insts_per_launch"] = valu
+        out["frac_of_limiting_term"] = round(max(terms.values()) * 1e-3 / launch_s, 4)
     if t_hbm >= t_f32:
         ach = alg_bytes / launch_s / 1e9
         out.update(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
@@ -339,24 +375,58 @@ def roofline(shape, launch_s, matrix_core, traffic_and_source):
                                  "peak": BF16_PEAK_TFLOPS,
                                  "note": "split-bf16: 8 bf16 products per f32 product, 2M x 2KL x N real GEMM"}
     out["hbm_frac"] = round(alg_bytes / launch_s / 1e9 / HBM_PEAK_GBS, 4)
+    if mean_s:
+        out["frac_mean"] = round(out["frac"] * launch_s / mean_s, 4)
+        out["kernel_ms_per_launch_mean"] = round(mean_s * 1e3, 6)
+    if ceiling:
+        out["read_ceiling_GBps"] = ceiling.get("GBps")
+        out["read_ceiling"] = ceiling
+        if ceiling.get("GBps"):
+            out["frac_of_ceiling"] = round(alg_bytes / launch_s / 1e9 / ceiling["GBps"], 4)
     return out
 
 
+def read_ceiling(ctx, sig, layout_planar: bool) -> dict:
+    """"also report vs the measured read ceiling".  A kernel that ONLY reads (gat_debug_read_stream:
+    one 16-byte load per lane and step, nothing else) over the stream the correlator has just walked -- for the planar
+    layout its re plane (half the stream, still far beyond the 256 MB Infinity Cache) --, every reader variant 6 launches,
+    the best variant's median: what this device's memory system gives a read-once kernel in this process, now."""
+    try:
+        t = sig[0]
+        nbytes = (t.numel() * t.element_size()) // 16 * 16
+        best = None
+        for variant in (0, 1, 2, 3, 4, 5, 8, 9):  # 8 .. 64 workgroups per CU x {nt, plain} x {8, 4} loads in flight
+            ms = ctx.read_stream_ms(t, nbytes, variant=variant, launches=6)
+            med = float(np.median(ms[1:]))
+            if best is None or med < best[1]:
+                best = (variant, med, float(ms[1:].min()))
+        v, med, mn = best
+        ms = ctx.read_stream_ms(t, nbytes, variant=v, launches=12)  # the winner once more, longer
+        med, mn = float(np.median(ms[1:])), float(ms[1:].min())
+        return {"GBps": round(nbytes / med / 1e6, 1), "GBps_best_launch": round(nbytes / mn / 1e6, 1), "bytes": int(nbytes),
+                "ms_median": round(med, 6), "variant": v, "launches": 11,
+                "what": "gat_debug_read_stream over the " + ("re plane of the " if layout_planar else "") + "same stream: 16-byte loads only"}
+    except Exception as exc:  # noqa: BLE001 -- never fails the line
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def stored_traffic(key):
-    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE in separate runs, FETCH_SIZE doubled per the microarchitecture guide), keyed by workload.  NOT a
-    counter of this run (a PMC pass needs the profiler around the process): returns (bytes, where they come from)."""
+    """HBM bytes and vector instructions per launch from the committed PMC passes (profiles/pmc_traffic.json: rocprofv3
+    --pmc FETCH_SIZE, --pmc WRITE_SIZE and the SQ set in separate runs, FETCH_SIZE doubled per the microarchitecture guide),
+    keyed by workload.  NOT counters of this run (a PMC pass needs the profiler around the process): returns (bytes,
+    SQ_INSTS_VALU, where they come from)."""
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(tpath) as f:
             tj = json.load(f)
         for e in tj.get("entries", [tj]):
             if e.get("workload_key") == key:
-                return e.get("hbm_bytes_per_launch"), (f"stored: profiles/pmc_traffic.json <- {tj.get('source', '?')}, kernel "
-                                                       f"{e.get('kernel', '?')} (2 x FETCH_SIZE + WRITE_SIZE; not measured in this run)")
+                return (e.get("hbm_bytes_per_launch"), e.get("valu_insts_per_launch"),
+                        f"stored: profiles/pmc_traffic.json <- {tj.get('source', '?')}, kernel {e.get('kernel', '?')} "
+                        f"(2 x FETCH_SIZE + WRITE_SIZE; SQ_INSTS_VALU; not measured in this run)")
     except Exception:
         pass
-    return None, "none: no stored PMC pass for this workload"
+    return None, None, "none: no stored PMC pass for this workload"
 
 
 def measure(args, g, torch, dist, world, rank, shape_kw, steps, warmup, settle, want_host_copy):
@@ -365,8 +435,15 @@ def measure(args, g, torch, dist, world, rank, shape_kw, steps, warmup, settle, 
               "i16": g.GAT_LAYOUT_INTERLEAVED_I16, "i8": g.GAT_LAYOUT_INTERLEAVED_I8}[shape_kw["layout"]]
     flags = g.GAT_FLAG_ATOMIC if args.atomic else 0
     N, M, L, K, B = (shape_kw[k] for k in ("num_samples", "num_ants", "num_taps", "channels", "blocks"))
-    # channel sharding: rank r correlates PRNs [r*K, (r+1)*K) of the constellation on a replicated signal
-    plan = g.shard_channels(K * world, world, rank)
+    # channel sharding: rank r correlates PRNs [r*K, (r+1)*K) of the constellation on a replicated signal (weak scaling:
+    # K per GPU whatever N is); with "channels_total" the constellation is fixed and ShardPlan cuts it (strong scaling)
+    if shape_kw.get("channels_total"):
+        plan = g.shard_channels(int(shape_kw["channels_total"]), world, rank)
+        K = plan.count
+        if K < 1:
+            raise SystemExit(f"bench.py: rank {rank} of {world} gets no channel of {shape_kw['channels_total']}")
+    else:
+        plan = g.shard_channels(K * world, world, rank)
     op, desc, sig, prm = g.build_stream(shape_kw["gnss"], N, M, L, K, B, layout=layout, first_prn=plan.lo, flags=flags,
                                         block_seconds=shape_kw["block_ms"] * 1e-3, ant_pad=args.ant_pad)
     ctx = op.ctx
@@ -391,12 +468,17 @@ def measure(args, g, torch, dist, world, rank, shape_kw, steps, warmup, settle, 
     barrier()
     t0 = time.perf_counter()
     ctx.timer_start()
+    ctx.timer_lap()  # one HIP event per step on the launch stream: every step's duration, read after the timed region
     for _ in range(steps):
         op.launch(desc)
+        ctx.timer_lap()
     kernel_ms_total = ctx.timer_stop()  # HIP events on the launch stream; synchronises
     barrier()
     elapsed = time.perf_counter() - t0
+    laps = ctx.timer_laps(steps + 1)
+    median_ms = float(np.median(laps)) if laps.size else kernel_ms_total / steps
     per_rank = [elapsed * 1e3 / steps]
+    per_rank_kernel = [median_ms]
     props = torch.cuda.get_device_properties(torch.cuda.current_device())
     ident = {"rank": rank, "device": torch.cuda.current_device(), "name": ctx.device_info()["name"],  # name + gfx arch
              "pci_bus_id": "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
@@ -405,17 +487,37 @@ def measure(args, g, torch, dist, world, rank, shape_kw, steps, warmup, settle, 
     idents = [ident]
     if dist is not None:
         dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
-        t = torch.tensor([elapsed, kernel_ms_total], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, kernel_ms_total, median_ms], dtype=torch.float64, device=dev)
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms_total = float(t[0]), float(t[1])
+        elapsed, kernel_ms_total, median_ms = float(t[0]), float(t[1]), float(t[2])
         per_rank = [float(x[0]) * 1e3 / steps for x in gathered]
+        per_rank_kernel = [float(x[2]) for x in gathered]
         idents = [None] * world
         dist.all_gather_object(idents, ident)
     res = dict(devices=idents, op=op, desc=desc, sig=sig, prm=prm, ctx=ctx, fs=fs, layout=layout, shape=(B, N, M, L, K, layout),
-               elapsed=elapsed, launch_s=kernel_ms_total * 1e-3 / steps, per_rank_ms=per_rank, steps=steps)
+               elapsed=elapsed, launch_s=kernel_ms_total * 1e-3 / steps, per_rank_ms=per_rank, steps=steps, laps_ms=laps,
+               median_s=median_ms * 1e-3, per_rank_kernel_ms=per_rank_kernel, plan=plan, world=world)
     return res
+
+
+def leg_record(g, m, gnss, layout_name, args, backend, want_ceiling):
+    """What every measured shape reports beside its headline figures (rank 0): launch geometry, per-step statistics, roofline
+    (median-based, with the read ceiling and the issue-rate term), parity spot check."""
+    B, N, M, L, K, _ = m["shape"]
+    info = m["ctx"].last_launch_info()
+    err, h_re, h_im = parity_check(g, m)
+    ceiling = read_ceiling(m["ctx"], m["sig"], layout_name == "planar") if want_ceiling else None
+    rec = {"launch": info, "step_ms": step_stats(m["laps_ms"]),
+           "roofline": roofline(m["shape"], m["median_s"], info.get("matrix_core", 0), stored_traffic([gnss, N, M, L, K, B, layout_name]),
+                                mean_s=m["launch_s"], ceiling=ceiling),
+           "parity_max_rel_err_vs_f64_oracle": err}
+    if m["world"] > 1:
+        rec["ms_per_step_by_rank"] = [round(x, 6) for x in m["per_rank_ms"]]
+        rec["kernel_ms_median_by_rank"] = [round(x, 6) for x in m["per_rank_kernel_ms"]]
+        rec["backend"] = backend
+    return rec, (h_re, h_im)
 
 
 def parity_check(g, m):
@@ -533,10 +635,17 @@ def main():
         t = torch.tensor([float(rank)], dtype=torch.float64)
         got = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(got, t)
+        # the strong-scaling leg's plan, computed by every rank for itself as measure() does, then gathered
+        from gpuacceleratedtracking_amd.sharding import ShardPlan  # host arithmetic only (no GPU, no library load)
+        mine = ShardPlan(CONSTELLATION_PRNS, world, rank)
+        plans = [None] * world
+        dist.all_gather_object(plans, (rank, mine.lo, mine.count))
         dist.barrier()
         dist.destroy_process_group()
         if rank == 0:
-            rec = {"dryrun": True, "n_gpus": world, "ranks_seen": [int(x[0]) for x in got], "local_rank": local_rank}
+            rec = {"dryrun": True, "n_gpus": world, "ranks_seen": [int(x[0]) for x in got], "local_rank": local_rank,
+                   "constellation_config3": {"prns_total": CONSTELLATION_PRNS, "first_prn_by_rank": [p[1] for p in sorted(plans)],
+                                             "prns_by_rank": [p[2] for p in sorted(plans)], "scaling": "strong"}}
             if world > 1 and os.environ.get("GAT_BENCH_CHILD") != "1" and not args.no_group_check:
                 rec["group_check"] = group_check()  # external launcher: rank 0 runs it once the group is gone
             print(json.dumps(rec), flush=True)
@@ -575,12 +684,11 @@ def main():
     fs = m["fs"]
 
     out = None
+    want_ceiling = not args.no_read_ceiling
     if rank == 0:
         total_samples = float(B) * N * K * world * args.steps
         value = total_samples / m["elapsed"] / 1e6
-        info = m["ctx"].last_launch_info()
-        err, h_re, h_im = parity_check(g, m)
-        traffic = stored_traffic([args.gnss, N, M, L, K, B, args.layout])
+        rec, (h_re, h_im) = leg_record(g, m, args.gnss, args.layout, args, backend, want_ceiling)
         out = {
             "metric": "Msamples/s downconvert+correlate (E/P/L x ants x sats); real-time factor @ 1ms",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -595,21 +703,23 @@ def main():
                 "num_samples": N, "num_ants": M, "num_taps": L, "channels_per_gpu": K, "blocks_per_launch": B,
                 "layout": args.layout, "second_stage": "atomic" if args.atomic else "deterministic",
                 "sharding": f"channels x{world} (replicated signal, no collective)",
-                "launch": info,
+                "launch": rec["launch"],
             },
             "real_time_factor": round(value * 1e6 / fs / (K * world), 3),
-            "roofline": roofline(m["shape"], m["launch_s"], info.get("matrix_core", 0), traffic),
-            "parity_max_rel_err_vs_f64_oracle": err,
+            "step_ms": rec["step_ms"],
+            "roofline": rec["roofline"],
+            "parity_max_rel_err_vs_f64_oracle": rec["parity_max_rel_err_vs_f64_oracle"],
         }
         from gpuacceleratedtracking_amd.benchmarks import provenance
         out.update(provenance())  # "libgat": version + kernel-source commit + build flags, "git": repository commit
         if args.option:
             out["config"]["options"] = list(args.option)
         if world > 1:
-            out["ranks"] = {"world_size": world, "backend": backend, "ms_per_step_by_rank": [round(x, 6) for x in m["per_rank_ms"]],
-                            "devices": m["devices"]}
+            out["ranks"] = {"world_size": world, "backend": backend, "ms_per_step_by_rank": rec["ms_per_step_by_rank"],
+                            "kernel_ms_median_by_rank": rec["kernel_ms_median_by_rank"], "devices": m["devices"]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, h_re, h_im, m["prm"], m["op"].shifts, fs, m["op"].system)
+        del h_re, h_im
     del m
     if rank == 0 and world == 1 and not args.no_single_block:
         torch.cuda.empty_cache()
@@ -627,21 +737,39 @@ def main():
         if rank == 0:
             B3, N3, M3, L3, K3, _ = m3["shape"]
             v3 = float(B3) * N3 * K3 * world * steps3 / m3["elapsed"] / 1e6
-            info3 = m3["ctx"].last_launch_info()
-            err3, _, _ = parity_check(g, m3)
+            rec3, _ = leg_record(g, m3, "GPSL1", "planar", args, backend, False)
             out["shard_config3"] = {
                 "workload": f"GPSL1, {M3} ants, {K3 * world} PRNs sharded {K3}/GPU over {world} GPUs, {L3} correlators, 1 ms @ "
                             f"{m3['fs'] / 1e6:g} MHz, {B3} blocks/launch (BASELINE configs[3]: 32 PRNs at 8 GPUs)",
-                "value": round(v3, 3), "unit": "Msamples/s", "n_gpus": world, "steps": steps3, "warmup": args.warmup,
+                "value": round(v3, 3), "unit": "Msamples/s", "n_gpus": world, "scaling": "weak", "steps": steps3, "warmup": args.warmup,
                 "settle": args.settle, "ms_per_step": round(m3["elapsed"] * 1e3 / steps3, 6),
-                "ms_per_step_by_rank": [round(x, 6) for x in m3["per_rank_ms"]],
                 "real_time_factor": round(v3 * 1e6 / m3["fs"] / (K3 * world), 3),
-                "rccl_world_size": world, "backend": backend, "launch": info3,
-                "roofline": roofline(m3["shape"], m3["launch_s"], info3.get("matrix_core", 0),
-                                     stored_traffic(["GPSL1", N3, M3, L3, K3, B3, "planar"])),
-                "parity_max_rel_err_vs_f64_oracle": err3,
+                "rccl_world_size": world, **rec3,
             }
         del m3
+
+    # BASELINE configs[3] AS A WHOLE on however many GPUs there are (strong scaling): 32 PRNs x 16 antennas @ 50 MHz, the PRNs
+    # cut by ShardPlan(32, world, rank) -- 32 / 16 / 8 / 4 per GPU at N = 1 / 2 / 4 / 8 -- on a replicated signal, no collective
+    # (the reference's several-satellites-per-launch form: src/algorithms.jl:637-718).  value = samples x 32 channels per second
+    # of the whole receiver; real_time_factor = signal time per wall time of the slowest rank.
+    if (args.constellation or world > 1) and not args.no_constellation and args.baseline_config is None:
+        torch.cuda.empty_cache()
+        kwc = dict(PRESETS[3], layout="planar", block_ms=1.0, channels_total=CONSTELLATION_PRNS)
+        mc = measure(args, g, torch, dist, world, rank, kwc, args.steps, args.warmup, args.settle, False)
+        if rank == 0:
+            Bc, Nc, Mc, Lc_, Kc, _ = mc["shape"]
+            vc = float(Bc) * Nc * CONSTELLATION_PRNS * args.steps / mc["elapsed"] / 1e6
+            recc, _ = leg_record(g, mc, "GPSL1", "planar", args, backend, False)
+            out["constellation_config3"] = {
+                "workload": f"GPSL1, {Mc} ants, {CONSTELLATION_PRNS} PRNs over {world} GPU(s) = {mc['plan'].counts()} per GPU "
+                            f"(ShardPlan, contiguous), {Lc_} correlators, 1 ms @ {mc['fs'] / 1e6:g} MHz, {Bc} blocks/launch "
+                            f"(BASELINE configs[3] as a whole)",
+                "value": round(vc, 3), "unit": "Msamples/s", "n_gpus": world, "scaling": "strong", "steps": args.steps,
+                "warmup": args.warmup, "settle": args.settle, "ms_per_step": round(mc["elapsed"] * 1e3 / args.steps, 6),
+                "real_time_factor": round(Bc * 1e-3 * args.steps / mc["elapsed"], 3),
+                "prns_by_rank": mc["plan"].counts(), "rccl_world_size": world, **recc,
+            }
+        del mc
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

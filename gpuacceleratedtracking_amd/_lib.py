@@ -38,7 +38,9 @@ EXPORTS = [
     "gat_group_gather", "gat_group_sync",
     # resident correlator: single-block calls without a kernel launch
     "gat_resident_open", "gat_resident_correlate", "gat_resident_info_get", "gat_resident_park", "gat_resident_close",
-    "gat_tracking_update_host", "gat_resident_tracking_run",
+    "gat_tracking_update_host", "gat_resident_tracking_run", "gat_resident_park_all",
+    # measurement: per-call statistics, the in-run read ceiling; the texture-addressing study
+    "gat_timer_lap", "gat_timer_laps", "gat_debug_read_stream", "gat_gen_code_replica_texaddr",
 ]
 
 
@@ -188,6 +190,11 @@ def load(build_if_missing: bool = True):
         "gat_resident_close": (i32, [vp]),
         "gat_tracking_update_host": (i32, [vp, vp, i32, i32, C.POINTER(LoopConfig), vp, vp, vp]),
         "gat_resident_tracking_run": (i32, [vp, i32, i64, i64, C.POINTER(LoopConfig), vp, vp, vp, vp, i64]),
+        "gat_resident_park_all": (i32, [vp]),
+        "gat_timer_lap": (i32, [vp]),
+        "gat_timer_laps": (i32, [vp, C.POINTER(C.c_float), i32, i32p]),
+        "gat_debug_read_stream": (i32, [vp, vp, C.c_size_t, i32, i32, C.POINTER(C.c_float)]),
+        "gat_gen_code_replica_texaddr": (i32, [vp, vp, i64, i32, dbl, dbl, dbl, i64, i32, i32]),
     }
     assert sorted(sigs) == sorted(EXPORTS)
     for name, (res, args) in sigs.items():

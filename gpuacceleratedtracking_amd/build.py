@@ -15,7 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgat.so")
 SOURCES = ["gat_dc_f0.hip", "gat_dc_f1.hip", "gat_dc_f2.hip", "gat_dc_f3.hip", "gat_resident_f0.hip", "gat_resident_f1.hip",
            "gat_resident_f2.hip", "gat_resident_f3.hip",
-           "gat_kernels.hip", "gat_mfma.hip", "gat_mfma_bf16.hip", "gat_api.cpp", "gat_resident_api.cpp", "gat_codes.cpp"]
+           "gat_kernels.hip", "gat_mfma.hip", "gat_mfma_bf16.hip", "gat_api.cpp", "gat_planner.cpp", "gat_group.cpp",
+           "gat_resident_api.cpp", "gat_codes.cpp"]
 # gat_version.cpp is not in SOURCES: it is compiled at every link with the build's identity (git commit, flags)
 HEADERS = [os.path.join(CSRC, "gat_internal.h"), os.path.join(CSRC, "gat_phase.h"), os.path.join(CSRC, "gat_dc.h"),
            os.path.join(CSRC, "gat_dc_body.inc"), os.path.join(CSRC, "gat_resident.h"), os.path.join(CSRC, "gat_ctx.h"),
@@ -113,7 +114,7 @@ def build_libgat(force: bool = False, verbose: bool = False, extra_flags: tuple[
         sp = os.path.join(CSRC, src)
         # flags that only touch the fused vector kernel (-DGAT_DC_*): every other object is shared with the main build
         vector_tu = src.startswith("gat_dc_f") or src.startswith("gat_resident_f")  # both are made of gat_dc_body.inc
-        shared = dc_only and not vector_tu and src not in ("gat_api.cpp", "gat_resident_api.cpp")  # the planner shares gat_internal.h
+        shared = dc_only and not vector_tu and src not in ("gat_api.cpp", "gat_planner.cpp", "gat_resident_api.cpp")  # the planner shares gat_internal.h
         obj = os.path.join(base_objdir if shared else objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if shared:

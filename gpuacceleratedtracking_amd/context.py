@@ -102,6 +102,38 @@ class Context:
         self.check(self.lib.gat_timer_stop(self._h, C.byref(ms)), "gat_timer_stop")
         return float(ms.value)
 
+    def timer_lap(self):
+        """One event on the context's stream (include/gat.h gat_timer_lap): before the first timed launch and after every one."""
+        self.check(self.lib.gat_timer_lap(self._h), "gat_timer_lap")
+
+    def timer_laps(self, capacity: int = 1 << 16) -> np.ndarray:
+        """Waits for the newest lap; the intervals between consecutive laps in milliseconds (BenchmarkTools keeps every
+        sample's time the same way, src/benchmarks.jl:1-9)."""
+        buf = np.zeros(int(capacity), dtype=np.float32)
+        n = C.c_int32()
+        self.check(self.lib.gat_timer_laps(self._h, buf.ctypes.data_as(C.POINTER(C.c_float)), int(capacity), C.byref(n)), "gat_timer_laps")
+        return buf[:n.value].astype(np.float64)
+
+    def read_stream_ms(self, tensor_or_ptr, nbytes: int, variant: int = 0, launches: int = 8) -> np.ndarray:
+        """A kernel that only reads ``nbytes`` of device memory, ``launches`` times; milliseconds per launch
+        (include/gat.h gat_debug_read_stream: the in-run read ceiling of SURVEY section 8-d)."""
+        ptr = tensor_or_ptr if isinstance(tensor_or_ptr, int) else _ptr(tensor_or_ptr)
+        ms = np.zeros(int(launches), dtype=np.float32)
+        self.check(self.lib.gat_debug_read_stream(self._h, C.c_void_p(ptr), int(nbytes), int(variant), int(launches),
+                                                  ms.ctypes.data_as(C.POINTER(C.c_float))), "gat_debug_read_stream")
+        return ms.astype(np.float64)
+
+    def park_residents(self):
+        """Ask every resident correlator of this context to leave the device and wait until it has (gat_resident_park_all):
+        before anything that waits for the WHOLE device -- ``torch.cuda.synchronize()``, ``hipDeviceSynchronize`` -- which
+        would otherwise sit out the resident kernels' idle limit (5 ms by default).  The next call starts them again."""
+        self.check(self.lib.gat_resident_park_all(self._h), "gat_resident_park_all")
+
+    def device_synchronize(self):
+        """``torch.cuda.synchronize()`` that does not stall behind this context's resident correlators."""
+        self.park_residents()
+        torch.cuda.synchronize(self.device)
+
     # -- code tables --------------------------------------------------------------------
     def set_codes(self, codes: np.ndarray):
         """codes: int8 [num_prns, code_length] (C-order == reference's column-major [Lc x P]).
@@ -121,6 +153,19 @@ class Context:
             self.check(self.lib.gat_set_codes(self._h, arr.ctypes.data_as(C.POINTER(C.c_int8)), lc, p), "gat_set_codes")
             self._codes_key = key
         self._codes_obj = codes  # keeps the array alive, so the identity test above cannot be fooled by a recycled id
+        # the identity shortcut above is only sound while the bound array does not change: make an in-place edit RAISE instead
+        # of silently keeping the old chips on the device (bind a new array, or call invalidate_codes(), to change chips)
+        if isinstance(codes, np.ndarray):
+            try:
+                codes.flags.writeable = False
+            except ValueError:  # pragma: no cover - an array that does not own its flags
+                pass
+
+    def invalidate_codes(self):
+        """Forget which table is bound: the next operator call hashes and, if the contents changed, uploads its table again
+        (for a caller that had to edit a bound code array in place, after setting ``codes.flags.writeable = True``)."""
+        self._codes_obj = None
+        self._codes_key = None
 
     # -- operators ----------------------------------------------------------------------
     def downconvert_and_correlate(self, desc: _lib.SignalDesc, params, num_blocks: int, num_channels: int,
@@ -177,9 +222,17 @@ class Context:
 
     def gen_code_replica(self, out: torch.Tensor, count: int, prn: int, code_frequency: float,
                          sampling_frequency: float, code_phase: float, first_shift: int,
-                         f32_coordinates: bool = False):
+                         f32_coordinates: bool = False, texture_addressing: tuple[int, int] | None = None):
+        """``texture_addressing = (coord_frac_bits, texel_frac_bits)``: the fixed-point model of the texture unit's
+        addressing (include/gat.h gat_gen_code_replica_texaddr; study use)."""
         if out.numel() < count or out.dtype != torch.float32:
             raise ValueError("replica tensor too small or not float32")
+        if texture_addressing is not None:
+            cb, tb = texture_addressing
+            rc = self.lib.gat_gen_code_replica_texaddr(self._h, C.c_void_p(_ptr(out)), count, prn, float(code_frequency),
+                                                       float(sampling_frequency), float(code_phase), int(first_shift), int(cb), int(tb))
+            self.check(rc, "gat_gen_code_replica_texaddr")
+            return
         fn = self.lib.gat_gen_code_replica_f32coord if f32_coordinates else self.lib.gat_gen_code_replica
         rc = fn(self._h, C.c_void_p(_ptr(out)), count, prn, float(code_frequency), float(sampling_frequency),
                 float(code_phase), int(first_shift))
@@ -242,9 +295,13 @@ class Context:
                                             C.c_void_p(_ptr(out_re)), C.c_void_p(_ptr(out_im)))
         self.check(rc, "gat_reduce_cplx_multi")
 
-    def open_resident(self, desc: _lib.SignalDesc, num_channels: int, shifts, sampling_frequency: float, **config):
-        """A resident correlator for single-block calls (include/gat.h gat_resident_open): see ``ResidentCorrelator``."""
-        return ResidentCorrelator(self, desc, num_channels, shifts, sampling_frequency, **config)
+    def open_resident(self, desc: _lib.SignalDesc, num_channels: int, shifts, sampling_frequency: float,
+                      buffer_samples: int | None = None, **config):
+        """A resident correlator for single-block calls (include/gat.h gat_resident_open): see ``ResidentCorrelator``.
+        ``buffer_samples``: samples per antenna of the device buffer ``desc`` points into -- ``correlate`` then refuses a
+        ``block_offset`` whose block would end behind it (the kernel reads past its caches: an offset beyond the allocation
+        is a GPU page fault, not an exception)."""
+        return ResidentCorrelator(self, desc, num_channels, shifts, sampling_frequency, buffer_samples=buffer_samples, **config)
 
     def params_to_device(self, params: np.ndarray) -> torch.Tensor:
         prm = np.ascontiguousarray(params, dtype=_lib.PARAMS_DTYPE)
@@ -260,7 +317,11 @@ class ResidentCorrelator:
     The caller makes sure the block's samples are in device memory before ``correlate`` (``torch.cuda.synchronize()`` or
     ``ctx.sync()`` after whatever produced them).  Use as a context manager, or ``close()`` it."""
 
-    def __init__(self, ctx: Context, desc: _lib.SignalDesc, num_channels: int, shifts, sampling_frequency: float, **config):
+    def __init__(self, ctx: Context, desc: _lib.SignalDesc, num_channels: int, shifts, sampling_frequency: float,
+                 buffer_samples: int | None = None, **config):
+        self._limit = None if buffer_samples is None else int(buffer_samples) - int(desc.num_samples)  # largest block offset
+        if self._limit is not None and self._limit < 0:
+            raise ValueError("buffer_samples is shorter than one block")
         unknown = set(config) - {"idle_us", "life_ms", "max_calls", "max_workgroups", "host_pollers", "doorbell"}
         if unknown:
             raise TypeError(f"unknown resident option(s): {sorted(unknown)}")
@@ -293,6 +354,8 @@ class ResidentCorrelator:
             pp = prm.ctypes.data_as(C.POINTER(_lib.ChannelParams))
             if prm is params:
                 self._prm_obj, self._prm_ptr = params, pp
+        if self._limit is not None and not 0 <= block_offset <= self._limit:
+            raise ValueError(f"block_offset {block_offset}: the block would lie outside the buffer (0 .. {self._limit})")
         rc = self._fn(self._h, pp, int(block_offset), self._pre, self._pim)
         if rc != 0:
             self.ctx.check(rc, "gat_resident_correlate")

@@ -1,15 +1,6 @@
-// gat_api.cpp -- the C ABI declared in include/gat.h: context, validation, launch planning.
-//
-// Launch planning for the fused correlator (DESIGN.md "Kernels"):
-//   ant_tile MT = largest of {4,3,2,1} dividing M          (register accumulators 2*MT*L <= 64)
-//   vec      = 4 when every plane base/stride is 16-byte aligned, else 1
-//   aw, kt   = antenna tiles (waves) and channels per workgroup: 16 antennas share one replica, up to 4 channels loop
-//              over register-resident samples
-//   nw       = waves per workgroup: 4, or 1 for short blocks of 1-2 antenna tiles in a long stream
-//   splits   = workgroups per (block, channel, antenna tile): 1 once B*K*M/MT already fills the
-//              chip (>= 8 workgroups per CU), otherwise the block's samples are split and a
-//              finalize launch sums the per-split partials in fixed order.
-//   matrix-core kernels where they measured faster (auto rule below).
+// gat_api.cpp -- the C ABI declared in include/gat.h: context, validation, the stand-alone operators, timers, options, the
+// closed tracking loop with its graph cache.  The launch planner of the correlator is gat_planner.cpp, the device groups
+// gat_group.cpp, the resident correlator's host side gat_resident_api.cpp; all four share gat_ctx.h.
 #include <algorithm>
 #include <cctype>
 #include <cmath>
@@ -26,7 +17,7 @@
 
 using namespace gat;
 
-namespace {
+namespace gat {
 
 // Tracing ranges around the library's launch sequences (the reference wraps every launch of kernel_algorithm in
 // NVTX.@range, src/algorithms.jl:953, :973 ... :1526): roctxRangePush / Pop from librocprofiler-sdk-roctx, resolved at
@@ -48,19 +39,17 @@ struct Roctx {
         if (!push || !pop) push = nullptr, pop = nullptr;
     }
 };
-struct TraceRange { // RAII: one range per launch sequence of an entry point
-    explicit TraceRange(const char *name)
-    {
-        static const Roctx r; // resolved once, thread-safe
-        rx = &r;
-        if (rx->push) (void)rx->push(name);
-    }
-    ~TraceRange()
-    {
-        if (rx->pop) (void)rx->pop();
-    }
-    const Roctx *rx;
-};
+TraceRange::TraceRange(const char *name)
+{
+    static const Roctx r; // resolved once, thread-safe
+    rx = &r;
+    if (r.push) (void)r.push(name);
+}
+TraceRange::~TraceRange()
+{
+    const Roctx *r = static_cast<const Roctx *>(rx);
+    if (r->pop) (void)r->pop();
+}
 
 constexpr size_t kMaxLoopGraphs = 4;
 
@@ -112,517 +101,7 @@ int32_t upload_params(gat_ctx *c, const gat_channel_params *params_host, size_t 
 }
 
 
-} // namespace
-
-// (declared in gat_ctx.h: the resident correlator's host side asks it for a launch plan)
-int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_channel_params *params_dev,
-                            int32_t B, int32_t K, int32_t L, const int32_t *shifts, double fs,
-                            float *out_re, float *out_im, uint32_t flags, const gat_channel_params *params_inline,
-                            DcPlan *plan_out)
-{
-    c->wait_seq = 0;
-    const TraceRange trace("gat_downconvert_and_correlate");
-    if (!sig || (!params_dev && !params_inline) || !shifts || !out_re || !out_im) return fail(c, GAT_ERR_ARG, "null argument");
-    if (!c->d_codes) return fail(c, GAT_ERR_STATE, "gat_set_codes has not been called");
-    const int fmt = sig->layout;
-    if (fmt < GAT_LAYOUT_PLANAR || fmt > GAT_LAYOUT_INTERLEAVED_I8) return fail(c, GAT_ERR_ARG, "unknown signal layout");
-    const bool planar = fmt == GAT_LAYOUT_PLANAR;
-    if (!sig->re || (planar && !sig->im) || (!planar && sig->im))
-        return fail(c, GAT_ERR_ARG, "signal pointers do not match the layout");
-    if (B < 1 || K < 1 || sig->num_ants < 1 || sig->num_samples < 1)
-        return fail(c, GAT_ERR_ARG, "sizes must be positive");
-    if (L < 1 || L > GAT_MAX_TAPS) return fail(c, GAT_ERR_RANGE, "num_taps outside 1..GAT_MAX_TAPS");
-    if (!(fs > 0.0) || !std::isfinite(fs)) return fail(c, GAT_ERR_ARG, "sampling frequency must be positive");
-    if (flags & ~GAT_FLAG_ATOMIC) return fail(c, GAT_ERR_ARG, "unknown flag bits");
-    long long max_shift = 0;
-    for (int l = 0; l < L; ++l) max_shift = std::max<long long>(max_shift, std::llabs((long long)shifts[l]));
-    if (sig->num_samples + max_shift >= (1ll << 30))
-        return fail(c, GAT_ERR_RANGE, "num_samples + |shift| must stay below 2^30");
-    if (sig->ant_stride < 0 || sig->block_stride < 0 || sig->chan_stride < 0)
-        return fail(c, GAT_ERR_ARG, "negative stride");
-
-    const int M = sig->num_ants;
-    int MT = 1;
-    for (int mt = c->max_ant_tile; mt >= 1; --mt)
-        if (M % mt == 0) {
-            MT = mt;
-            break;
-        }
-    // 16-byte vector loads need every group start 16-byte aligned: plane bases and all strides
-    // multiples of the samples one 16-byte load holds (4 / 2 / 4 / 8 by format)
-    const int spv = dc_group_samples(4, fmt);
-    const long long plane_bytes = fmt == GAT_LAYOUT_PLANAR ? 4 : fmt == GAT_LAYOUT_INTERLEAVED ? 8 : fmt == GAT_LAYOUT_INTERLEAVED_I16 ? 4 : 2;
-    int vec = 1;
-    // ... in a block that a 32-bit descriptor length can describe.  The block LENGTH may be anything (the reference
-    // bounds each thread by num_samples, src/algorithms.jl:170): lanes beyond the last whole group read zeros through
-    // the buffer range check and the N % spv samples behind it are taken one per lane after the step loop.
-    // (a stride that is never applied -- one antenna, one block -- does not matter)
-    if (aligned16(sig->re) && (!planar || aligned16(sig->im)) && (sig->num_ants == 1 || sig->ant_stride % spv == 0) &&
-        (B == 1 || sig->block_stride % spv == 0) && sig->chan_stride % spv == 0 &&
-        sig->num_samples * plane_bytes < (1ll << 31))
-        vec = 4;
-
-    const long long N = sig->num_samples;
-    if (vec != 4) MT = 1; // unaligned input (scalar loads) is served one antenna per wave
-    // the vector kernel reaches a wave's MT antennas through ONE descriptor per plane (antenna = scalar offset): the
-    // tile's span of bytes must stay below 2^31 (a lane offset of 2^31 then means "beyond every record")
-    while (MT > 1 && ((long long)(MT - 1) * sig->ant_stride + N) * plane_bytes >= (1ll << 31)) {
-        int next = 1;
-        for (int mt = MT - 1; mt >= 1; --mt)
-            if (M % mt == 0) { next = mt; break; }
-        MT = next;
-    }
-
-    // ---- matrix-core paths: antenna-rich shapes whose (channel, tap) columns fill a useful part of
-    // a 32-column tile run on the matrix cores -- the split-bf16 kernel (gat_mfma_bf16.hip) by default,
-    // the f32-MFMA kernel (gat_mfma.hip) on request; everything else takes the vector kernel below.
-    {
-        int order[GAT_MAX_TAPS];
-        for (int l = 0; l < L; ++l) order[l] = l;
-        std::stable_sort(order, order + L, [&](int x, int y) { return shifts[x] < shifts[y]; });
-        const long long span = (long long)shifts[order[L - 1]] - shifts[order[0]];
-        const int CT = L <= kMfmaMaxTaps ? 16 / L : 0;
-        const bool shape_any = !plan_out && c->mc_mode != 0 && vec == 4 && N % spv == 0 /* whole load groups */ && M % 16 == 0 && sig->chan_stride == 0 && CT >= 1 &&
-                              span <= kMfmaMaxSpan && 2 * std::min(K, CT) * L >= 12 /* >= 3/8 of the columns */;
-        const bool shape_ok = shape_any && planar; // the f32-MFMA kernel reads planar f32 only
-        const int nct_total = shape_ok ? (K + CT - 1) / CT : 1;
-        int nct = nct_total >= 4 ? 4 : (nct_total >= 2 ? 2 : 1);
-        while (nct > 1 && nct * CT > 20) nct >>= 1; // both kernels keep at most 20 channel slots per workgroup
-        // kernel choice: 3 / 1 (auto) -> split-bf16 when its tile fits in LDS, 2 -> f32 MFMA.  GAT_MC_AUTO picks a matrix
-        // kernel only where it measured faster than the vector kernel (scripts/history/r02/r02_planner_scan.sh, profiles/r02/
-        // r02h_planner_scan.txt; N = 50 000, 3 taps): with float samples the round-2 vector kernel (16 antennas per
-        // workgroup, channel loop over register-resident samples, lean step loop) wins or ties up to 24 channels at 64
-        // antennas, 32 at 32 and 16 at 128, so the split-bf16 kernel takes M >= 32 with K >= 32 and M * K >= 2048
-        // (64 x 32: 0.53 vs 0.58 ms, 32 x 64: 0.84 vs 0.99, 64 x 64: 0.75 vs 1.03); from int8 pairs (single-term
-        // path, half the MFMAs) it wins from 24 (channel, tap, re/im) columns on at every M.  The f32-MFMA kernel is
-        // never chosen by itself any more: the round-2 vector kernel is faster everywhere (configs[4]: 2.45 vs 4.19 ms,
-        // 64 antennas x 32 channels: 0.58 vs 0.92 ms); it runs on request (GAT_MC_F32).
-        const bool int8_in = fmt == GAT_LAYOUT_INTERLEAVED_I8;
-        const bool auto_bf16 = 2ll * L * K >= 24 && (int8_in || (M >= 32 && K >= 32 && (long long)M * K >= 2048));
-        const bool auto_f32 = false;
-        const bool want_bf16 = c->mc_mode == 3 || (c->mc_mode == 1 && auto_bf16);
-        const bool want_f32 = c->mc_mode == 2 || (c->mc_mode == 1 && auto_f32);
-        int kind = 0, rt = 1, rep_stride_m = 0;
-        int nslots_b = 0, tiles_b = 0, nct_b = 1;
-        if (shape_any && want_bf16 && c->d_code_bits && c->d_zeros && N % spv == 0 && spv <= 8) {
-            // split-bf16 kernel: columns packed flat (2 L per channel), 32 per tile
-            tiles_b = (2 * L * K + 31) / 32;
-            const int rt_max = (M / 16) % 4 == 0 ? 4 : ((M / 16) % 2 == 0 ? 2 : 1);
-            for (int n = tiles_b >= 4 ? 4 : (tiles_b >= 2 ? 2 : 1); n >= 1 && !kind; n >>= 1) {
-                rt = (rt_max == 4 && n == 1) ? 2 : rt_max; // <4,1> does not fit the VGPR budget of a 12-wave workgroup
-                const int T = mfma_bf16_tile_samples(rt, n);
-                const int rs = ((T + (int)span + 31) / 32) * 32 + 1; // odd: channel rows land on different banks
-                const int ns = mfma_bf16_slots(n, L, K);
-                // at most one (slot, sample pair) item per producer thread
-                if (ns * T / 2 > mfma_bf16_producer_threads(rt, n) || ns > mfma_bf16_max_slots()) continue;
-                if (mfma_bf16_lds_bytes(rt, n, fmt, ns, rs, c->code_bits_stride) <= 160 * 1024) {
-                    kind = 2;
-                    nct_b = n;
-                    nslots_b = ns;
-                    rep_stride_m = rs;
-                }
-            }
-        }
-        if (shape_ok && !kind && want_f32) {
-            rep_stride_m = ((256 + (int)span + 31) / 32) * 32 + 1;
-            if (mfma_lds_bytes(nct, CT, rep_stride_m, c->code_row_stride, 0) <= 160 * 1024) kind = 1;
-        }
-        if (kind) {
-            if (kind == 2) nct = nct_b;
-            const int T = kind == 2 ? mfma_bf16_tile_samples(rt, nct) : 256;
-            if (!params_dev) {
-                const int32_t rc = upload_params(c, params_inline, (size_t)B * K);
-                if (rc != GAT_OK) return rc;
-                params_dev = c->d_params;
-            }
-            MfArgs m{};
-            m.re = sig->re;
-            m.im = sig->im;
-            m.params = params_dev;
-            m.codes = c->d_codes;
-            m.out_re = out_re;
-            m.out_im = out_im;
-            m.N = N;
-            m.ant_stride = sig->ant_stride;
-            m.block_stride = sig->block_stride;
-            m.fs = fs;
-            m.M = M; m.K = K; m.B = B; m.L = L; m.Lc = c->Lc; m.num_prns = c->P; m.code_row_stride = c->code_row_stride;
-            m.CT = CT;
-            m.chan_groups = kind == 2 ? (tiles_b + nct - 1) / nct : (nct_total + nct - 1) / nct;
-            m.nslots = nslots_b;
-            m.ant_tiles = kind == 2 ? M / (16 * rt) : M / 16;
-            m.total_steps = (int)((N + T - 1) / T);
-            const long long groups_m = (long long)B * m.ant_tiles * m.chan_groups;
-            // the split-bf16 kernel runs one 8-wave workgroup per CU (its LDS tile): 2 rounds fill the chip
-            const long long want = (kind == 2 ? 2ll : 4ll) * c->num_cus;
-            long long sp = std::max<long long>(1, (want + groups_m - 1) / groups_m);
-            sp = std::min<long long>(sp, m.total_steps);
-            m.steps_per_split = (int)((m.total_steps + sp - 1) / sp);
-            if (kind == 2) m.steps_per_split = std::min(m.steps_per_split, std::max(1, mfma_bf16_max_chain() / T));
-            m.splits = (m.total_steps + m.steps_per_split - 1) / m.steps_per_split;
-            if (kind == 2 && m.splits > 1) {
-                // one workgroup per CU at a time: prefer a split count whose workgroups fill whole rounds of the chip
-                // (735 workgroups on 256 CUs idle 13 % of the third round; 768 do not)
-                int best = m.splits;
-                double best_eff = 0.0;
-                for (int sp2 = m.splits; sp2 <= std::min<long long>(m.total_steps, (long long)m.splits + m.splits / 4 + 8); ++sp2) {
-                    const int sps = (m.total_steps + sp2 - 1) / sp2;
-                    const int real = (m.total_steps + sps - 1) / sps; // split count that step size really gives
-                    const long long wgs = groups_m * real;
-                    const long long rounds = (wgs + c->num_cus - 1) / c->num_cus;
-                    const double eff = (double)wgs / (double)(rounds * c->num_cus);
-                    if (eff > best_eff + 1e-9) {
-                        best_eff = eff;
-                        best = real;
-                    }
-                }
-                m.steps_per_split = (m.total_steps + best - 1) / best;
-                m.splits = (m.total_steps + m.steps_per_split - 1) / m.steps_per_split;
-            }
-            m.num_tiles = B * m.ant_tiles * m.splits;
-            m.max_abs_shift = (int)max_shift;
-            m.rep_span = (int)span;
-            m.rep_stride = rep_stride_m;
-            m.flags = flags;
-            for (int l = 0; l < kMfmaMaxTaps; ++l) {
-                m.shifts[l] = shifts[order[std::min(l, L - 1)]];
-                m.tap_index[l] = order[std::min(l, L - 1)];
-            }
-            const long long grid_m = ((long long)(m.num_tiles + 7) / 8) * 8 * m.chan_groups;
-            if (grid_m >= (1ll << 31)) return fail(c, GAT_ERR_RANGE, "grid too large");
-            const bool atomic_m = (flags & GAT_FLAG_ATOMIC) != 0;
-            const size_t out_elems_m = (size_t)B * K * L * M;
-            if (atomic_m) {
-                GAT_HIP(c, hipMemsetAsync(out_re, 0, out_elems_m * sizeof(float), c->stream));
-                GAT_HIP(c, hipMemsetAsync(out_im, 0, out_elems_m * sizeof(float), c->stream));
-            } else if (m.splits > 1) {
-                const int32_t rc = ensure_partial(c, (size_t)B * K * m.splits * L * M * 2 * sizeof(float));
-                if (rc != GAT_OK) return rc;
-            }
-            m.partial = c->d_partial;
-#ifdef GAT_MFMA_STAMPS
-            {
-                static unsigned long long *dbg = nullptr;
-                if (!dbg) hipMalloc(reinterpret_cast<void **>(&dbg), 8u << 20);
-                m.dbg = dbg;
-                c->dbg_ptr = dbg;
-            }
-#endif
-            unsigned lds;
-            if (kind == 2) {
-                m.codes_in_lds = 1; // sign-bit tables, always staged
-                m.code_bits = c->d_code_bits;
-                m.zeros = c->d_zeros;
-                m.code_bits_stride = c->code_bits_stride;
-                lds = (unsigned)mfma_bf16_lds_bytes(rt, nct, fmt, m.nslots, m.rep_stride, c->code_bits_stride);
-                GAT_HIP(c, launch_mfma_bf16(m, rt, nct, fmt, (unsigned)grid_m, lds, c->stream));
-            } else {
-                m.codes_in_lds = mfma_lds_bytes(nct, CT, m.rep_stride, c->code_row_stride, 1) <= 160 * 1024;
-                lds = (unsigned)mfma_lds_bytes(nct, CT, m.rep_stride, c->code_row_stride, m.codes_in_lds);
-                GAT_HIP(c, launch_mfma(m, nct, (unsigned)grid_m, lds, c->stream));
-            }
-            const bool fin_m = !atomic_m && m.splits > 1;
-            if (fin_m)
-                GAT_HIP(c, launch_finalize(c->d_partial, out_re, out_im, m.splits, L * M * 2, (long long)B * K, c->stream));
-            c->last.workgroups = (int32_t)grid_m;
-            c->last.threads = kind == 2 ? mfma_bf16_threads(rt, nct) : 2 * kThreads;
-            c->last.splits = m.splits;
-            c->last.ant_tile = kind == 2 ? 16 * rt : 16;
-            c->last.vec = 4;
-            c->last.lds_bytes = (int32_t)lds;
-            c->last.finalize_launched = fin_m ? 1 : 0;
-            c->last.matrix_core = kind;
-            c->last.channels_per_wg = kind == 2 ? m.nslots : nct * CT;
-            c->last.blocks_per_wg = 1;
-            c->last.prefetch_depth = 0;
-            return GAT_OK;
-        }
-    }
-    c->last.matrix_core = 0;
-
-    // ---- vector kernel (gat_dc.h): launch geometry ---------------------------------------------------------
-    // aw: antenna tiles (waves) per workgroup -- 16 antennas on 4 waves walk the same samples, so carrier and replica
-    //     are produced once per workgroup; kt: channels a workgroup loops over with the samples held in registers.
-    const int AT = M / MT;
-    int aw = 1, kt = 1;
-    if (vec == 4 && MT == 4) aw = AT % 4 == 0 ? 4 : (AT % 2 == 0 ? 2 : 1);
-    aw = std::min(aw, c->max_aw);
-    if (vec == 4 && aw == 4 && sig->chan_stride == 0 && K > 1) kt = K >= 3 ? 4 : 2;
-    kt = std::min(kt, c->max_kt);
-    if (plan_out) aw = 1, kt = 1;
-    // tap launches: sorted taps cut into groups of <= kMaxTapsPerLaunch whose span fits the LDS replica segment
-    int order[GAT_MAX_TAPS];
-    for (int l = 0; l < L; ++l) order[l] = l;
-    std::stable_sort(order, order + L, [&](int x, int y) { return shifts[x] < shifts[y]; });
-    int max_taps = 1; // taps of the widest launch (register accumulators 2 * MT * taps * kt)
-    for (int t0 = 0; t0 < L;) {
-        int t1 = t0 + 1;
-        while (t1 < L && t1 - t0 < kMaxTapsPerLaunch && (long long)shifts[order[t1]] - shifts[order[t0]] <= kMaxLaunchSpan) ++t1;
-        max_taps = std::max(max_taps, t1 - t0);
-        t0 = t1;
-    }
-    while (kt > 1 && !dc_has_instance(MT, max_taps, vec, aw, kt)) kt >>= 1;
-    while (aw > 1 && !dc_has_instance(MT, max_taps, vec, aw, kt)) aw >>= 1;
-    // LDS: two workgroups per CU at least (80 KB each); a chip table that does not even fit alone is an error
-    auto lds_of = [&](int kt_, int aw_) { return dc_lds_bytes(kt_, MT, c->code_row_stride, dc_chunk(vec, fmt, aw_)); };
-    while (kt > 1 && lds_of(kt, aw) > 80 * 1024) kt >>= 1;
-    if (lds_of(kt, aw) > 160 * 1024)
-        return fail(c, GAT_ERR_RANGE, "code table too long for the LDS-resident chip table of the vector kernel");
-    if (!dc_has_instance(MT, max_taps, vec, aw, kt)) return fail(c, GAT_ERR_UNSUPPORTED, "no kernel instance for this shape");
-    const int AG = AT / aw;
-    const int KG = (K + kt - 1) / kt;
-
-    const long long groups = (long long)B * KG * AG;
-    // One-wave workgroups: short blocks (a few steps of a four-wave workgroup) of one- or two-antenna tiles in a stream
-    // long enough to fill the chip with single waves.  Per block the set-up (parameters, rotations, walk constants) is
-    // then done by one wave instead of four, and no wave waits at a workgroup barrier.
-    int nw = 4;
-    if (c->one_wave && !plan_out && vec == 4 && aw == 1 && kt == 1 && MT <= 2 && c->code_row_stride <= 2048 &&
-        (N + dc_chunk(vec, fmt, 1) - 1) / dc_chunk(vec, fmt, 1) <= 8 &&
-        groups >= (c->one_wave_min >= 0 ? c->one_wave_min : 32ll * c->num_cus) &&
-        c->max_aw >= 4 /* the (1, 1, 1) tiling of the A/B tests keeps the four-wave geometry */ &&
-        dc_has_instance(MT, max_taps, vec, 1, 1, 1))
-        nw = 1;
-    const long long chunk = dc_chunk(vec, fmt, aw, nw);
-    // Workgroups per CU the split aims for: 8 -- except for the channel-looping instances (KT >= 2: 170-250 registers,
-    // two workgroups resident per CU), where a finer split only adds partial sums, a second launch and workgroup starts
-    // (configs[3] shard, 512 tiles: 2 / 4 / 8 per CU = 0.667 / 0.675 / 0.687 ms, profiles/r03/r03a_c4_split.txt).
-    const int per_cu = c->wgs_per_cu > 0 ? c->wgs_per_cu : (kt >= 2 ? 2 : 8);
-    const long long target = plan_out ? plan_out->max_wgs : (long long)per_cu * c->num_cus * (nw == 1 ? 4 : 1);
-    long long chunks = 0, splits = 1, cps = 1, bpw = 1;
-    auto plan = [&](long long slack) { // slack: virtual samples in front of a block (line alignment, below)
-        chunks = (N + slack + chunk - 1) / chunk;
-        splits = std::max<long long>(1, (target + groups - 1) / groups);
-        splits = std::min(splits, chunks);
-        // tiny blocks (latency regime): a second launch costs more than a few serial steps
-        // (a resident correlator has no second launch: its workgroups post their sums to the host, which adds them)
-        if (chunks <= 4 && !(flags & GAT_FLAG_ATOMIC) && !plan_out) splits = 1;
-        cps = (chunks + splits - 1) / splits;
-        splits = (chunks + cps - 1) / cps;
-    };
-    plan(0);
-    // short blocks in a long stream: one workgroup loops over several consecutive blocks (chip table, channel set-up
-    // and the workgroup launch are paid once) while the chip stays filled 16 workgroups deep per CU
-    if (splits == 1 && c->max_bpw > 1) {
-        const long long by_fill = std::max<long long>(1, groups / (16ll * c->num_cus * (nw == 1 ? 4 : 1)));
-        const long long by_len = std::max<long long>(1, (nw == 1 ? 64 : 16) / chunks);
-        bpw = std::min<long long>(std::min(by_fill, by_len), c->max_bpw);
-        if (c->force_bpw > 0) bpw = std::min<long long>(c->force_bpw, B); // A/B runs: option dc_bpw_force
-    }
-    // Line alignment (gat_dc.h): where a block of some antenna may start off a 128-byte line -- the base pointer or a stride
-    // that is applied is no multiple of 128 bytes (N = 50 000 floats: every other block) -- workgroups walk each block from
-    // the line its first sample lies in: up to 112 bytes of virtual samples in front of the block, hence the slack in the
-    // chunk count.  Four-wave workgroups that own one block each (several short blocks per workgroup keep their walk across
-    // block boundaries instead); option dc_align = 0 turns it off for A/B runs.
-    // (a resident correlator is told the block's offset with every call: it always walks from the line)
-    const bool align_head = c->align_head && vec == 4 && nw == 4 && bpw == 1 &&
-                            (plan_out || (reinterpret_cast<uintptr_t>(sig->re) & 127u) != 0 || (B > 1 && (sig->block_stride * plane_bytes) % 128 != 0) ||
-                             (M > MT && (sig->ant_stride * plane_bytes * MT) % 128 != 0) || (sig->chan_stride * plane_bytes) % 128 != 0);
-    if (align_head) plan(112 / plane_bytes);
-    const long long BG = (B + bpw - 1) / bpw;
-    const long long tiles = BG * AG * splits;
-    const long long grid_wgs = ((tiles + 7) / 8) * 8 * KG;
-    if (grid_wgs >= (1ll << 31)) return fail(c, GAT_ERR_RANGE, "grid too large");
-
-    const bool atomic = (flags & GAT_FLAG_ATOMIC) != 0;
-    const size_t out_elems = (size_t)B * K * L * M;
-    if (atomic) {
-        GAT_HIP(c, hipMemsetAsync(out_re, 0, out_elems * sizeof(float), c->stream));
-        GAT_HIP(c, hipMemsetAsync(out_im, 0, out_elems * sizeof(float), c->stream));
-    } else if (splits > 1 && !plan_out) {
-        const int32_t rc = ensure_partial(c, (size_t)B * K * splits * L * M * 2 * sizeof(float));
-        if (rc != GAT_OK) return rc;
-    }
-
-    DcArgs a{};
-    a.re = sig->re;
-    a.im = sig->im;
-    a.params = params_dev;
-    if (!params_dev && !plan_out) std::memcpy(a.inl, params_inline, (size_t)B * K * sizeof(gat_channel_params));
-    a.codes = c->d_codes;
-    a.out_re = out_re;
-    a.out_im = out_im;
-    a.partial = c->d_partial;
-    a.total_wgs = (unsigned)(tiles * KG);
-    // completion flag: small launches outside a stream capture (a replayed graph would store a stale number)
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(c->stream, &cap);
-    // (library-owned streams only: nobody else can have enqueued newer work on them behind the library's back)
-    const bool flagged = !plan_out && c->own_stream && c->d_flag && c->flag_max_wgs > 0 && tiles * KG <= c->flag_max_wgs && cap == hipStreamCaptureStatusNone;
-    (void)hipGetLastError();
-    auto next_seq = [&]() { // sequence numbers of flagged launches: never 0 (0 = "nothing to wait for")
-        if (++c->flag_seq == 0) ++c->flag_seq;
-        return c->flag_seq;
-    };
-    a.N = N;
-    a.ant_stride = sig->ant_stride;
-    a.block_stride = sig->block_stride;
-    a.chan_stride = sig->chan_stride;
-    a.fs = fs;
-    a.M = M;
-    a.K = K;
-    a.B = B;
-    a.Lc = c->Lc;
-    a.num_prns = c->P;
-    a.code_row_stride = c->code_row_stride;
-    a.KG = KG;
-    a.splits = (int)splits;
-    a.chunks_per_split = (int)cps;
-    a.total_chunks = (int)chunks;
-    a.ant_groups = AG;
-    a.blocks_per_wg = (int)bpw;
-    a.num_tiles = (int)tiles;
-    a.Ltot = L;
-    a.flags = flags;
-    a.keep_l2 = c->keep_l2 >= 0 ? c->keep_l2 : (KG > 1 && sig->chan_stride == 0);
-    a.n_vec = (int)(vec == 4 ? N - N % spv : N);
-    a.align_head = align_head ? 1 : 0;
-    // a block length that is no multiple of the load group: the N % spv samples behind the last whole group are added
-    // by dc_tail_kernel, one more (tiny) launch behind the vector kernel and its second stage
-    const bool tail = vec == 4 && N % spv != 0;
-    a.max_abs_shift = (int)max_shift;
-
-    DcLaunch cfg{};
-    cfg.ant_tile = MT;
-    cfg.aw = aw;
-    cfg.kt = kt;
-    cfg.nw = nw;
-    // Two register sets of samples (steps c+1 and c+2 in flight): the streaming regime of the four-antenna <= 3-tap tile
-    // only -- every byte read once (one channel group), a workgroup owns whole blocks (no split), >= 2 steps per block.
-    // (float samples: with int16 / int8 pairs the conversions make the step vector-bound and the third wave per SIMD that
-    // the second set costs is worth more: 0.206 -> 0.209 ms, 0.169 -> 0.170 ms)
-    const bool deep_ok = !plan_out && c->max_depth >= 2 && vec == 4 && splits == 1 && KG == 1 && c->keep_l2 != 1 && sig->chan_stride == 0 && chunks >= 2 &&
-                         (fmt == GAT_LAYOUT_PLANAR || fmt == GAT_LAYOUT_INTERLEAVED);
-    cfg.vec = vec;
-    cfg.format = fmt;
-    cfg.grid = (unsigned)grid_wgs;
-    const int seg_max = nw == 1 ? c->one_wave_seg : dc_segment_steps((int)chunk, kt, MT);
-    cfg.lds_bytes = (unsigned)dc_lds_bytes(kt, MT, c->code_row_stride, (int)chunk);
-
-    // Taps in any order: tap_index maps each tap of a launch back to its position in the caller's list
-    // (a single-tap launch always fits: span 0).
-    for (int t0 = 0; t0 < L;) {
-        int t1 = t0 + 1;
-        while (t1 < L && t1 - t0 < kMaxTapsPerLaunch &&
-               (long long)shifts[order[t1]] - shifts[order[t0]] <= kMaxLaunchSpan)
-            ++t1;
-        cfg.taps = t1 - t0;
-        for (int l = 0; l < kMaxTapsPerLaunch; ++l) {
-            a.shifts[l] = shifts[order[t0 + std::min(l, cfg.taps - 1)]];
-            a.tap_index[l] = order[t0 + std::min(l, cfg.taps - 1)];
-        }
-        a.rep_span = a.shifts[cfg.taps - 1] - a.shifts[0];
-        // Replica layout in LDS (gat_dc.h): linear, one 8-byte-aligned vector read per tap and 4 samples.  Taps at an
-        // even distance from the first read the replica itself; any tap at an odd distance needs the copy stored one
-        // entry further, and the segment shrinks so that both fit the channel's share of LDS.
-        bool odd = false;
-        for (int l = 0; l < cfg.taps; ++l) odd |= ((a.shifts[l] - a.shifts[0]) & 1) != 0;
-        int seg = seg_max;
-        if (nw == 1) { // the replica's LDS is sized for this launch: segment + tap span + one entry per producer lane
-            cfg.depth = 1;
-            a.seg_steps = (int)std::min<long long>(seg, cps);
-            if (deep_ok && seg >= 2 && dc_has_instance(MT, cfg.taps, vec, aw, kt, nw, 2)) {
-                cfg.depth = 2; // whole groups of two steps per segment; the kernel pads the block's last group
-                a.seg_steps = (int)std::min<long long>(seg - seg % 2, (cps + 1) / 2 * 2);
-            }
-            const int one = dc_rep_copy_floats(a.seg_steps, (int)chunk, a.rep_span, 64);
-            a.rep_copy_stride = odd ? one : 0;
-            a.rep_chan_floats = ((odd ? 2 : 1) * one + 7) & ~7;
-            cfg.lds_bytes = (unsigned)dc_lds_bytes_one_wave(a.rep_chan_floats, c->code_row_stride);
-        } else {
-            // An instance that holds four waves per SIMD (dc_min_waves) needs four workgroups per CU to get them: with
-            // 10 KB chip tables (GPS L5) the full eight-step segment makes a workgroup 47 KB -- three per CU.  Such launches
-            // take a segment short enough for 40 KB (configs[2]: six steps; 1.151 -> 1.106 ms together with the two-sample
-            // passes that bring the five-tap instance to 128 registers, profiles/r04/r04g_c2_four_waves.txt).
-            // (a tap span beyond the default sizing -- seven taps half a chip apart at 262 MHz span 768 samples -- gets the
-            // room it needs in the same launch instead of a second launch: 22.8 -> 17 us for that call)
-            const int span_sz = std::max(kMaxReplicaSpan, a.rep_span);
-            const int want_waves = dc_min_waves(MT, cfg.taps, kt, 1, fmt);
-            if (want_waves >= 4)
-                while (seg > 2 && dc_lds_bytes_floats(kt, c->code_row_stride, dc_rep_chan_floats_steps(seg, (int)chunk, span_sz)) > (size_t)(160 / want_waves) * 1024) --seg;
-            if (span_sz > kMaxReplicaSpan)
-                while (seg > 1 && dc_lds_bytes_floats(kt, c->code_row_stride, dc_rep_chan_floats_steps(seg, (int)chunk, span_sz)) > 64 * 1024) --seg;
-            const int chan_floats = dc_rep_chan_floats_steps(seg, (int)chunk, span_sz);
-            if (dc_lds_bytes_floats(kt, c->code_row_stride, chan_floats) > 160 * 1024)
-                return fail(c, GAT_ERR_RANGE, "tap span and code table do not fit the LDS of one workgroup");
-            a.rep_chan_floats = chan_floats;
-            cfg.lds_bytes = (unsigned)dc_lds_bytes_floats(kt, c->code_row_stride, chan_floats);
-            if (odd)
-                while (seg > 1 && 2 * dc_rep_copy_floats(seg, (int)chunk, a.rep_span) > chan_floats) --seg;
-            cfg.depth = 1;
-            if (deep_ok && seg >= 2 && dc_has_instance(MT, cfg.taps, vec, aw, kt, nw, 2)) {
-                cfg.depth = 2;
-                seg -= seg % 2; // whole groups of two steps per segment; the kernel pads the block's last group
-            }
-            a.seg_steps = (int)std::min<long long>(seg, (cps + cfg.depth - 1) / cfg.depth * cfg.depth);
-            a.rep_copy_stride = odd ? dc_rep_copy_floats(a.seg_steps, (int)chunk, a.rep_span) : 0;
-        }
-        for (int l = 0; l < kMaxTapsPerLaunch; ++l) {
-            const int d = a.shifts[l] - a.shifts[0];
-            a.tap_off[l] = (d & 1) ? a.rep_copy_stride + d - 1 : d;
-        }
-        // completion flag: carried by the call's last launch -- the last tap group's kernel, or the second stage behind it
-        const bool later_follows = (!atomic && splits > 1) || tail;
-        if (flagged && !later_follows && t1 >= L) {
-            a.done_counter = c->d_done;
-            a.host_flag = c->d_flag;
-            a.flag_seq = next_seq();
-        }
-        if (plan_out) {
-            if (t1 < L) return fail(c, GAT_ERR_UNSUPPORTED, "resident correlator: the taps need more than one launch");
-            if (vec != 4 || tail) return fail(c, GAT_ERR_UNSUPPORTED, "resident correlator: block starts must be 16-byte aligned and num_samples a multiple of the load group");
-            if (cfg.depth != 1 || nw != 4) return fail(c, GAT_ERR_UNSUPPORTED, "resident correlator: no instance for this geometry");
-            plan_out->a = a;
-            plan_out->a.keep_l2 = 0; // the resident instances read the signal with non-temporal loads
-            plan_out->cfg = cfg;
-            return GAT_OK;
-        }
-        GAT_HIP(c, launch_dc(a, cfg, c->stream));
-        t0 = t1;
-    }
-    const bool fin = !atomic && splits > 1;
-    if (fin) {
-        const bool carry = flagged && !tail;
-        GAT_HIP(c, launch_finalize(c->d_partial, out_re, out_im, (int)splits, L * M * 2, (long long)B * K, c->stream,
-                                   carry ? c->d_done : nullptr, c->d_flag, carry ? next_seq() : 0u));
-    }
-    if (tail) {
-        DcTailArgs t{};
-        t.re = sig->re;
-        t.im = sig->im;
-        t.params = params_dev;
-        if (!params_dev) std::memcpy(t.inl, params_inline, (size_t)B * K * sizeof(gat_channel_params));
-        t.codes = c->d_codes;
-        t.out_re = out_re;
-        t.out_im = out_im;
-        if (flagged) {
-            t.done_counter = c->d_done;
-            t.host_flag = c->d_flag;
-            t.flag_seq = next_seq();
-        }
-        t.N = N; t.ant_stride = sig->ant_stride; t.block_stride = sig->block_stride; t.chan_stride = sig->chan_stride;
-        t.fs = fs;
-        t.M = M; t.K = K; t.B = B; t.L = L; t.Lc = c->Lc; t.num_prns = c->P; t.code_row_stride = c->code_row_stride;
-        t.format = fmt; t.n_vec = a.n_vec; t.max_abs_shift = (int)max_shift;
-        for (int l = 0; l < L; ++l) t.shifts[l] = shifts[l];
-        GAT_HIP(c, launch_dc_tail(t, c->stream));
-    }
-    if (flagged) c->wait_seq = c->flag_seq;
-
-    c->last.workgroups = (int32_t)cfg.grid;
-    c->last.threads = 64 * nw;
-    c->last.splits = (int32_t)splits;
-    c->last.ant_tile = MT * aw;
-    c->last.vec = vec;
-    c->last.lds_bytes = (int32_t)cfg.lds_bytes;
-    c->last.finalize_launched = fin ? 1 : 0;
-    c->last.channels_per_wg = kt;
-    c->last.blocks_per_wg = (int32_t)bpw;
-    c->last.prefetch_depth = cfg.depth;
-    return GAT_OK;
-}
-
-
+} // namespace gat
 
 namespace {
 
@@ -843,6 +322,7 @@ GAT_API int32_t gat_destroy(gat_ctx *c)
     if (c->d_params) (void)hipFree(c->d_params);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->lap_events) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return GAT_OK;
@@ -1039,6 +519,25 @@ GAT_API int32_t gat_gen_code_replica_f32coord(gat_ctx *c, float *rep, int64_t co
                                               double fs, double tau, int64_t first_shift)
 {
     return gen_code_replica_impl(c, rep, count, prn, fc, fs, tau, first_shift, true);
+}
+
+GAT_API int32_t gat_gen_code_replica_texaddr(gat_ctx *c, float *rep, int64_t count, int32_t prn, double fc, double fs, double tau,
+                                             int64_t first_shift, int32_t coord_frac_bits, int32_t texel_frac_bits)
+{
+    if (!c || !rep) return fail(c, GAT_ERR_ARG, "null argument");
+    if (!c->d_codes) return fail(c, GAT_ERR_STATE, "gat_set_codes has not been called");
+    if (count < 1) return fail(c, GAT_ERR_ARG, "count must be positive");
+    if (prn < 0 || prn >= c->P) return fail(c, GAT_ERR_RANGE, "prn outside the code table");
+    if (!(fs > 0.0) || !std::isfinite(fc) || !std::isfinite(tau)) return fail(c, GAT_ERR_ARG, "bad frequency / phase");
+    if (count + std::llabs((long long)first_shift) >= (1ll << 30)) return fail(c, GAT_ERR_RANGE, "replica too long");
+    if (coord_frac_bits < 0 || coord_frac_bits > 32 || texel_frac_bits < -1 || texel_frac_bits > 24)
+        return fail(c, GAT_ERR_RANGE, "coord_frac_bits 0 .. 32, texel_frac_bits -1 .. 24");
+    GAT_HIP(c, hipSetDevice(c->device));
+    c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
+    const TraceRange trace("gat_gen_code_replica_texaddr");
+    GAT_HIP(c, launch_gen_code_replica_texaddr(rep, count, c->d_codes + (size_t)prn * c->code_row_stride, c->Lc, fc, fs, tau,
+                                               first_shift, coord_frac_bits, texel_frac_bits, c->stream));
+    return GAT_OK;
 }
 
 GAT_API int32_t gat_gen_code_replica_multi(gat_ctx *c, float *rep, int64_t count, int64_t row_stride, int32_t K,
@@ -1290,6 +789,59 @@ GAT_API int32_t gat_timer_stop(gat_ctx *c, float *ms)
     return GAT_OK;
 }
 
+// per-call statistics (src/benchmarks.jl:1-9 keeps every sample's time): one event per lap from a pool of the context's
+GAT_API int32_t gat_timer_lap(gat_ctx *c)
+{
+    if (!c) return GAT_ERR_ARG;
+    GAT_HIP(c, hipSetDevice(c->device));
+    if (c->laps == c->lap_events.size()) {
+        if (c->laps >= (size_t)1 << 20) return fail(c, GAT_ERR_RANGE, "too many laps outstanding: call gat_timer_laps");
+        hipEvent_t e = nullptr;
+        GAT_HIP(c, hipEventCreate(&e));
+        c->lap_events.push_back(e);
+    }
+    c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
+    GAT_HIP(c, hipEventRecord(c->lap_events[c->laps], c->stream));
+    ++c->laps;
+    return GAT_OK;
+}
+
+GAT_API int32_t gat_timer_laps(gat_ctx *c, float *ms, int32_t capacity, int32_t *num)
+{
+    if (!c || !num || capacity < 0 || (capacity > 0 && !ms)) return fail(c, GAT_ERR_ARG, "null argument or negative capacity");
+    *num = 0;
+    const size_t laps = c->laps;
+    c->laps = 0; // forgotten whatever happens below
+    if (laps == 0) return GAT_OK;
+    GAT_HIP(c, hipSetDevice(c->device));
+    GAT_HIP(c, hipEventSynchronize(c->lap_events[laps - 1]));
+    const size_t n = std::min<size_t>(laps - 1, (size_t)capacity);
+    for (size_t i = 0; i < n; ++i) GAT_HIP(c, hipEventElapsedTime(&ms[i], c->lap_events[i], c->lap_events[i + 1]));
+    *num = (int32_t)n;
+    return GAT_OK;
+}
+
+// a kernel that only reads (the measured read ceiling beside the spec peak)
+GAT_API int32_t gat_debug_read_stream(gat_ctx *c, const void *dev, size_t bytes, int32_t variant, int32_t launches, float *ms_each)
+{
+    if (!c || !dev || !ms_each) return fail(c, GAT_ERR_ARG, "null argument");
+    if (bytes < 16 || bytes % 16 != 0 || !aligned16(dev)) return fail(c, GAT_ERR_ARG, "the range must be whole, aligned 16-byte groups");
+    if (launches < 1 || launches > 4096 || variant < 0 || variant > 15) return fail(c, GAT_ERR_RANGE, "1 .. 4096 launches, variants 0 .. 15");
+    GAT_HIP(c, hipSetDevice(c->device));
+    c->wait_seq = 0; // newer work than a flagged launch: gat_sync waits on the stream
+    int32_t rc = ensure_partial(c, 64);
+    if (rc != GAT_OK) return rc;
+    const TraceRange trace("gat_debug_read_stream");
+    for (int32_t i = 0; i < launches; ++i) {
+        GAT_HIP(c, hipEventRecord(c->ev0, c->stream));
+        GAT_HIP(c, launch_read_stream(dev, bytes, variant, c->num_cus, c->d_partial, c->stream));
+        GAT_HIP(c, hipEventRecord(c->ev1, c->stream));
+        GAT_HIP(c, hipEventSynchronize(c->ev1));
+        GAT_HIP(c, hipEventElapsedTime(&ms_each[i], c->ev0, c->ev1));
+    }
+    return GAT_OK;
+}
+
 #ifdef GAT_MFMA_STAMPS
 extern "C" GAT_API int32_t gat_debug_read(gat_ctx *c, unsigned long long *host, size_t count)
 {
@@ -1333,265 +885,6 @@ GAT_API int32_t gat_last_launch_info(const gat_ctx *c, gat_launch_info *out, siz
     if (!c || !out || struct_size == 0) return GAT_ERR_ARG;
     // the struct grows at its end: a caller built against an older header gets the fields it knows
     std::memcpy(out, &c->last, std::min(struct_size, sizeof(gat_launch_info)));
-    return GAT_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Device groups: satellite channels sharded over several devices from ONE host thread.
-// Every member is an ordinary context with its own stream; nothing below synchronises unless it says so, so the
-// per-device launches of one gat_group_correlate overlap.  No collective: the signal is replicated with peer copies
-// (xGMI between the GPUs of one node), outputs are disjoint per channel.
-// ---------------------------------------------------------------------------------------------------------------------
-struct gat_group {
-    std::vector<gat_ctx *> ctx;
-    std::vector<gat_channel_params> staging; // host copy of one shard's parameters ([K_r x B]); reused per rank
-    std::string err;
-};
-
-namespace {
-int32_t gfail(gat_group *g, int32_t code, const char *msg)
-{
-    if (g) g->err = msg;
-    return code;
-}
-void shard_bounds(int total, int n, int r, int *lo, int *cnt)
-{
-    const int base = total / n, extra = total % n;
-    *lo = r * base + std::min(r, extra);
-    *cnt = base + (r < extra ? 1 : 0);
-}
-} // namespace
-
-GAT_API int32_t gat_device_count(int32_t *count)
-{
-    if (!count) return GAT_ERR_ARG;
-    int n = 0;
-    const hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess) return -(int32_t)e;
-    *count = n;
-    return GAT_OK;
-}
-
-namespace {
-// one peer copy on dst's stream behind `filled` (an event recorded on the source stream); *copied (optional) receives an
-// event recorded behind the copy on dst's stream
-hipError_t peer_copy_after(gat_ctx *dst, void *dst_dev, gat_ctx *src, const void *src_dev, size_t bytes, hipEvent_t filled,
-                           hipEvent_t *copied)
-{
-    hipError_t e = hipSetDevice(dst->device);
-    if (e == hipSuccess) e = hipStreamWaitEvent(dst->stream, filled, 0);
-    if (e == hipSuccess) {
-        if (dst->device == src->device)
-            e = hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, dst->stream);
-        else
-            e = hipMemcpyPeerAsync(dst_dev, dst->device, src_dev, src->device, bytes, dst->stream);
-    }
-    if (e == hipSuccess && copied && dst->stream != src->stream) {
-        e = hipEventCreateWithFlags(copied, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventRecord(*copied, dst->stream);
-    }
-    return e;
-}
-
-// dsts[i] <- src for every i, all copies in flight together: ONE "source is complete" event on the source stream, a
-// copy on every destination's stream behind it, then the source stream waits for all of them -- whatever it is given
-// next (the following block's ingest overwriting src) runs after the copies have read the buffer.  (Waiting per copy
-// would chain them: the second destination's "complete" event would sit behind the wait for the first copy.)
-int32_t peer_fanout(gat_ctx *err_ctx, gat_ctx *src, const void *src_dev, size_t n, gat_ctx *const *dsts, void *const *dst_devs,
-                    size_t bytes)
-{
-    hipEvent_t filled = nullptr;
-    std::vector<hipEvent_t> copied(n, nullptr);
-    GAT_HIP(err_ctx, hipSetDevice(src->device));
-    GAT_HIP(err_ctx, hipEventCreateWithFlags(&filled, hipEventDisableTiming));
-    hipError_t e = hipEventRecord(filled, src->stream);
-    src->wait_seq = 0;
-    for (size_t i = 0; i < n && e == hipSuccess; ++i) {
-        dsts[i]->wait_seq = 0;
-        e = peer_copy_after(dsts[i], dst_devs[i], src, src_dev, bytes, filled, &copied[i]);
-    }
-    if (e == hipSuccess) e = hipSetDevice(src->device);
-    for (size_t i = 0; i < n; ++i) {
-        if (!copied[i]) continue;
-        if (e == hipSuccess) e = hipStreamWaitEvent(src->stream, copied[i], 0);
-        (void)hipEventDestroy(copied[i]); // released once the recorded work has completed
-    }
-    (void)hipEventDestroy(filled);
-    if (e != hipSuccess) return hipfail(err_ctx, e, "peer copy");
-    return GAT_OK;
-}
-} // namespace
-
-GAT_API int32_t gat_memcpy_peer(gat_ctx *dst_ctx, void *dst_dev, gat_ctx *src_ctx, const void *src_dev, size_t bytes)
-{
-    if (!dst_ctx || !src_ctx || !dst_dev || !src_dev) return fail(dst_ctx, GAT_ERR_ARG, "null argument");
-    if (bytes == 0) return GAT_OK;
-    // Order, both ways: everything enqueued so far on the SOURCE stream (the upload / generator that fills src) completes
-    // before the copy, which runs on the DESTINATION stream (its correlator launches follow in stream order); and whatever
-    // the source stream is given AFTER this call (the next block's ingest overwriting src) waits for the copy to have read
-    // it -- a streaming receiver refills its ingest buffer every millisecond without a group-wide sync in between.
-    return peer_fanout(dst_ctx, src_ctx, src_dev, 1, &dst_ctx, &dst_dev, bytes);
-}
-
-GAT_API int32_t gat_group_create(int32_t num_members, const int32_t *devices, gat_group **out)
-{
-    if (!out || num_members < 1 || num_members > 64) return GAT_ERR_ARG;
-    *out = nullptr;
-    gat_group *g = new (std::nothrow) gat_group();
-    if (!g) return GAT_ERR_NOMEM;
-    for (int r = 0; r < num_members; ++r) {
-        gat_ctx *c = nullptr;
-        const int32_t rc = gat_create(devices ? devices[r] : r, GAT_OWN_STREAM, &c);
-        if (rc != GAT_OK) {
-            for (gat_ctx *x : g->ctx) (void)gat_destroy(x);
-            delete g;
-            return rc;
-        }
-        g->ctx.push_back(c);
-    }
-    // direct peer access between distinct member devices where the platform offers it (xGMI); without it
-    // hipMemcpyPeerAsync still works, staged by the runtime
-    for (gat_ctx *a : g->ctx)
-        for (gat_ctx *b : g->ctx) {
-            if (a->device == b->device) continue;
-            int can = 0;
-            if (hipDeviceCanAccessPeer(&can, a->device, b->device) == hipSuccess && can) {
-                (void)hipSetDevice(a->device);
-                const hipError_t e = hipDeviceEnablePeerAccess(b->device, 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-            }
-        }
-    (void)hipGetLastError();
-    *out = g;
-    return GAT_OK;
-}
-
-GAT_API int32_t gat_group_destroy(gat_group *g)
-{
-    if (!g) return GAT_ERR_ARG;
-    for (gat_ctx *c : g->ctx) (void)gat_destroy(c);
-    delete g;
-    return GAT_OK;
-}
-
-GAT_API int32_t gat_group_size(const gat_group *g, int32_t *num_members)
-{
-    if (!g || !num_members) return GAT_ERR_ARG;
-    *num_members = (int32_t)g->ctx.size();
-    return GAT_OK;
-}
-
-GAT_API int32_t gat_group_ctx(gat_group *g, int32_t rank, gat_ctx **ctx)
-{
-    if (!g || !ctx || rank < 0 || rank >= (int32_t)g->ctx.size()) return gfail(g, GAT_ERR_ARG, "rank outside the group");
-    *ctx = g->ctx[(size_t)rank];
-    return GAT_OK;
-}
-
-GAT_API const char *gat_group_last_error(const gat_group *g)
-{
-    if (!g) return "null group";
-    if (!g->err.empty()) return g->err.c_str();
-    for (const gat_ctx *c : g->ctx)
-        if (!c->err.empty()) return c->err.c_str();
-    return "";
-}
-
-GAT_API int32_t gat_group_shard(const gat_group *g, int32_t num_channels, int32_t rank, int32_t *first, int32_t *count)
-{
-    if (!g || !first || !count || num_channels < 0 || rank < 0 || rank >= (int32_t)g->ctx.size()) return GAT_ERR_ARG;
-    int lo, cnt;
-    shard_bounds(num_channels, (int)g->ctx.size(), rank, &lo, &cnt);
-    *first = lo;
-    *count = cnt;
-    return GAT_OK;
-}
-
-GAT_API int32_t gat_group_set_codes(gat_group *g, const int8_t *codes_host, int32_t code_length, int32_t num_prns)
-{
-    if (!g) return GAT_ERR_ARG;
-    for (gat_ctx *c : g->ctx) {
-        const int32_t rc = gat_set_codes(c, codes_host, code_length, num_prns);
-        if (rc != GAT_OK) return rc;
-    }
-    return GAT_OK;
-}
-
-GAT_API int32_t gat_group_replicate(gat_group *g, int32_t src_rank, void *const *bufs_dev, size_t bytes)
-{
-    if (!g || !bufs_dev || src_rank < 0 || src_rank >= (int32_t)g->ctx.size()) return gfail(g, GAT_ERR_ARG, "bad argument");
-    std::vector<gat_ctx *> dsts;
-    std::vector<void *> ptrs;
-    for (size_t r = 0; r < g->ctx.size(); ++r) {
-        if (!bufs_dev[r]) return gfail(g, GAT_ERR_ARG, "null buffer");
-        if ((int32_t)r == src_rank || bufs_dev[r] == bufs_dev[src_rank]) continue;
-        dsts.push_back(g->ctx[r]);
-        ptrs.push_back(bufs_dev[r]);
-    }
-    if (dsts.empty() || bytes == 0) return GAT_OK;
-    gat_ctx *src = g->ctx[(size_t)src_rank];
-    // all peers at once (one link per peer on an xGMI node), the source stream ordered behind all of them
-    return peer_fanout(src, src, bufs_dev[src_rank], dsts.size(), dsts.data(), ptrs.data(), bytes);
-}
-
-GAT_API int32_t gat_group_correlate(gat_group *g, const gat_signal_desc *signals, const gat_channel_params *params_host,
-                                    int32_t B, int32_t K, int32_t L, const int32_t *shifts, double fs,
-                                    float *const *out_re_dev, float *const *out_im_dev, uint32_t flags)
-{
-    if (!g || !signals || !params_host || !shifts || !out_re_dev || !out_im_dev) return gfail(g, GAT_ERR_ARG, "null argument");
-    if (B < 1 || K < 1) return gfail(g, GAT_ERR_ARG, "sizes must be positive");
-    const int n = (int)g->ctx.size();
-    for (int r = 0; r < n; ++r) {
-        int lo, cnt;
-        shard_bounds(K, n, r, &lo, &cnt);
-        if (cnt == 0) continue; // fewer channels than members: this one idles
-        if (!out_re_dev[r] || !out_im_dev[r]) return gfail(g, GAT_ERR_ARG, "null output buffer");
-        // this member's channels of every block, channel fastest: [cnt x B]
-        g->staging.resize((size_t)cnt * B);
-        for (int b = 0; b < B; ++b)
-            std::memcpy(&g->staging[(size_t)b * cnt], &params_host[(size_t)b * K + lo], (size_t)cnt * sizeof(gat_channel_params));
-        gat_ctx *c = g->ctx[(size_t)r];
-        // the parameter upload is asynchronous from pageable host memory: the runtime copies it out before returning,
-        // so the staging vector may be reused for the next member
-        const int32_t rc = gat_downconvert_and_correlate(c, &signals[r], g->staging.data(), B, cnt, L, shifts, fs,
-                                                         out_re_dev[r], out_im_dev[r], flags);
-        if (rc != GAT_OK) return rc;
-    }
-    return GAT_OK;
-}
-
-GAT_API int32_t gat_group_gather(gat_group *g, float *const *out_re_dev, float *const *out_im_dev, int32_t B, int32_t K,
-                                 int32_t L, int32_t M, float *host_re, float *host_im)
-{
-    if (!g || !out_re_dev || !out_im_dev || !host_re || !host_im) return gfail(g, GAT_ERR_ARG, "null argument");
-    if (B < 1 || K < 1 || L < 1 || M < 1) return gfail(g, GAT_ERR_ARG, "sizes must be positive");
-    const int n = (int)g->ctx.size();
-    const size_t lm = (size_t)L * M;
-    std::vector<float> tmp;
-    for (int r = 0; r < n; ++r) {
-        int lo, cnt;
-        shard_bounds(K, n, r, &lo, &cnt);
-        if (cnt == 0) continue;
-        tmp.resize((size_t)B * cnt * lm);
-        for (int comp = 0; comp < 2; ++comp) {
-            const float *src = comp ? out_im_dev[r] : out_re_dev[r];
-            float *dst = comp ? host_im : host_re;
-            const int32_t rc = gat_memcpy_d2h(g->ctx[(size_t)r], tmp.data(), src, tmp.size() * sizeof(float)); // synchronises
-            if (rc != GAT_OK) return rc;
-            for (int b = 0; b < B; ++b)
-                std::memcpy(dst + ((size_t)b * K + lo) * lm, tmp.data() + (size_t)b * cnt * lm, (size_t)cnt * lm * sizeof(float));
-        }
-    }
-    return GAT_OK;
-}
-
-GAT_API int32_t gat_group_sync(gat_group *g)
-{
-    if (!g) return GAT_ERR_ARG;
-    for (gat_ctx *c : g->ctx) {
-        const int32_t rc = gat_sync(c);
-        if (rc != GAT_OK) return rc;
-    }
     return GAT_OK;
 }
 

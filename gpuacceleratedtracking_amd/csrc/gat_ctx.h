@@ -1,5 +1,5 @@
-// gat_ctx.h -- what the translation units of the C-ABI layer share (gat_api.cpp: contexts, planning, operators, groups;
-// gat_resident_api.cpp: the resident correlator's host side): the context, error helpers, the planner's entry point.
+// gat_ctx.h -- what the translation units of the C-ABI layer share (gat_api.cpp: contexts, operators, loop; gat_planner.cpp: the
+// correlator call's launch planning; gat_group.cpp: device groups; gat_resident_api.cpp: the resident correlator's host side): the context, error helpers, the planner's entry point.
 #pragma once
 
 #include <cmath>
@@ -24,6 +24,7 @@ struct gat_resident {
     unsigned *d_bell = nullptr;       // device (fine-grained, host-writable through the BAR): the doorbell's copies, or null: it is in h_block
     int bell_copies = 1;
     int wgs = 0, lines_per_wg = 0, nval = 0; // working workgroups, result lines and values of each
+    int blocks_per_cu = 1;                   // workgroups of its kernel instance one compute unit holds at once
     std::vector<int> val_src, val_dst; // value pair (re, im) i of a workgroup: word of its lines holding re | tap * M + antenna of the tile it adds to
     unsigned seq = 0;                 // sequence number of the last call
     bool running = false;             // a kernel was started and has not been seen to end
@@ -73,6 +74,8 @@ struct gat_ctx {
     size_t params_cap = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timer_running = false;
+    std::vector<hipEvent_t> lap_events; // gat_timer_lap: pool, grows to the most laps ever outstanding
+    size_t laps = 0;                    // laps recorded since the last gat_timer_laps
     int num_cus = 256;
     unsigned long long *dbg_ptr = nullptr; // diagnostic builds only
     int max_ant_tile = gat::kMaxAntTile; // option max_ant_tile (gat_set_option)
@@ -120,6 +123,20 @@ inline bool code_span_ok(double ratio, double tau, double reach, int Lc)
     const double span = std::fabs(tau) + std::fabs(ratio) * reach + 1.0;
     return span < 1073741824.0 && (Lc <= 0 || span < 2097152.0 * (double)Lc) && ratio >= 0.0;
 }
+
+// Tracing ranges around the library's launch sequences (the reference wraps every launch of kernel_algorithm in
+// NVTX.@range, src/algorithms.jl:953 ...): roctxRangePush / Pop, resolved at the first use (gat_api.cpp).  RAII.
+struct TraceRange {
+    explicit TraceRange(const char *name);
+    ~TraceRange();
+    TraceRange(const TraceRange &) = delete;
+    TraceRange &operator=(const TraceRange &) = delete;
+    const void *rx;
+};
+// scratch and graph housekeeping shared by the planner, the operators and the loop (gat_api.cpp)
+void drop_loop_graphs(gat_ctx *c);
+int32_t ensure_partial(gat_ctx *c, size_t bytes);
+int32_t upload_params(gat_ctx *c, const gat_channel_params *params_host, size_t n);
 
 // What the planner hands to gat_resident_open instead of launching: the arguments and geometry of the ONE vector launch
 // that would serve the call (four-wave workgroups, one antenna tile and one channel each: the resident instances).

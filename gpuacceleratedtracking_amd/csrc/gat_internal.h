@@ -142,7 +142,9 @@ struct ResidentArgs {
 enum ResidentExit : unsigned { kResidentRuns = 0, kResidentQuit = 1, kResidentIdle = 2, kResidentLife = 3, kResidentCalls = 4 };
 bool dc_has_resident_instance(int ant_tile, int taps, int format);
 hipError_t launch_dc_resident(const DcArgs &a, const DcLaunch &cfg, const ResidentArgs &r, hipStream_t s);
-template <int FMT> hipError_t launch_dc_resident_fmt(const DcArgs &a, const DcLaunch &cfg, const ResidentArgs &r, hipStream_t s);
+// workgroups of the instance that one compute unit holds at once (occupancy API with the launch's LDS)
+hipError_t dc_resident_blocks_per_cu(const DcLaunch &cfg, int *blocks_per_cu);
+template <int FMT> hipError_t launch_dc_resident_fmt(const DcArgs &a, const DcLaunch &cfg, const ResidentArgs &r, hipStream_t s, int *blocks_per_cu);
 
 // carrier table of one segment: [steps <= kUcarSteps][samples of a lane's groups, G * S <= 8][re, im] floats per channel
 constexpr int kUcarSteps = 8;
@@ -335,6 +337,12 @@ hipError_t launch_finalize(const float *partial, float *out_re, float *out_im, i
 hipError_t launch_gen_code_replica(float *rep, long long count, const int8_t *code_row, int Lc,
                                    double fc, double fs, double tau, long long first_shift,
                                    bool f32_coordinates, hipStream_t s);
+// the texture-addressing study (gat.h gat_gen_code_replica_texaddr): fixed-point normalised coordinate / texel address
+hipError_t launch_gen_code_replica_texaddr(float *rep, long long count, const int8_t *code_row, int Lc, double fc, double fs,
+                                           double tau, long long first_shift, int coord_frac_bits, int texel_frac_bits,
+                                           hipStream_t s);
+// a kernel that only reads `bytes` (16-byte groups) of device memory (gat.h gat_debug_read_stream); sink: 4 bytes nobody reads
+hipError_t launch_read_stream(const void *dev, size_t bytes, int variant, int num_cus, float *sink, hipStream_t s);
 hipError_t launch_gen_code_replica_multi(float *rep, long long count, long long row_stride, int K,
                                          const gat_channel_params *params, const int8_t *codes, int code_row_stride,
                                          int Lc, int num_prns, double fs, long long first_shift, hipStream_t s);

@@ -186,6 +186,50 @@ code_replica_kernel(float *__restrict__ rep, long long count, const int8_t *__re
     }
 }
 
+// The texture path's addressing with the unit's FIXED-POINT steps modelled (gat.h gat_gen_code_replica_texaddr; the study of
+// paper/paper.tex:318-331): u = float32(phase / Lc) as the reference hands it to the texture fetch (src/algorithms.jl:136),
+// wrapped; the wrapped coordinate truncated to `coord_bits` fractional bits (0: kept), multiplied by Lc EXACTLY (24-bit x
+// 14-bit fits a double), the texel address rounded to nearest at `texel_bits` fractional bits (-1: kept); chip = floor.
+__global__ void __launch_bounds__(kThreads)
+code_replica_texaddr_kernel(float *__restrict__ rep, long long count, const int8_t *__restrict__ code, int Lc, double fc,
+                            double fs, double tau, long long first_shift, int coord_bits, int texel_bits)
+{
+    const double ratio = fc / fs;
+    const double cscale = __builtin_ldexp(1.0, coord_bits), tscale = __builtin_ldexp(1.0, texel_bits < 0 ? 0 : texel_bits);
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < count; i += (long long)gridDim.x * kThreads) {
+        const double p = __dadd_rn(__dmul_rn(ratio, (double)(i + first_shift)), tau);
+        const float u = (float)__ddiv_rn(p, (double)Lc);   // normalised coordinate, Float32
+        double w = (double)(u - __builtin_floorf(u));     // ADDRESS_MODE_WRAP (exact in Float32)
+        if (coord_bits > 0) w = __builtin_floor(w * cscale) / cscale; // fixed-point normalised coordinate (truncated)
+        double x = w * (double)Lc;                         // exact
+        if (texel_bits >= 0) x = __builtin_rint(x * tscale) / tscale; // fixed-point texel address (round to nearest)
+        int idx = (int)__builtin_floor(x);
+        idx = idx >= Lc ? idx - Lc : (idx < 0 ? 0 : idx);  // (an address rounded up to Lc wraps to chip 0)
+        rep[i] = (float)code[idx];
+    }
+}
+
+// A kernel that ONLY reads (gat.h gat_debug_read_stream): what the memory system gives a read-once kernel on this device.
+// Workgroup w of the grid walks 16-byte groups w * 256 + t, + grid * 256, ... -- UNROLL loads in flight per lane; the sum goes
+// nowhere unless it equals a value it cannot have (keeps the loads alive).
+template <int UNROLL, bool NT>
+__global__ void __launch_bounds__(kThreads) read_stream_kernel(const f32x4 *__restrict__ in, size_t n16, float *sink)
+{
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    for (; i + (UNROLL - 1) * stride < n16; i += UNROLL * stride) {
+        f32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = NT ? __builtin_nontemporal_load(&in[i + u * stride]) : in[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) acc += v[u];
+    }
+    for (; i < n16; i += stride) acc += in[i];
+    const float t = (acc.x + acc.y) + (acc.z + acc.w);
+    if (t == 123.456f) sink[0] = t;
+}
+
 // gen_code_replica_texture_mem_strided_nsat_kernel! (src/algorithms.jl:78-98): one replica row per satellite channel
 // (grid.y = channel), each with its own PRN, code rate and code phase; exact index arithmetic.
 __global__ void __launch_bounds__(kThreads)
@@ -441,6 +485,31 @@ hipError_t launch_gen_code_replica(float *rep, long long count, const int8_t *co
     else
         hipLaunchKernelGGL(code_replica_kernel<false>, dim3((unsigned)blocks), dim3(kThreads), 0, s, rep, count,
                            code_row, Lc, fc, fs, tau, first_shift);
+    return hipGetLastError();
+}
+
+hipError_t launch_gen_code_replica_texaddr(float *rep, long long count, const int8_t *code_row, int Lc, double fc, double fs,
+                                           double tau, long long first_shift, int coord_frac_bits, int texel_frac_bits,
+                                           hipStream_t s)
+{
+    long long blocks = (count + kThreads - 1) / kThreads;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(code_replica_texaddr_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, s, rep, count, code_row, Lc, fc,
+                       fs, tau, first_shift, coord_frac_bits, texel_frac_bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_read_stream(const void *dev, size_t bytes, int variant, int num_cus, float *sink, hipStream_t s)
+{
+    const unsigned grid = (unsigned)num_cus * (8u << (variant & 3));
+    const f32x4 *in = static_cast<const f32x4 *>(dev);
+    const size_t n16 = bytes / 16;
+    switch ((variant >> 2) & 3) {
+    case 0: hipLaunchKernelGGL((read_stream_kernel<8, true>), dim3(grid), dim3(kThreads), 0, s, in, n16, sink); break;
+    case 1: hipLaunchKernelGGL((read_stream_kernel<8, false>), dim3(grid), dim3(kThreads), 0, s, in, n16, sink); break;
+    case 2: hipLaunchKernelGGL((read_stream_kernel<4, true>), dim3(grid), dim3(kThreads), 0, s, in, n16, sink); break;
+    default: hipLaunchKernelGGL((read_stream_kernel<4, false>), dim3(grid), dim3(kThreads), 0, s, in, n16, sink); break;
+    }
     return hipGetLastError();
 }
 

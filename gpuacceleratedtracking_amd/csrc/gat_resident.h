@@ -139,11 +139,15 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
                 if (mine) v = load16();
                 const unsigned leave = (unsigned)__builtin_amdgcn_readlane((int)leave_w, 0); // (lane 0 always loads)
                 seq = (unsigned)__builtin_amdgcn_readlane((int)v.x, 0);
-                if (seq == kBellQuit || leave != 0u) { why = kResidentQuit; seq = kBellQuit; break; }
+                if (seq == kBellQuit) { why = kResidentQuit; break; }
+                // (a whole pending ring is served BEFORE the master's leave word is honoured: a workgroup that starts late --
+                // more workgroups than the device holds at once -- would otherwise see "leave" first and exit without serving,
+                // and the host would restart the same schedule until its deadline)
                 if (seq != last) {
                     if (whole(v, seq)) break;
                     seq = last; // a line caught half-written (or the host has not reached line 0's siblings yet): read again
                 }
+                if (leave != 0u) { why = kResidentQuit; seq = kBellQuit; break; }
                 const long long now = wall_clock64();
                 if (master) {
                     unsigned reason = kResidentRuns;
@@ -234,12 +238,16 @@ __global__ void __launch_bounds__(256) dc_resident_kernel(const DcArgs a, const 
     }
 }
 
+// blocks_per_cu != null: nothing is launched; *blocks_per_cu = workgroups of the instance one compute unit holds at once
+// (every workgroup of a resident kernel has to be ON the device for a call to complete: gat_resident_open sizes by it)
 template <int FMT, int MT>
-static hipError_t launch_dc_resident_m(const DcArgs &a, const DcLaunch &cfg, const ResidentArgs &r, hipStream_t s)
+static hipError_t launch_dc_resident_m(const DcArgs &a, const DcLaunch &cfg, const ResidentArgs &r, hipStream_t s, int *blocks_per_cu)
 {
     auto go = [&](auto l_c) -> hipError_t {
         constexpr int L = decltype(l_c)::value;
         if constexpr (dc_resident_instance(MT, L)) {
+            if (blocks_per_cu)
+                return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, dc_resident_kernel<MT, L, FMT>, 256, cfg.lds_bytes);
             hipLaunchKernelGGL((dc_resident_kernel<MT, L, FMT>), dim3(cfg.grid), dim3(256), cfg.lds_bytes, s, a, r);
             return hipGetLastError();
         } else {
@@ -260,14 +268,14 @@ static hipError_t launch_dc_resident_m(const DcArgs &a, const DcLaunch &cfg, con
 }
 
 template <int FMT>
-hipError_t launch_dc_resident_fmt(const DcArgs &a, const DcLaunch &cfg, const ResidentArgs &r, hipStream_t s)
+hipError_t launch_dc_resident_fmt(const DcArgs &a, const DcLaunch &cfg, const ResidentArgs &r, hipStream_t s, int *blocks_per_cu)
 {
     if (cfg.vec != 4 || cfg.aw != 1 || cfg.kt != 1 || cfg.nw != 4 || cfg.depth != 1) return hipErrorInvalidValue;
     switch (cfg.ant_tile) {
-    case 1: return launch_dc_resident_m<FMT, 1>(a, cfg, r, s);
-    case 2: return launch_dc_resident_m<FMT, 2>(a, cfg, r, s);
-    case 3: return launch_dc_resident_m<FMT, 3>(a, cfg, r, s);
-    case 4: return launch_dc_resident_m<FMT, 4>(a, cfg, r, s);
+    case 1: return launch_dc_resident_m<FMT, 1>(a, cfg, r, s, blocks_per_cu);
+    case 2: return launch_dc_resident_m<FMT, 2>(a, cfg, r, s, blocks_per_cu);
+    case 3: return launch_dc_resident_m<FMT, 3>(a, cfg, r, s, blocks_per_cu);
+    case 4: return launch_dc_resident_m<FMT, 4>(a, cfg, r, s, blocks_per_cu);
     default: return hipErrorInvalidValue;
     }
 }

@@ -67,10 +67,18 @@ static int32_t resident_start(gat_resident *res, unsigned start_seq)
     // device words: the master's "leaving" word = 0; the eight forwarded doorbells say "nothing newer than start_seq"
     std::memset(res->h_init, 0, kResDevBytes);
     for (int c8 = 0; c8 < 8; ++c8) res->h_init[16 + c8 * (kResMaxChannels * kBellDwords)] = start_seq;
-    GAT_HIP(c, hipMemcpyAsync(res->d_quit, res->h_init, kResDevBytes, hipMemcpyHostToDevice, res->stream));
     res->r.start_seq = start_seq;
     res->a.codes = c->d_codes;
-    GAT_HIP(c, launch_dc_resident(res->a, res->cfg, res->r, res->stream));
+    hipError_t e = hipMemcpyAsync(res->d_quit, res->h_init, kResDevBytes, hipMemcpyHostToDevice, res->stream);
+    if (e == hipSuccess) e = launch_dc_resident(res->a, res->cfg, res->r, res->stream);
+    if (e != hipSuccess) {
+        // no kernel is on the device: the state must not read "runs" (the next call would skip the restart and spin until its
+        // deadline), and nothing is `running`
+        __atomic_store_n(&res->h_state[0], (unsigned)kResidentQuit, __ATOMIC_RELEASE);
+        res->last_exit = kResidentQuit;
+        res->running = false;
+        return hipfail(c, e, "resident correlator: kernel start");
+    }
     res->running = true;
     ++res->launches;
     return GAT_OK;
@@ -168,8 +176,24 @@ GAT_API int32_t gat_resident_open(gat_ctx *c, const gat_signal_desc *sig, int32_
     if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && khz > 0) res->ticks_per_us = std::max(1, khz / 1000);
     (void)hipGetLastError();
 
-    // pinned host block: doorbell | state | result lines of every workgroup
+    // Every workgroup has to be ON the device for a call to complete (a surplus workgroup starts only when a resident one has
+    // left, i.e. never while the kernel serves calls): this correlator's workgroups and those of the context's other open
+    // ones, each counted in compute units at what one unit holds of its instance (occupancy API with the launch's LDS; the
+    // API may answer one block too many near scalar-register limits -- MI355X_MICROARCH.md, Residency --, so one is taken off
+    // every answer above one), may not exceed the device's.
     res->wgs = (int)plan.a.total_wgs;
+    {
+        int occ = 0;
+        hipError_t oe = dc_resident_blocks_per_cu(plan.cfg, &occ);
+        if (oe != hipSuccess) return bail(hipfail(c, oe, "hipOccupancyMaxActiveBlocksPerMultiprocessor"));
+        if (occ < 1) return bail(fail(c, GAT_ERR_UNSUPPORTED, "resident correlator: the kernel instance does not fit a compute unit with this LDS size"));
+        res->blocks_per_cu = occ > 1 ? occ - 1 : 1;
+        long long cus = (res->wgs + res->blocks_per_cu - 1) / res->blocks_per_cu;
+        for (const gat_resident *o : c->residents) cus += (o->wgs + o->blocks_per_cu - 1) / o->blocks_per_cu;
+        if (cus > c->num_cus)
+            return bail(fail(c, GAT_ERR_UNSUPPORTED, "resident correlator: more workgroups than the device holds at once (with the context's other open resident correlators): lower max_workgroups, the channel count or close one"));
+    }
+    // pinned host block: doorbell | state | result lines of every workgroup
     res->nval = 2 * plan.cfg.ant_tile * plan.cfg.taps;
     res->lines_per_wg = (res->nval + kResLinePayload - 1) / kResLinePayload;
     for (int o = 0; o < res->nval; ++o) { // where the host's second stage finds a workgroup's values and where they go
@@ -378,6 +402,21 @@ GAT_API int32_t gat_resident_park(gat_resident *res)
     if (!res) return GAT_ERR_ARG;
     (void)hipSetDevice(res->ctx->device);
     return resident_park(res);
+}
+
+GAT_API int32_t gat_resident_park_all(gat_ctx *c)
+{
+    if (!c) return GAT_ERR_ARG;
+    GAT_HIP(c, hipSetDevice(c->device));
+    int32_t rc = GAT_OK;
+    // ring "quit" into every running kernel first, then wait for them one by one: the waits overlap
+    for (gat_resident *r : c->residents)
+        if (r->running && __atomic_load_n(&r->h_state[0], __ATOMIC_ACQUIRE) == kResidentRuns) bell_set_seq(r, kBellQuit);
+    for (gat_resident *r : c->residents) {
+        const int32_t one = resident_park(r);
+        if (rc == GAT_OK) rc = one;
+    }
+    return rc;
 }
 
 GAT_API int32_t gat_resident_close(gat_resident *res)

@@ -147,8 +147,9 @@ class ResidentTrackingLoop:
         self._state = dev_loop.state().copy()
         self._signal = (re, im)  # kept alive: the resident kernel reads it
         desc = _signal_desc(re, im, self.N, start=0)
+        self._samples = int(re.shape[-2] if im is None else re.shape[-1])  # per antenna: every block has to end inside
         torch.cuda.current_stream(self.ctx.device).synchronize()  # the signal is on the device before the first ring
-        self.resident = self.ctx.open_resident(desc, self.K, self.shifts, self.fs, **resident_config)
+        self.resident = self.ctx.open_resident(desc, self.K, self.shifts, self.fs, buffer_samples=self._samples, **resident_config)
         self.resident_workgroups = self.resident.info()["workgroups"]
         self._lib = self.ctx.lib
         self._fn = self._lib.gat_tracking_update_host
@@ -178,6 +179,9 @@ class ResidentTrackingLoop:
         re = np.empty((nb if keep_all else 1, self.K, self.L, self.M), np.float32)
         im = np.empty_like(re)
         stride = self.N if block_stride is None else int(block_stride)
+        # (the resident kernel reads the blocks with system-scope loads: a block outside the allocation is a GPU page fault)
+        if start < 0 or stride < 0 or int(start) + (nb - 1) * stride + self.N > self._samples:
+            raise ValueError("signal shorter than start + (num_blocks - 1) * block_stride + num_samples")
         rc = self._lib.gat_resident_tracking_run(self.resident._h, nb, int(start), stride, C.byref(self.config), C.c_void_p(self._state.ctypes.data),
                                                  C.c_void_p(self._cur.ctypes.data), C.c_void_p(re.ctypes.data), C.c_void_p(im.ctypes.data), n if keep_all else 0)
         self.ctx.check(rc, "gat_resident_tracking_run")

@@ -104,21 +104,23 @@ def downconvert_and_correlate(system: GNSSSystem, signal: StructSignal, correlat
 def gen_code_replica(code_replica: torch.Tensor, system: GNSSSystem, code_frequency: float,
                      sampling_frequency: float, start_code_phase: float, start_sample: int,
                      num_samples: int, correlator_sample_shifts, prn: int,
-                     texture_coordinates: bool = False) -> torch.Tensor:
+                     texture_coordinates: bool = False, texture_addressing=None) -> torch.Tensor:
     """Mirror of ``Tracking.gen_code_replica!`` (scripts/code_replica_experiment.jl:70) ==
     ``gen_code_replica_kernel!`` with ``latest_shift = shifts[1]`` in the 0-based convention of
     kernel 5431 (src/algorithms.jl:752-758): fills
     ``code_replica[start_sample-1 : start_sample-1 + num_samples + (shifts[-1]-shifts[0])]`` with
     ``c[floor(fc/fs*(i + shifts[0]) + phase) mod Lc]``.  ``texture_coordinates=True`` addresses the
     table through a Float32 normalised coordinate like ``gen_code_replica_texture_mem_kernel!``
-    (src/algorithms.jl:121-140) -- for the code-phase-error study only."""
+    (src/algorithms.jl:121-140) -- for the code-phase-error study only; ``texture_addressing=(coord_frac_bits,
+    texel_frac_bits)`` adds the fixed-point model of the texture unit's addressing (include/gat.h
+    gat_gen_code_replica_texaddr)."""
     ctx = get_context(code_replica.device)
     ctx.set_codes(system.codes)
     shifts = np.asarray(correlator_sample_shifts, dtype=np.int64)
     count = int(num_samples + shifts[-1] - shifts[0])
     view = code_replica[start_sample - 1:]
     ctx.gen_code_replica(view, count, prn - 1, code_frequency, sampling_frequency, start_code_phase,
-                         int(shifts[0]), f32_coordinates=texture_coordinates)
+                         int(shifts[0]), f32_coordinates=texture_coordinates, texture_addressing=texture_addressing)
     return code_replica
 
 

@@ -193,6 +193,21 @@ GAT_API int32_t gat_gen_code_replica_f32coord(gat_ctx *ctx, float *replica_dev, 
                                               double sampling_freq_hz, double code_phase_chips,
                                               int64_t first_shift);
 
+/* The same study with the texture unit's FIXED-POINT addressing modelled (paper/paper.tex:322-331 reports min 0 / mean
+ * 0.03 / median 0.02 / max 3.17 % relative code-phase error; Float32 rounding of the coordinate alone gives 1/16 of the
+ * mean and 1/25 of the maximum).  From the Float32 normalised coordinate u = float32(phase / code_length), wrapped to
+ * w = u - floor(u):
+ *   coord_frac_bits > 0 : w is TRUNCATED to that many fractional bits (the unit's fixed-point normalised coordinate);
+ *   x = w * code_length, exact (no Float32 rounding of the product);
+ *   texel_frac_bits >= 0: x is ROUNDED to nearest at that many fractional bits (a fixed-point texel address; 8 = the
+ *                         sub-texel precision CUDA documents for its filter weights); -1: left as it is;
+ *   chip = floor(x).
+ * (0, -1) is Float32 rounding of the coordinate alone with an exact product.  Study use only
+ * (scripts/code_replica_experiment.py runs the reference's sweep over these modes). */
+GAT_API int32_t gat_gen_code_replica_texaddr(gat_ctx *ctx, float *replica_dev, int64_t count, int32_t prn,
+                                             double code_freq_hz, double sampling_freq_hz, double code_phase_chips,
+                                             int64_t first_shift, int32_t coord_frac_bits, int32_t texel_frac_bits);
+
 /* gen_code_replica_texture_mem_strided_nsat_kernel! (src/algorithms.jl:78-98): the replicas of num_channels
  * satellite channels in ONE call -- row k (row_stride floats apart) = channel k with its own prn, code_freq_hz and
  * code_phase_chips (params_dev[k]; the carrier fields are ignored); rep[k][i] = c_k[floor(fc_k/fs*(i + first_shift)
@@ -322,6 +337,23 @@ GAT_API int32_t gat_memset(gat_ctx *ctx, void *dst_dev, int32_t value, size_t by
  * src/benchmarks.jl:120; CUDA.@elapsed in test/algorithms.jl:1242).  stop() synchronises. */
 GAT_API int32_t gat_timer_start(gat_ctx *ctx);
 GAT_API int32_t gat_timer_stop(gat_ctx *ctx, float *elapsed_ms);
+/* Per-call statistics as the reference's harness keeps them (BenchmarkTools stores every sample's time: Minimum / Median /
+ * Mean / sigma / Maximum + RawTimes, src/benchmarks.jl:1-9): gat_timer_lap records ONE event on the ctx stream -- call it
+ * before the first timed launch and after every launch --; gat_timer_laps waits for the newest lap and returns the
+ * intervals between consecutive laps in milliseconds (laps - 1 of them, at most `capacity`), then forgets the laps.  The
+ * events come from a pool the context owns (it grows to the largest number of laps ever outstanding). */
+GAT_API int32_t gat_timer_lap(gat_ctx *ctx);
+GAT_API int32_t gat_timer_laps(gat_ctx *ctx, float *intervals_ms, int32_t capacity, int32_t *num_intervals);
+
+/* Measurement aid ("also report vs the measured read ceiling"): a kernel that ONLY reads -- every lane
+ * one 16-byte load per step over `bytes` of device memory (a multiple of 16), summed into a value nobody stores -- launched
+ * `launches` times on the ctx stream, each launch timed by its own event pair (ms_each_host[launches]).  `variant` picks
+ * the reader: bits 0-1 workgroups per CU (0: 8, 1: 16, 2: 32, 3: 64), bit 2 plain instead of non-temporal loads, bit 3
+ * four instead of eight loads in flight per lane.  What the best variant reaches over the correlator's own stream is the
+ * memory system's ceiling for a read-once kernel on this device, in this process, at this moment (bench.py:
+ * roofline.read_ceiling_GBps; tests: the box-tolerant performance guard).  Not part of the reference's surface. */
+GAT_API int32_t gat_debug_read_stream(gat_ctx *ctx, const void *dev, size_t bytes, int32_t variant, int32_t launches,
+                                      float *ms_each_host);
 
 /* Kernel selection.  By default (GAT_MC_AUTO) the library runs the split-bf16 matrix-core kernel (gat_mfma_bf16.hip:
  * both operands as hi+mid+lo bf16 terms, f32-equivalent accuracy; every sample format) where it measured faster than
@@ -437,6 +469,10 @@ GAT_API int32_t gat_resident_tracking_run(gat_resident *resident, int32_t num_bl
 GAT_API int32_t gat_resident_info_get(const gat_resident *resident, gat_resident_info *out, size_t struct_size);
 /* asks the kernel to leave and waits until it has (bounded by the kernel's own limits); the next call starts it again */
 GAT_API int32_t gat_resident_park(gat_resident *resident);
+/* the same for every resident correlator of the context: call it before anything that waits for the WHOLE device
+ * (hipDeviceSynchronize, torch.cuda.synchronize(), hipFree of a foreign allocation) -- such a call otherwise sits out the
+ * resident kernels' idle limit (5 ms by default).  gat_free, gat_set_codes and gat_destroy do it themselves. */
+GAT_API int32_t gat_resident_park_all(gat_ctx *ctx);
 /* (a correlator that is still open when its context is destroyed is closed by gat_destroy: its handle dies with the context) */
 GAT_API int32_t gat_resident_close(gat_resident *resident);
 

@@ -232,6 +232,23 @@ function timer_stop(ctx::Context)                   # synchronises; milliseconds
     Float64(ms[])
 end
 
+# per-call statistics (BenchmarkTools keeps every sample's time, src/benchmarks.jl:1-9): one lap before the first timed launch and
+# one after every launch; `timer_laps` waits for the newest and returns the intervals in milliseconds
+timer_lap(ctx::Context) = check(ctx, ccall((:gat_timer_lap, libgat), Int32, (Ptr{Cvoid},), ctx.handle))
+function timer_laps(ctx::Context, capacity::Integer = 65536)
+    ms = Vector{Cfloat}(undef, capacity)
+    n = Ref{Int32}(0)
+    check(ctx, ccall((:gat_timer_laps, libgat), Int32, (Ptr{Cvoid}, Ptr{Cfloat}, Int32, Ref{Int32}), ctx.handle, ms, Int32(capacity), n))
+    Float64.(ms[1:n[]])
+end
+# a kernel that only reads `bytes` of device memory, `launches` times: milliseconds per launch (the in-run read ceiling)
+function debug_read_stream(ctx::Context, dev::Ptr{Cvoid}, bytes::Integer, variant::Integer = 0, launches::Integer = 8)
+    ms = Vector{Cfloat}(undef, launches)
+    check(ctx, ccall((:gat_debug_read_stream, libgat), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Int32, Int32, Ptr{Cfloat}),
+                     ctx.handle, dev, Csize_t(bytes), Int32(variant), Int32(launches), ms))
+    Float64.(ms)
+end
+
 # ---- device memory (for hosts without AMDGPU.jl; with AMDGPU.jl pass ROCArray pointers instead)
 function dmalloc(ctx::Context, bytes::Integer)
     p = Ref{Ptr{Cvoid}}(C_NULL)
@@ -589,6 +606,8 @@ function info(r::Resident)
     i[]
 end
 park!(r::Resident) = check(r.ctx, ccall((:gat_resident_park, libgat), Int32, (Ptr{Cvoid},), r.handle))
+# every resident correlator of the context: before anything that waits for the whole device (AMDGPU.synchronize(), hipFree)
+park_residents!(ctx::Context) = check(ctx, ccall((:gat_resident_park_all, libgat), Int32, (Ptr{Cvoid},), ctx.handle))
 # the receiver loop with the host in it, from native code: num_blocks blocks (block b at first_block_offset + b * block_stride
 # samples of the buffer) through {resident call, gat_tracking_update_host}; r.prm: in the first block's records, out the next
 # ones; acc_re / acc_im: host arrays of at least max(1, acc_block_stride > 0 ? num_blocks : 1) * M * L * K floats
@@ -627,6 +646,17 @@ function gen_code_replica_f32coord!(ctx::Context, code_replica_dev::Ptr{Cfloat},
                      (Ptr{Cvoid}, Ptr{Cfloat}, Int64, Int32, Float64, Float64, Float64, Int64),
                      ctx.handle, code_replica_dev, Int64(count), Int32(prn - 1), code_frequency_hz, sampling_frequency_hz,
                      start_code_phase, Int64(first_shift)))
+end
+
+# the same study with the texture unit's fixed-point addressing modelled (include/gat.h gat_gen_code_replica_texaddr):
+# coord_frac_bits > 0 truncates the wrapped normalised coordinate, texel_frac_bits >= 0 rounds the texel address
+function gen_code_replica_texaddr!(ctx::Context, code_replica_dev::Ptr{Cfloat}, count::Integer, prn::Integer,
+                                   code_frequency_hz::Float64, sampling_frequency_hz::Float64, start_code_phase::Float64,
+                                   first_shift::Integer, coord_frac_bits::Integer, texel_frac_bits::Integer)
+    check(ctx, ccall((:gat_gen_code_replica_texaddr, libgat), Int32,
+                     (Ptr{Cvoid}, Ptr{Cfloat}, Int64, Int32, Float64, Float64, Float64, Int64, Int32, Int32),
+                     ctx.handle, code_replica_dev, Int64(count), Int32(prn - 1), code_frequency_hz, sampling_frequency_hz,
+                     start_code_phase, Int64(first_shift), Int32(coord_frac_bits), Int32(texel_frac_bits)))
 end
 
 end # module

@@ -94,7 +94,7 @@ end
 # DataFrame columns from them) plus "HIP" (runtime version) and "libgat" (library version, git commit and build flags of
 # the kernels that were timed; the script's @tagsave adds the harness's own commit, scripts/run_benchmarks_gpsl1.jl:24-27).
 function add_metadata!(benchmark_results_w_params, processor, algorithm::KernelAlgorithm{9000})
-    os_name = @static Sys.iswindows() ? "windows" : (@static Sys.isapple() ? "macos" : @static Sys.islinux() ? "linux" : @static Sys.isunix() ? "generic_unix" : throw("Can't determine OS name"))
+    os_name = lowercase(string(Sys.KERNEL))                  # "linux" on every host libgat runs on (the "os" column)
     cpu_name = Sys.cpu_info()[1].model
     gpu_name, hip_version, _ = GATHip.device_info(0)          # gat_device_info: "AMD Instinct MI355X (gfx950...)", "7.2.x"
     benchmark_results_w_params["os"] = os_name

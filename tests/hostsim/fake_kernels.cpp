@@ -171,6 +171,18 @@ hipError_t launch_mfma_bf16(const MfArgs &a, int rt, int nct, int fmt, unsigned 
 }
 
 hipError_t launch_gen_code_replica(float *, long long, const int8_t *, int, double, double, double, long long, bool, hipStream_t) { ++counters.other_launches; return hipSuccess; }
+hipError_t launch_gen_code_replica_texaddr(float *, long long, const int8_t *, int, double, double, double, long long, int coord_bits, int texel_bits, hipStream_t)
+{
+    ++counters.other_launches;
+    REQUIRE(coord_bits >= 0 && coord_bits <= 32 && texel_bits >= -1 && texel_bits <= 24, "texture addressing study: %d / %d bits", coord_bits, texel_bits);
+    return hipSuccess;
+}
+hipError_t launch_read_stream(const void *dev, size_t bytes, int variant, int num_cus, float *sink, hipStream_t)
+{
+    ++counters.other_launches;
+    REQUIRE(dev && sink && bytes >= 16 && bytes % 16 == 0 && variant >= 0 && variant < 16 && num_cus > 0, "read stream: %zu bytes, variant %d", bytes, variant);
+    return hipSuccess;
+}
 hipError_t launch_gen_code_replica_multi(float *, long long, long long, int, const gat_channel_params *, const int8_t *, int, int, int, double, long long, hipStream_t) { ++counters.other_launches; return hipSuccess; }
 hipError_t launch_accumulate_debug(const float *, const float *, long long, int, long long, const gat_channel_params &, const int8_t *, int, double, int, const int *, float *, float *, float *, float *, float *, float *, hipStream_t) { ++counters.other_launches; return hipSuccess; }
 hipError_t launch_gen_signal(void *, void *, int, long long, int, long long, long long, int, int, const gat_channel_params *, const int8_t *, int, int, int, double, float, const float *, float, unsigned long long, hipStream_t) { ++counters.other_launches; return hipSuccess; }
@@ -252,6 +264,15 @@ static void resident_device(DcArgs a, DcLaunch cfg, ResidentArgs r)
     }
     r.host_state[1] = calls;
     __atomic_store_n(r.host_state, why, __ATOMIC_RELEASE);
+}
+
+// what one "compute unit" of the simulated device holds of a resident instance: two workgroups by the occupancy API's word
+// (the library takes one off every answer above one)
+hipError_t dc_resident_blocks_per_cu(const DcLaunch &cfg, int *blocks_per_cu)
+{
+    REQUIRE(blocks_per_cu != nullptr && dc_has_resident_instance(cfg.ant_tile, cfg.taps, cfg.format), "resident occupancy query: instance");
+    *blocks_per_cu = 2;
+    return hipSuccess;
 }
 
 hipError_t launch_dc_resident(const DcArgs &a, const DcLaunch &cfg, const ResidentArgs &r, hipStream_t s)

@@ -193,6 +193,21 @@ int main(int argc, char **argv)
         EXPECT(gat_reduce_cplx_multi(ctx, (float *)are, (float *)aim, 1000, 6, (float *)are, (float *)aim) == GAT_OK, "reduction");
         float ms = -1.f;
         EXPECT(gat_timer_start(ctx) == GAT_OK && gat_timer_stop(ctx, &ms) == GAT_OK && ms >= 0.f, "timer");
+        {
+            const int laps = (int)uni(0, 40);
+            float iv[64];
+            int32_t got = -1;
+            for (int i = 0; i < laps; ++i) EXPECT(gat_timer_lap(ctx) == GAT_OK, "lap");
+            const int32_t cap = (int32_t)uni(0, 64);
+            EXPECT(gat_timer_laps(ctx, iv, cap, &got) == GAT_OK && got == std::min(std::max(laps - 1, 0), (int)cap), "laps: %d intervals of %d laps (capacity %d)", got, laps, cap);
+            for (int i = 0; i < got; ++i) EXPECT(iv[i] >= 0.f, "lap interval");
+            EXPECT(gat_timer_laps(ctx, iv, 64, &got) == GAT_OK && got == 0, "laps are forgotten once read");
+            float each[3] = {-1.f, -1.f, -1.f};
+            EXPECT(gat_debug_read_stream(ctx, rep, sizeof(float) * (N + 2) * 2 / 16 * 16, (int32_t)uni(0, 15), 3, each) == GAT_OK && each[2] >= 0.f, "read stream");
+            EXPECT(gat_debug_read_stream(ctx, rep, 24, 0, 1, each) == GAT_ERR_ARG && gat_debug_read_stream(ctx, rep, 64, 16, 1, each) == GAT_ERR_RANGE, "read stream: refusals");
+            EXPECT(gat_gen_code_replica_texaddr(ctx, (float *)rep, N + 2, 3, fc, N / 1e-3, 5.5, -1, (int32_t)uni(0, 32), (int32_t)uni(-1, 24)) == GAT_OK, "texture addressing study");
+            EXPECT(gat_gen_code_replica_texaddr(ctx, (float *)rep, N + 2, 3, fc, N / 1e-3, 5.5, -1, 33, 8) == GAT_ERR_RANGE, "texture addressing study: bits");
+        }
         char name[64];
         int32_t ver = 0, cus = 0;
         EXPECT(gat_device_info(ctx, name, sizeof name, &ver, &cus) == GAT_OK && cus == 256, "device info");
@@ -236,7 +251,10 @@ int main(int argc, char **argv)
     }
 
     // ---- 3. the resident correlator against an emulated device -------------------------------------------------------------
-    long res_calls = 0, res_opened = 0, res_refused = 0;
+    long res_calls = 0, res_opened = 0, res_refused = 0, res_capacity_refused = 0;
+    long open_cus = 0; // workgroups of the correlators left open on ctx (the simulated device holds one resident workgroup per unit)
+    gat_ctx *probe_ctx = nullptr; // a context without open correlators: tells how many workgroups a refused geometry has
+    EXPECT(gat_create(0, GAT_OWN_STREAM, &probe_ctx) == GAT_OK && gat_set_codes(probe_ctx, codes.data(), lc, 32) == GAT_OK, "probe context");
     for (int it = 0; it < 60; ++it) {
         const int fmt = (int)uni(0, 3), M = (int)pick<long long>({1, 2, 3, 4, 8, 16}), K = (int)pick<long long>({1, 1, 2, 3, 4, 5, 9, 12, 16, 17}), L = (int)pick<long long>({1, 3, 5, 7, 8, 9});
         long long N = pick<long long>({2048, 2500, 4096, 16384, 20000, 65536, 262144, uni(100, 100000)});
@@ -250,10 +268,23 @@ int main(int argc, char **argv)
         gat_resident_config cfg = {sizeof cfg, (uint32_t)pick<long long>({150, 400, 100000}), (uint32_t)pick<long long>({5, 50, 2000}), (uint32_t)pick<long long>({0, 5, 17}),
                                    (uint32_t)pick<long long>({0, 1, 8, 200}), (uint32_t)pick<long long>({0, 1, 64}), (uint32_t)pick<long long>({0, 1, 2})};
         gat_resident *res = nullptr;
-        const int32_t rc = gat_resident_open(ctx, &sig, K, L, sh.data(), N / 1e-3, uni(0, 4) ? &cfg : nullptr, &res);
+        const gat_resident_config *const cfgp = uni(0, 4) ? &cfg : nullptr;
+        const int32_t rc = gat_resident_open(ctx, &sig, K, L, sh.data(), N / 1e-3, cfgp, &res);
         std::vector<int32_t> sorted(sh);
         std::sort(sorted.begin(), sorted.end());
         const bool servable = K <= 16 && L <= 8 && sorted.back() - sorted.front() <= 2048 && N % kSpv[fmt] == 0 && mis == 0;
+        if (rc == GAT_ERR_UNSUPPORTED && servable) {
+            // refused for want of room: the same geometry opens on a context without open correlators, and its workgroups
+            // together with those left open here are more than the device's 256 units hold
+            gat_resident *probe = nullptr;
+            gat_resident_info pi{};
+            const int32_t prc = gat_resident_open(probe_ctx, &sig, K, L, sh.data(), N / 1e-3, cfgp, &probe);
+            EXPECT(prc == GAT_OK && gat_resident_info_get(probe, &pi, sizeof pi) == GAT_OK, "capacity refusal: the geometry itself is servable (%d, %s)", prc, gat_last_error(probe_ctx));
+            EXPECT(open_cus + pi.workgroups > 256, "refused %d workgroups beside %ld left open: room for 256", pi.workgroups, open_cus);
+            if (probe) EXPECT(gat_resident_close(probe) == GAT_OK, "close probe");
+            ++res_capacity_refused;
+            continue;
+        }
         EXPECT((rc == GAT_OK) == servable, "resident open: rc %d for fmt %d M %d K %d L %d N %lld span %d mis %d (%s)", rc, fmt, M, K, L, N, sorted.back() - sorted.front(),
                (int)mis, gat_last_error(ctx));
         if (rc != GAT_OK) {
@@ -329,10 +360,26 @@ int main(int argc, char **argv)
             EXPECT(gat_set_codes(ctx, codes.data(), lc, 32) == GAT_OK, "rebind");
             EXPECT(gat_resident_correlate(res, prm.data(), 0, r_re.data(), r_im.data()) == GAT_ERR_STATE, "stale correlator");
         }
+        EXPECT(open_cus + info.workgroups <= 256, "resident open accepted %d workgroups beside %ld left open", info.workgroups, open_cus);
         if (it % 7 != 3) EXPECT(gat_resident_close(res) == GAT_OK, "close"); // (the others die with the context)
+        else open_cus += info.workgroups;
     }
-    std::printf("resident correlator: %ld opened, %ld refused as unsupported, %ld calls answered; the emulated kernel was started %ld times and served %ld rings\n",
-                res_opened, res_refused, res_calls, hostsim::counters.resident_starts.load(), hostsim::counters.resident_calls.load());
+    { // room on the device: every workgroup of every open correlator has to be resident at once
+        const long long N = 262144;
+        const int32_t sh3[3] = {-10, 0, 10};
+        gat_signal_desc sig = {(void *)(uintptr_t)0x10000000, (void *)(uintptr_t)0x50000000, 0, 4, N, N * 4, N, 0};
+        gat_resident_config cfg = {sizeof cfg, 100000, 2000, 0, 200, 0, 0};
+        gat_resident *a = nullptr, *b = nullptr;
+        gat_resident_info ia{};
+        EXPECT(gat_resident_open(probe_ctx, &sig, 1, 3, sh3, N / 1e-3, &cfg, &a) == GAT_OK && gat_resident_info_get(a, &ia, sizeof ia) == GAT_OK && ia.workgroups > 128,
+               "a correlator of > 128 workgroups (%d)", ia.workgroups);
+        EXPECT(gat_resident_open(probe_ctx, &sig, 1, 3, sh3, N / 1e-3, &cfg, &b) == GAT_ERR_UNSUPPORTED && b == nullptr, "a second one beside it must be refused");
+        EXPECT(gat_resident_park_all(probe_ctx) == GAT_OK && gat_resident_info_get(a, &ia, sizeof ia) == GAT_OK && ia.running == 0, "park_all");
+        EXPECT(gat_resident_close(a) == GAT_OK && gat_resident_open(probe_ctx, &sig, 1, 3, sh3, N / 1e-3, &cfg, &b) == GAT_OK, "room again once the first is closed");
+        EXPECT(gat_destroy(probe_ctx) == GAT_OK, "destroy probe context (one correlator still open)");
+    }
+    std::printf("resident correlator: %ld opened, %ld refused as unsupported (+ %ld for want of room), %ld calls answered; the emulated kernel was started %ld times and served %ld rings\n",
+                res_opened, res_refused, res_capacity_refused, res_calls, hostsim::counters.resident_starts.load(), hostsim::counters.resident_calls.load());
     EXPECT(res_opened > 10 && res_refused > 3 && hostsim::counters.resident_starts > res_opened, "the resident sweep restarted kernels");
     EXPECT(gat_destroy(ctx) == GAT_OK, "destroy");
     EXPECT(hostsim::counters.violations == 0, "%ld planner invariants broken", hostsim::counters.violations.load());

@@ -65,6 +65,28 @@ def test_group_check_failure_is_recorded_not_fatal():
     assert p.returncode == 0 and "group_check" not in _one_line(p.stdout)
 
 
+@pytest.mark.parametrize("n, want", [(2, [16, 16]), (3, [11, 11, 10])])
+def test_strong_scaling_plan_of_the_constellation_leg(n, want):
+    """`constellation_config3`: BASELINE configs[3]'s 32 PRNs cut by ShardPlan(32, N, rank) -- every rank computes its own
+    slice as measure() does; contiguous, disjoint, complete (32 / 16 / 8 / 4 per GPU at N = 1 / 2 / 4 / 8)."""
+    p = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--steps", "2", "--warmup", "1", "--no-group-check"],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    leg = _one_line(p.stdout)["constellation_config3"]
+    assert leg["scaling"] == "strong" and leg["prns_total"] == 32 and leg["prns_by_rank"] == want
+    firsts = leg["first_prn_by_rank"]
+    assert firsts[0] == 0 and all(firsts[r + 1] == firsts[r] + want[r] for r in range(n - 1)) and firsts[-1] + want[-1] == 32
+    sys.path.insert(0, ROOT)
+    from gpuacceleratedtracking_amd.sharding import ShardPlan
+    assert [ShardPlan(32, 8, r).count for r in range(8)] == [4] * 8 and ShardPlan(32, 1, 0).count == 32
+
+
+def test_constellation_leg_runs_the_headline_protocol():
+    src = open(BENCH).read()
+    assert "measure(args, g, torch, dist, world, rank, kwc, args.steps, args.warmup, args.settle, False)" in src
+    assert 'channels_total=CONSTELLATION_PRNS' in src and '"scaling": "strong"' in src
+
+
 def test_shard_leg_runs_the_headline_protocol():
     """N > 1: the configs[3] shard is measured with the same settle / warm-up / steps as the headline (a shortened
     protocol reads the device while it leaves idle: 0.70 instead of 0.58 ms per launch)."""

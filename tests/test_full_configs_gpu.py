@@ -45,6 +45,7 @@ CONFIGS = {
     "C2": ("GPSL1", 20000, 4, 3, 1, 4096, 1.0),     # the bench workload, full batch
     "C3": ("GPSL5", 50000, 4, 5, 12, 8, 1.0),
     "C4": ("GPSL1", 50000, 16, 3, 4, 8, 1.0),       # per-GPU shard of config 4 (4 of 32 PRNs)
+    "C4x32": ("GPSL1", 50000, 16, 3, 32, 8, 1.0),   # the whole constellation on ONE GPU (bench.py constellation_config3 at N = 1)
 }
 
 
