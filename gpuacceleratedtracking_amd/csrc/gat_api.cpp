@@ -219,6 +219,10 @@ constexpr OptionDesc kOptions[] = {
     {"dc_ow_seg", 1, kUcarSteps},    // steps per replica segment of a one-wave workgroup
     {"dc_depth", 1, 2},              // cap of the sample prefetch depth (register sets per wave)
     {"dc_keep_l2", -1, 1},           // sample loads: -1 by rule (plain when channel groups share a tile through L2), 0 non-temporal, 1 plain
+    {"dc_quads", -1, 1},             // replica fill four entries at a time: -1 by rule (the two-channel 2 x 2 tile), 0 never, 1 wherever the code rate allows
+    {"dc_bits", 0, 2},               // chip tables in LDS as sign bits: 0 never, 1 long codes (> 2 KB per PRN), 2 whenever every chip is +-1
+    {"dc_aw2", -1, 1},               // the two-channel 2 x 2 tile (two waves of two antennas, two channels each): -1 by rule, 0 never, 1 wherever an instance exists
+    {"dc_seg", 0, kUcarSteps},       // cap of the steps per replica segment of a four-wave workgroup (0: by instance)
     {"dc_align", 0, 1},              // blocks walked from the 128-byte line their first sample lies in (1) or from the sample itself (0)
 };
 
@@ -242,6 +246,10 @@ int32_t set_option(gat_ctx *c, const char *name, long long v)
     else if (n == "dc_ow_seg") c->one_wave_seg = (int)v;
     else if (n == "dc_depth") c->max_depth = (int)v;
     else if (n == "dc_keep_l2") c->keep_l2 = (int)v;
+    else if (n == "dc_quads") c->quads = (int)v;
+    else if (n == "dc_bits") c->bit_tables = (int)v;
+    else if (n == "dc_aw2") c->aw2 = (int)v;
+    else if (n == "dc_seg") c->seg_cap = (int)v;
     else if (n == "dc_align") c->align_head = (int)v;
     return GAT_OK;
 }
@@ -412,12 +420,19 @@ GAT_API int32_t gat_set_codes(gat_ctx *c, const int8_t *codes_host, int32_t code
         GAT_HIP(c, hipFree(c->d_code_bits));
         c->d_code_bits = nullptr;
     }
-    const int stride = (code_length + 15) & ~15; // 16-byte rows: dc_kernel stages them with 16-byte copies
+    // 16-byte rows (dc_kernel stages them with 16-byte copies) with room for one more chip: every row carries its FIRST chip
+    // again at index code_length, so that "this chip and the next" are two reads without a wrap (the replica fill by quads)
+    const int stride = (code_length + 16) & ~15;
     const size_t bytes = (size_t)stride * num_prns;
-    GAT_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->d_codes), bytes));
-    GAT_HIP(c, hipMemset(c->d_codes, 0, bytes));
-    GAT_HIP(c, hipMemcpy2D(c->d_codes, (size_t)stride, codes_host, (size_t)code_length, (size_t)code_length,
-                           (size_t)num_prns, hipMemcpyHostToDevice));
+    {
+        std::vector<int8_t> rows(bytes, 0);
+        for (int p = 0; p < num_prns; ++p) {
+            std::memcpy(&rows[(size_t)p * stride], codes_host + (size_t)p * code_length, (size_t)code_length);
+            rows[(size_t)p * stride + code_length] = codes_host[(size_t)p * code_length];
+        }
+        GAT_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->d_codes), bytes));
+        GAT_HIP(c, hipMemcpy(c->d_codes, rows.data(), bytes, hipMemcpyHostToDevice));
+    }
     c->code_row_stride = stride;
     c->Lc = code_length;
     c->P = num_prns;
@@ -425,11 +440,15 @@ GAT_API int32_t gat_set_codes(gat_ctx *c, const int8_t *codes_host, int32_t code
     bool pm1 = true;
     for (size_t i = 0; i < (size_t)code_length * num_prns && pm1; ++i) pm1 = codes_host[i] == 1 || codes_host[i] == -1;
     if (pm1) {
-        const int bstride = (((code_length + 31) / 32) + 3) & ~3;
+        // (rows: chip code_length repeats chip 0 -- see above --, and one whole dword of slack behind the last chip, so that the
+        // two dwords holding "this chip and the next" can always be read together)
+        const int bstride = (((code_length + 1 + 32 + 31) / 32) + 3) & ~3;
         std::vector<uint32_t> bits((size_t)bstride * num_prns, 0u);
         for (int p = 0; p < num_prns; ++p)
             for (int i = 0; i < code_length; ++i)
                 if (codes_host[(size_t)p * code_length + i] < 0) bits[(size_t)p * bstride + (i >> 5)] |= 1u << (i & 31);
+        for (int p = 0; p < num_prns; ++p)
+            if (codes_host[(size_t)p * code_length] < 0) bits[(size_t)p * bstride + (code_length >> 5)] |= 1u << (code_length & 31);
         GAT_HIP(c, hipMalloc(reinterpret_cast<void **>(&c->d_code_bits), bits.size() * sizeof(uint32_t)));
         GAT_HIP(c, hipMemcpy(c->d_code_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         c->code_bits_stride = bstride;

@@ -87,6 +87,10 @@ struct gat_ctx {
     int one_wave_seg = gat::kOneWaveSegSteps;      // option dc_ow_seg: steps per replica segment of a one-wave workgroup
     int max_depth = 2;                        // option dc_depth: cap of the sample prefetch depth (register sets per wave)
     int keep_l2 = -1;                         // option dc_keep_l2: cache policy of the sample loads (-1: by rule)
+    int quads = -1;                           // option dc_quads: replica fill by quads (-1 by rule, 0 never, 1 wherever possible)
+    int bit_tables = 1;                       // option dc_bits: chip tables staged as sign bits (0 never, 1 long codes, 2 whenever chips are +-1)
+    int aw2 = -1;                             // option dc_aw2: the two-channel 2 x 2 tile (-1 by rule, 0 never, 1 wherever possible)
+    int seg_cap = 0;                          // option dc_seg: cap of the steps per replica segment (0: by instance)
     int align_head = 1;                       // option dc_align: line-aligned virtual block starts where blocks start off a line
     int mc_mode = 1; // GAT_MC_* kernel selection (gat_set_matrix_core)
     std::string err;

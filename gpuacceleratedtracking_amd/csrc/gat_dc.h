@@ -250,7 +250,7 @@ __device__ __forceinline__ void completion_flag(unsigned *done_counter, unsigned
 #endif
 
 template <int MT, int L, int VEC, int FMT, int AW, int KT, bool KEEP, int NW, int D>
-__global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D, FMT)) dc_kernel(const DcArgs a)
+__global__ void __launch_bounds__(64 * NW, dc_min_waves(MT, L, KT, D, FMT, AW)) dc_kernel(const DcArgs a)
 {
 #define GAT_DC_BODY_RESIDENT 0
 #include "gat_dc_body.inc"
@@ -298,6 +298,8 @@ static hipError_t launch_dc_ml(const DcArgs &a, const DcLaunch &cfg, hipStream_t
     case 1 * 8 + 1: return launch_dc_one<FMT, MT, L, 4, 1, 1>(a, cfg, s);
     case 1 * 8 + 2: return launch_dc_one<FMT, MT, L, 4, 1, 2>(a, cfg, s);
     case 1 * 8 + 4: return launch_dc_one<FMT, MT, L, 4, 1, 4>(a, cfg, s);
+    case 2 * 8 + 1: return launch_dc_one<FMT, MT, L, 4, 2, 1>(a, cfg, s);
+    case 2 * 8 + 2: return launch_dc_one<FMT, MT, L, 4, 2, 2>(a, cfg, s);
     case 4 * 8 + 1: return launch_dc_one<FMT, MT, L, 4, 4, 1>(a, cfg, s);
     case 4 * 8 + 2: return launch_dc_one<FMT, MT, L, 4, 4, 2>(a, cfg, s);
     case 4 * 8 + 4: return launch_dc_one<FMT, MT, L, 4, 4, 4>(a, cfg, s);

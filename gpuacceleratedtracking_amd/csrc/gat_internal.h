@@ -49,6 +49,9 @@ struct DcArgs {
     const void *im;                   // planar: float im plane; otherwise unused
     const gat_channel_params *params; // dev, [B*K], channel fastest; null: the records are in `inl` (B*K <= kInlineParams)
     const int8_t *codes;              // dev, [P][code_row_stride] (rows padded to 16 bytes)
+    const uint32_t *code_bits;        // dev, [P][table_stride / 4]: sign bits of +-1 chips (bit i & 31 of dword i >> 5), or null:
+                                      // the workgroups stage the int8 rows.  Long codes (GPS L5: 10 KB per PRN as int8) are staged as
+                                      // bits -- 1.3 KB -- so that the LDS holds long replica segments and two channels' tables
     float *out_re;                    // dev, [B][K][Ltot][M]
     float *out_im;
     float *partial;                   // dev, [B*K][splits][Ltot*M*2] (splits > 1 only)
@@ -58,6 +61,8 @@ struct DcArgs {
     long long N, ant_stride, block_stride, chan_stride;
     double fs;
     int M, K, B, Lc, num_prns, code_row_stride;
+    int table_stride;      // bytes of ONE channel's chip table in LDS and between rows of what is staged: code_row_stride (int8
+                           // chips) or 4 * dwords per sign-bit row (code_bits != null); a multiple of 16
     int KG;                // channel groups: ceil(K / KT)
     int splits, chunks_per_split, total_chunks;
     int ant_groups;        // M / (MT * AW): antenna groups, one workgroup each
@@ -73,6 +78,7 @@ struct DcArgs {
     int keep_l2;           // 1: plain loads (several channel groups share the tile through L2), 0: non-temporal
     int n_vec;             // samples of a block the vector path covers: N - N % (samples per 16-byte load); N for scalar loads
     int align_head;        // 1: workgroups walk a block from the 128-byte line its first sample lies in (gat_dc.h)
+    int fill_quads;        // 1: replica producers write four consecutive entries at a time where the code rate allows (gat_dc_body.inc)
     unsigned flags;
     int shifts[kMaxTapsPerLaunch];    // ascending
     int tap_off[kMaxTapsPerLaunch];   // float offset of tap l's chips from the lane's group base: even (8-byte aligned reads)
@@ -189,7 +195,11 @@ constexpr size_t dc_lds_bytes(int kt, int mt, int code_row_stride, int chunk)
 // Samples of a group handled at once in the one-channel step (chips, phasors and wipe-off products of SB samples live
 // together): the whole group, half of the eight-sample groups of int8 pairs (a fourth wave per SIMD, round 3), and two of
 // four for the tiles with 25-40 accumulator registers (four antennas x five taps: 145 -> 128 registers, round 4).
-constexpr int dc_sub_batch(int s, int mt, int l, int kt) { return s > 4 ? 4 : (s == 4 && kt == 1 && 2 * mt * l > 24 && 2 * mt * l <= 40 ? 2 : s); }
+constexpr int dc_sub_batch(int s, int mt, int l, int kt, int aw = 1)
+{
+    if (aw == 2 && mt == 2 && kt == 2 && s == 4) return 2; // the two-channel 2 x 2 tile: two-sample passes (chips of both channels live)
+    return s > 4 ? 4 : (s == 4 && kt == 1 && 2 * mt * l > 24 && 2 * mt * l <= 40 ? 2 : s);
+}
 // Occupancy hints (__launch_bounds__ of dc_kernel; the host sizes the LDS segment for the same number of workgroups per
 // CU).  scripts/kernel_resources.sh prints what every instance needs; a bound tighter than that spills into the step loop
 // (1.2-3x slower, rounds 1-2).  Round 4 took the per-lane phasor state and three hoisted fill addresses out of every
@@ -197,8 +207,13 @@ constexpr int dc_sub_batch(int s, int mt, int l, int kt) { return s > 4 ? 4 : (s
 // (<= 256 registers, no AGPR copies), without spills for float and int16 samples.  The int8 forms (eight samples per
 // group) keep round 3's bounds: 13-92 registers over 256 in their channel-looping instances (AGPR copies, one wave per
 // SIMD; by default such shapes run on the split-bf16 matrix kernel).
-constexpr int dc_min_waves(int mt, int l, int kt, int d, int fmt)
+constexpr int dc_min_waves(int mt, int l, int kt, int d, int fmt, int aw = 1)
 {
+    // the two-channel 2 x 2 tile: four waves per SIMD up to five taps (127 registers at five; three waves measured no faster than
+    // the one-channel tile, profiles/r05/ab_kt2.txt), three beyond
+    // (ComplexF32 pairs: two two-sample groups per lane and step cost ~20 registers more -- four waves up to three taps)
+    if (mt == 2 && aw == 2)
+        return fmt == GAT_LAYOUT_INTERLEAVED_I8 ? 2 : fmt == GAT_LAYOUT_INTERLEAVED ? (l <= 3 ? 4 : l <= 6 ? 3 : 2) : (l <= 5 ? 4 : 3);
     const int accs = 2 * mt * l * kt;
     const bool i8 = fmt == GAT_LAYOUT_INTERLEAVED_I8;
     if (accs > 40) return i8 ? 1 : (accs <= 48 && kt == 2 ? 3 : 2); // (four antennas x three taps x two channels: 167 registers)
@@ -227,6 +242,11 @@ constexpr size_t dc_lds_bytes_one_wave(int rep_chan_floats, int code_row_stride)
     return 32 + 64 * sizeof(float) + kUcarFloats * sizeof(float) + (size_t)rep_chan_floats * sizeof(float) + (size_t)code_row_stride;
 }
 
+// Which instances carry the replica fill by quads / from sign-bit chip tables (the host asks for them nowhere else: every
+// form costs an instance scalar registers whether it runs or not)
+constexpr bool dc_fill_quads(int aw, int kt, int nw) { return nw == 4 && aw == 2 && kt == 2; }
+constexpr bool dc_bit_tables(int nw) { return nw == 4; }
+
 // Which instances exist.  Register accumulators 2 * MT * L * KT <= 64; antenna-parallel waves (AW > 1) need full
 // 4-antenna tiles; unaligned input (VEC == 1, scalar loads) is served one antenna per workgroup.
 constexpr bool dc_instance(int mt, int l, int vec, int aw, int kt, int nw = 4, int depth = 1)
@@ -235,10 +255,14 @@ constexpr bool dc_instance(int mt, int l, int vec, int aw, int kt, int nw = 4, i
     // one-wave workgroups: short blocks of one- and two-antenna tiles
     if (nw != 4 && !(nw == 1 && vec == 4 && aw == 1 && kt == 1 && mt <= 2)) return false;
 #ifdef GAT_DC_DEV // development builds: only the instances the BASELINE shapes use (compiles in seconds)
-    if (!((mt == 1 || mt == 4) && (l == 3 || l == 5) && vec == 4)) return false;
+    if (!((mt == 1 || mt == 4 || mt == 2) && (l == 3 || l == 5) && vec == 4)) return false;
 #endif
     if (mt < 1 || mt > kMaxAntTile || l < 1 || l > kMaxTapsPerLaunch) return false;
     if (vec != 4) return vec == 1 && mt == 1 && aw == 1 && kt == 1;
+    // the two-channel 2 x 2 tile: two waves of two antennas each on the same samples, two sample sub-chunks, two channels per
+    // workgroup (the one-channel form of it measured 4-12 % slower than one wave of four antennas at 4, 5 and 6 waves per SIMD:
+    // profiles/r05/ab_aw2.txt -- it does not exist)
+    if (mt == 2 && aw == 2) return kt == 2 && nw == 4 && depth == 1;
     if (aw != 1 && (mt != 4 || aw != 4)) return false;
     // several channels per workgroup only with antenna-parallel waves: measured on MI355X, a channel loop over one
     // antenna tile never beat separate channel workgroups sharing the tile through L2 (M = 1, 4; K = 8, 12)

@@ -257,13 +257,6 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
     // ---- vector kernel (gat_dc.h): launch geometry ---------------------------------------------------------
     // aw: antenna tiles (waves) per workgroup -- 16 antennas on 4 waves walk the same samples, so carrier and replica
     //     are produced once per workgroup; kt: channels a workgroup loops over with the samples held in registers.
-    const int AT = M / MT;
-    int aw = 1, kt = 1;
-    if (vec == 4 && MT == 4) aw = AT % 4 == 0 ? 4 : (AT % 2 == 0 ? 2 : 1);
-    aw = std::min(aw, c->max_aw);
-    if (vec == 4 && aw == 4 && sig->chan_stride == 0 && K > 1) kt = K >= 3 ? 4 : 2;
-    kt = std::min(kt, c->max_kt);
-    if (plan_out) aw = 1, kt = 1;
     // tap launches: sorted taps cut into groups of <= kMaxTapsPerLaunch whose span fits the LDS replica segment
     int order[GAT_MAX_TAPS];
     for (int l = 0; l < L; ++l) order[l] = l;
@@ -275,10 +268,38 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
         max_taps = std::max(max_taps, t1 - t0);
         t0 = t1;
     }
+    // The two-channel 2 x 2 tile (round 5): a four-antenna tile as TWO waves of two antennas on the same samples, each wave
+    // looping over TWO channels on its register-resident samples -- half the sample loads per channel of the one-wave-of-four
+    // tile at the same registers per wave.  Several channels on one signal were bound by the CU's load path (L2 -> L1 -> registers:
+    // 12 channel workgroups re-read every tile), not by HBM or the vector pipe: configs[2] 1.14 -> 1.02 ms, four antennas x
+    // eight channels at 20 MHz 0.305 -> 0.253 ms, eight antennas x four channels 0.368 -> 0.291 ms
+    // (profiles/r05/ab_aw2_rule.txt).  Not for int8 pairs (eight-sample groups: the two-channel step spills), not for tiles of
+    // 16 antennas (AW = 4 with up to four channels per workgroup), not in the latency regime (too few workgroups to matter;
+    // + 6 % there), not for one signal per channel.  Option dc_aw2: -1 this rule, 0 never, 1 wherever an instance exists.
+    const long long pairs_wgs = (long long)B * ((K + 1) / 2) * (M / 4);
+    // (ComplexF32 pairs beyond five taps: the instance drops to two waves per SIMD)
+    const bool aw2_rule = fmt != GAT_LAYOUT_INTERLEAVED_I8 && !(fmt == GAT_LAYOUT_INTERLEAVED && max_taps > 5) && K >= 2 && sig->chan_stride == 0 &&
+                          pairs_wgs >= 2ll * c->num_cus;
+    const bool aw2 = (c->aw2 == 1 || (c->aw2 < 0 && aw2_rule)) && !plan_out && vec == 4 && MT == 4 && (M / MT) % 4 != 0 && c->max_kt >= 2 &&
+                     c->max_aw >= 2 && K >= 2 && sig->chan_stride == 0 && dc_has_instance(2, max_taps, 4, 2, 2);
+    if (aw2) MT = 2;
+    const int AT = M / MT;
+    int aw = 1, kt = 1;
+    if (vec == 4 && MT == 4) aw = AT % 4 == 0 ? 4 : (AT % 2 == 0 ? 2 : 1);
+    if (aw2) aw = 2;
+    aw = std::min(aw, c->max_aw);
+    if (vec == 4 && aw == 4 && sig->chan_stride == 0 && K > 1) kt = K >= 3 ? 4 : 2;
+    if (aw2 && sig->chan_stride == 0 && K > 1) kt = 2; // the 2 x 2 tile: two channels on the wave's two antennas (half the loads per channel)
+    kt = std::min(kt, c->max_kt);
+    if (plan_out) aw = 1, kt = 1;
     while (kt > 1 && !dc_has_instance(MT, max_taps, vec, aw, kt)) kt >>= 1;
     while (aw > 1 && !dc_has_instance(MT, max_taps, vec, aw, kt)) aw >>= 1;
     // LDS: two workgroups per CU at least (80 KB each); a chip table that does not even fit alone is an error
-    auto lds_of = [&](int kt_, int aw_) { return dc_lds_bytes(kt_, MT, c->code_row_stride, dc_chunk(vec, fmt, aw_)); };
+    // chip tables in LDS: int8 rows, or -- long codes (GPS L5: 10 KB per PRN) whose chips are all +-1 -- sign-bit rows (1.3 KB):
+    // room for long replica segments and for a second channel's table (option dc_bits: 0 never, 1 long codes, 2 always)
+    bool bit_tables = c->d_code_bits && c->code_bits_stride > 0 && (c->bit_tables == 2 || (c->bit_tables == 1 && c->code_row_stride > 2048));
+    int tab_bytes = bit_tables ? c->code_bits_stride * 4 : c->code_row_stride;
+    auto lds_of = [&](int kt_, int aw_) { return dc_lds_bytes(kt_, MT, tab_bytes, dc_chunk(vec, fmt, aw_)); };
     while (kt > 1 && lds_of(kt, aw) > 80 * 1024) kt >>= 1;
     if (lds_of(kt, aw) > 160 * 1024)
         return fail(c, GAT_ERR_RANGE, "code table too long for the LDS-resident chip table of the vector kernel");
@@ -297,6 +318,7 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
         c->max_aw >= 4 /* the (1, 1, 1) tiling of the A/B tests keeps the four-wave geometry */ &&
         dc_has_instance(MT, max_taps, vec, 1, 1, 1))
         nw = 1;
+    if (!dc_bit_tables(nw)) bit_tables = false, tab_bytes = c->code_row_stride; // (one-wave workgroups read int8 rows)
     const long long chunk = dc_chunk(vec, fmt, aw, nw);
     // Workgroups per CU the split aims for: 8 -- except for the channel-looping instances (KT >= 2: 170-250 registers,
     // two workgroups resident per CU), where a finer split only adds partial sums, a second launch and workgroup starts
@@ -379,6 +401,8 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
     a.Lc = c->Lc;
     a.num_prns = c->P;
     a.code_row_stride = c->code_row_stride;
+    a.code_bits = bit_tables ? c->d_code_bits : nullptr;
+    a.table_stride = tab_bytes;
     a.KG = KG;
     a.splits = (int)splits;
     a.chunks_per_split = (int)cps;
@@ -391,6 +415,9 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
     a.keep_l2 = c->keep_l2 >= 0 ? c->keep_l2 : (KG > 1 && sig->chan_stride == 0);
     a.n_vec = (int)(vec == 4 ? N - N % spv : N);
     a.align_head = align_head ? 1 : 0;
+    // replica fill by quads: where two channels share a wave's samples (the 2 x 2 tile) the fill's instructions are on the critical
+    // resource; the one-channel tiles measured no gain (option dc_quads: -1 by rule, 0 never, 1 wherever the code rate allows)
+    a.fill_quads = dc_fill_quads(aw, kt, nw) && (c->quads >= 0 ? c->quads : 1) ? 1 : 0;
     // a block length that is no multiple of the load group: the N % spv samples behind the last whole group are added
     // by dc_tail_kernel, one more (tiny) launch behind the vector kernel and its second stage
     const bool tail = vec == 4 && N % spv != 0;
@@ -410,8 +437,9 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
     cfg.vec = vec;
     cfg.format = fmt;
     cfg.grid = (unsigned)grid_wgs;
-    const int seg_max = nw == 1 ? c->one_wave_seg : dc_segment_steps((int)chunk, kt, MT);
-    cfg.lds_bytes = (unsigned)dc_lds_bytes(kt, MT, c->code_row_stride, (int)chunk);
+    int seg_max = nw == 1 ? c->one_wave_seg : dc_segment_steps((int)chunk, kt, MT);
+    if (nw == 4 && c->seg_cap > 0) seg_max = std::max(cfg.depth == 2 ? 2 : 1, std::min(seg_max, c->seg_cap));
+    cfg.lds_bytes = (unsigned)dc_lds_bytes(kt, MT, tab_bytes, (int)chunk);
 
     // Taps in any order: tap_index maps each tap of a launch back to its position in the caller's list
     // (a single-tap launch always fits: span 0).
@@ -442,7 +470,7 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
             const int one = dc_rep_copy_floats(a.seg_steps, (int)chunk, a.rep_span, 64);
             a.rep_copy_stride = odd ? one : 0;
             a.rep_chan_floats = ((odd ? 2 : 1) * one + 7) & ~7;
-            cfg.lds_bytes = (unsigned)dc_lds_bytes_one_wave(a.rep_chan_floats, c->code_row_stride);
+            cfg.lds_bytes = (unsigned)dc_lds_bytes_one_wave(a.rep_chan_floats, tab_bytes);
         } else {
             // An instance that holds four waves per SIMD (dc_min_waves) needs four workgroups per CU to get them: with
             // 10 KB chip tables (GPS L5) the full eight-step segment makes a workgroup 47 KB -- three per CU.  Such launches
@@ -451,16 +479,16 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
             // (a tap span beyond the default sizing -- seven taps half a chip apart at 262 MHz span 768 samples -- gets the
             // room it needs in the same launch instead of a second launch: 22.8 -> 17 us for that call)
             const int span_sz = std::max(kMaxReplicaSpan, a.rep_span);
-            const int want_waves = dc_min_waves(MT, cfg.taps, kt, 1, fmt);
-            if (want_waves >= 4)
-                while (seg > 2 && dc_lds_bytes_floats(kt, c->code_row_stride, dc_rep_chan_floats_steps(seg, (int)chunk, span_sz)) > (size_t)(160 / want_waves) * 1024) --seg;
+            const int want_waves = dc_min_waves(MT, cfg.taps, kt, 1, fmt, aw);
+            if (want_waves >= 4 || (aw == 2 && want_waves >= 3))
+                while (seg > 2 && dc_lds_bytes_floats(kt, tab_bytes, dc_rep_chan_floats_steps(seg, (int)chunk, span_sz)) > (size_t)(160 / want_waves) * 1024) --seg;
             if (span_sz > kMaxReplicaSpan)
-                while (seg > 1 && dc_lds_bytes_floats(kt, c->code_row_stride, dc_rep_chan_floats_steps(seg, (int)chunk, span_sz)) > 64 * 1024) --seg;
+                while (seg > 1 && dc_lds_bytes_floats(kt, tab_bytes, dc_rep_chan_floats_steps(seg, (int)chunk, span_sz)) > 64 * 1024) --seg;
             const int chan_floats = dc_rep_chan_floats_steps(seg, (int)chunk, span_sz);
-            if (dc_lds_bytes_floats(kt, c->code_row_stride, chan_floats) > 160 * 1024)
+            if (dc_lds_bytes_floats(kt, tab_bytes, chan_floats) > 160 * 1024)
                 return fail(c, GAT_ERR_RANGE, "tap span and code table do not fit the LDS of one workgroup");
             a.rep_chan_floats = chan_floats;
-            cfg.lds_bytes = (unsigned)dc_lds_bytes_floats(kt, c->code_row_stride, chan_floats);
+            cfg.lds_bytes = (unsigned)dc_lds_bytes_floats(kt, tab_bytes, chan_floats);
             if (odd)
                 while (seg > 1 && 2 * dc_rep_copy_floats(seg, (int)chunk, a.rep_span) > chan_floats) --seg;
             cfg.depth = 1;

@@ -73,7 +73,7 @@ static void check_dc(const DcArgs &a, const DcLaunch &cfg, bool resident)
     // LDS: what the kernel carves must fit what the launch gives it; the replica must hold a segment + taps + the producers' overshoot
     const int threads = 64 * nw, rpc = threads / kt;
     REQUIRE(a.seg_steps >= 1 && a.seg_steps <= kUcarSteps && a.seg_steps % cfg.depth == 0, "%s: %d steps per segment (depth %d)", tag, a.seg_steps, cfg.depth);
-    const size_t carve = nw == 1 ? dc_lds_bytes_one_wave(a.rep_chan_floats, a.code_row_stride) : dc_lds_bytes_floats(kt, a.code_row_stride, a.rep_chan_floats);
+    const size_t carve = nw == 1 ? dc_lds_bytes_one_wave(a.rep_chan_floats, a.table_stride) : dc_lds_bytes_floats(kt, a.table_stride, a.rep_chan_floats);
     REQUIRE(carve <= cfg.lds_bytes && cfg.lds_bytes <= 160 * 1024, "%s: LDS carve %zu of %u", tag, carve, cfg.lds_bytes);
     const long long seg_entries = (long long)a.seg_steps * chunk + a.rep_span;
     const long long filled = (seg_entries + rpc - 1) / rpc * rpc; // every producer takes the same number of steps
@@ -85,6 +85,8 @@ static void check_dc(const DcArgs &a, const DcLaunch &cfg, bool resident)
     }
     REQUIRE((long long)a.N + a.max_abs_shift < (1ll << 30), "%s: sample range", tag);
     REQUIRE(a.code_row_stride % 16 == 0 && a.code_row_stride >= a.Lc && a.codes != nullptr, "%s: chip table", tag);
+    REQUIRE(a.table_stride % 16 == 0 && (a.code_bits ? a.table_stride * 8 >= a.Lc : a.table_stride == a.code_row_stride), "%s: staged table of %d bytes (%s) for %d chips",
+            tag, a.table_stride, a.code_bits ? "sign bits" : "int8", a.Lc);
     if (!resident) {
         REQUIRE(a.params != nullptr || (long long)a.B * a.K <= kInlineParams, "launch: %d x %d records without a buffer", a.B, a.K);
         REQUIRE(a.out_re != nullptr && a.out_im != nullptr, "launch: no outputs");

@@ -60,7 +60,8 @@ EXPECTED = {
     # name: (build_stream args, expected launch-info fields)
     "configs[1]": (("GPSL1", 20000, 4, 3, 1, 4096), dict(matrix_core=0, threads=256, ant_tile=4, vec=4, channels_per_wg=1, splits=1, prefetch_depth=2)),
     "configs[0] shape": (("GPSL1", 4000, 1, 3, 1, 16384), dict(matrix_core=0, threads=64, ant_tile=1, vec=4, channels_per_wg=1, splits=1, prefetch_depth=2)),
-    "configs[2]": (("GPSL5", 50000, 4, 5, 12, 256), dict(matrix_core=0, threads=256, ant_tile=4, vec=4, channels_per_wg=1, splits=1, prefetch_depth=1)),
+    # (round 5: the two-channel 2 x 2 tile -- two waves of two antennas, two channels per workgroup)
+    "configs[2]": (("GPSL5", 50000, 4, 5, 12, 256), dict(matrix_core=0, threads=256, ant_tile=4, vec=4, channels_per_wg=2, splits=1, prefetch_depth=1)),
     "configs[3] shard": (("GPSL1", 50000, 16, 3, 4, 512), dict(matrix_core=0, threads=256, ant_tile=16, vec=4, channels_per_wg=4, splits=1, prefetch_depth=1)),
     "configs[3] whole": (("GPSL1", 50000, 16, 3, 32, 128), dict(matrix_core=0, threads=256, ant_tile=16, vec=4, channels_per_wg=4, splits=1, prefetch_depth=1)),
 }

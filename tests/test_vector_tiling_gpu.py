@@ -164,6 +164,122 @@ def test_exact_walk_survives_adversarial_code_phases(gat, vector_ctx):
         assert np.array_equal(got.real.astype(np.float64), ref.real), tiling
 
 
+# ---- the two-channel 2 x 2 tile (round 5: two waves of two antennas, two channels each; option dc_aw2) ----------------------
+TWO_BY_TWO_SHAPES = [
+    # system, N, M, L, K, B
+    ("GPSL1", 20000, 4, 3, 2, 3),    # configs[1]'s tile, two channels
+    ("GPSL5", 20000, 4, 5, 6, 2),    # configs[2] family: long codes -> sign-bit tables, quads
+    ("GPSL5", 6020, 4, 5, 3, 5),     # odd channel count (one empty channel slot), blocks that start off a 128-byte line
+    ("GPSL1", 5004, 8, 3, 4, 2),     # two antenna groups, blocks that start 16 bytes into a 128-byte line
+    ("GPSL1", 2048, 12, 7, 2, 2),    # three antenna groups, seven taps (three waves per SIMD)
+    ("GPSL1", 332, 4, 8, 7, 4),      # eight taps, seven channels, blocks of less than one step
+    ("GPSL1", 2500, 4, 3, 2, 1),     # the reference's N (2500 = 2.5 MHz: tap spacing 1 -> taps at ODD distances: the shifted copy, no quads)
+    ("GPSL5", 40000, 4, 3, 12, 1),   # one block split over workgroups (second stage), twelve channels
+]
+FILL_MODES = [dict(), dict(dc_quads=0), dict(dc_bits=0), dict(dc_bits=2), dict(dc_bits=2, dc_quads=0), dict(dc_seg=2)]
+
+
+@pytest.fixture()
+def two_by_two_ctx(gat, vector_ctx):
+    yield vector_ctx
+    for name, val in (("dc_aw2", -1), ("dc_quads", -1), ("dc_bits", 1), ("dc_seg", 0)):
+        vector_ctx.set_option(name, val)
+
+
+@pytest.mark.parametrize("mode", FILL_MODES, ids=lambda m: "-".join(f"{k}{v}" for k, v in m.items()) or "default")
+@pytest.mark.parametrize("shape", TWO_BY_TWO_SHAPES, ids=[f"{s[0]}-N{s[1]}-M{s[2]}-L{s[3]}-K{s[4]}-B{s[5]}" for s in TWO_BY_TWO_SHAPES])
+def test_two_channel_two_by_two_tile_matches_the_oracle(gat, two_by_two_ctx, shape, mode):
+    system, N, M, L, K, B = shape
+    case = make_case(zlib.crc32(repr(shape).encode()), system=system, N=N, M=M, L=L, K=K, B=B)
+    ctx = two_by_two_ctx
+    ctx.set_option("dc_aw2", 1)
+    for name, val in mode.items():
+        ctx.set_option(name, val)
+    got, info = run_case(gat, ctx, case)
+    assert info["matrix_core"] == 0 and info["channels_per_wg"] == 2 and info["ant_tile"] == 4 and info["threads"] == 256, info
+    check_close(got, oracle_result(case), what=f"{shape} {mode} {info}")
+    # the same call on the one-wave-of-four tile: the two tilings agree to rounding
+    ctx.set_option("dc_aw2", 0)
+    ref_tile, info0 = run_case(gat, ctx, case)
+    assert info0["channels_per_wg"] == 1
+    assert np.abs(got - ref_tile).max() <= 2e-6 * np.abs(ref_tile).max()
+
+
+@pytest.mark.parametrize("layout", [1, 2])
+def test_two_by_two_tile_in_complex_and_int16_samples(gat, two_by_two_ctx, layout):
+    shape = ("GPSL5", 6000, 4, 5, 4, 3)
+    system, N, M, L, K, B = shape
+    case = make_case(78, system=system, N=N, M=M, L=L, K=K, B=B)
+    peak = max(np.abs(case["re"]).max(), np.abs(case["im"]).max())
+    case["re"] = np.rint(case["re"] * (1000.0 / peak)).astype(np.float32)
+    case["im"] = np.rint(case["im"] * (1000.0 / peak)).astype(np.float32)
+    two_by_two_ctx.set_option("dc_aw2", 1)
+    got, info = run_case(gat, two_by_two_ctx, case, layout=layout)
+    assert info["channels_per_wg"] == 2 and info["ant_tile"] == 4, info
+    check_close(got, oracle_result(case), what=f"layout {layout} {info}")
+
+
+def test_two_by_two_tile_is_the_planners_choice_where_it_measured_faster(gat, vector_ctx):
+    """The rule of option dc_aw2 = -1 (gat_planner.cpp): float / int16 samples, four-antenna tiles that are no 16-antenna
+    group, two or more channels on one signal, enough workgroups to fill the chip; never int8 pairs, never the latency regime."""
+    import torch
+    g = gat
+    sysobj = g.GPSL1(use_gpu=True)
+    shifts = np.array([-10, 0, 10], dtype=np.int32)
+
+    def tile(M, K, B, N=20000, layout=0):
+        op = g.StreamCorrelator(sysobj, N, M, B, K, shifts, N / 1e-3, ctx=vector_ctx)
+        op.set_params(g.make_params(np.arange(K) % 32, 1.023e6, 1500.0, 0.0, 0.0, shape=(B, K)))
+        if layout == 0:
+            op(torch.zeros((M, B * N), device="cuda"), torch.zeros((M, B * N), device="cuda"))
+        else:
+            op(torch.zeros((M, B * N, 2), dtype=torch.int8 if layout == 3 else torch.int16, device="cuda"), None)
+        i = vector_ctx.last_launch_info()
+        return i["ant_tile"], i["channels_per_wg"]
+
+    assert tile(4, 8, 256) == (4, 2) and tile(8, 4, 256) == (4, 2) and tile(12, 2, 512) == (4, 2)
+    assert tile(4, 1, 1024) == (4, 1)                      # one channel: the one-wave-of-four tile
+    assert tile(16, 4, 64) == (16, 4)                      # sixteen antennas: AW = 4, four channels per workgroup
+    assert tile(4, 12, 1) == (4, 1)                        # one block: latency regime
+    assert tile(4, 8, 256, layout=3) == (4, 1)             # int8 pairs
+    assert tile(4, 8, 256, layout=2) == (4, 2)             # int16 pairs
+
+
+def test_chip_edges_exact_in_the_two_by_two_tile(gat, two_by_two_ctx):
+    """All-ones signal, zero carrier: integer sums, compared exactly with the oracle -- GPS L5 at 50 MHz with code phases at and
+    next to chip edges and the table's wrap (the quads read "this chip and the next": index Lc - 1 is followed by chip 0), in
+    every fill mode of the two-channel tile; and the adversarial ratio = 1/16 case on GPS L1 (every batch redone exactly)."""
+    import torch
+    g = gat
+    ctx = two_by_two_ctx
+    for system_name, N, fs, fc, L, taus in (
+            ("GPSL5", 50000, 50e6, 10.23e6, 5, [[0.0, 10229.999999, 5115.5, 1e-9], [3.0 - 1e-12, 7.25, 10229.0, 10229.5]]),
+            ("GPSL1", 8192, 1.023e6 * 16, 1.023e6, 3, [[0.0, 0.0625, 511.9375, 1022.9375], [512.0 - np.spacing(512.0), 1022.0 + 15 * 0.0625, 700.5, 1e-300]])):
+        M, K, B = 4, 4, 2
+        system = g.GNSSDICT[system_name](use_gpu=True)
+        shifts = oracle.sample_shifts(L, fs, fc) if system_name == "GPSL5" else np.array([-8, 0, 8], dtype=np.int32)
+        rng = np.random.default_rng(6)
+        prm = oracle.make_params(np.broadcast_to(np.arange(K), (B, K)), fc * (1 + (rng.uniform(-3e-6, 3e-6, (B, K)) if system_name == "GPSL5" else 0.0)),
+                                 np.zeros((B, K)), np.array(taus), np.zeros((B, K)))
+        re = np.ones((M, B * N), dtype=np.float32)
+        im = np.zeros_like(re)
+        ref = oracle.correlate_f64(re, im, oracle.codes(system_name, 32), prm, fs, shifts, N=N)
+        assert np.all(ref.imag == 0) and np.all(ref.real == np.rint(ref.real))
+        op = g.StreamCorrelator(system, N, M, B, K, shifts, fs, ctx=ctx)
+        op.set_params(g.make_params(prm["prn0"], prm["code_freq_hz"], prm["carrier_freq_hz"], prm["code_phase_chips"], prm["carrier_phase_cycles"]))
+        d_re, d_im = torch.from_numpy(re).to(ctx.device), torch.from_numpy(im).to(ctx.device)
+        ctx.set_option("dc_aw2", 1)
+        for mode in FILL_MODES:
+            for name, val in (("dc_quads", -1), ("dc_bits", 1), ("dc_seg", 0)):
+                ctx.set_option(name, val)
+            for name, val in mode.items():
+                ctx.set_option(name, val)
+            op(d_re, d_im)
+            got = op.result()
+            assert ctx.last_launch_info()["channels_per_wg"] == 2
+            assert np.array_equal(got.real.astype(np.float64), ref.real) and np.all(got.imag == 0), (system_name, mode)
+
+
 ONE_WAVE_SHAPES = [
     # system, N, M, L, K, B  -- short blocks of one- and two-antenna tiles: one wave per (block, channel, tile)
     ("GPSL1", 4000, 1, 3, 1, 40),    # configs[0] shape in a stream
