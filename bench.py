@@ -105,6 +105,8 @@ def parse_args(argv=None):
                          "write the rows to OUT.json -- the CPU series scripts/plot_benchmarks.py draws beside the GPU's")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="launch-geometry option of the library (include/gat.h gat_set_option), repeatable; recorded in the line")
+    ap.add_argument("--matrix-core", type=int, choices=[0, 1, 2, 3], default=None,
+                    help="kernel selection (include/gat.h GAT_MC_*): 0 vector kernel only, 1 auto (default), 2 f32 MFMA, 3 split-bf16 MFMA")
     ap.add_argument("--baseline-config", type=int, choices=[1, 2, 3, 4], default=None,
                     help="shape of BASELINE.json configs[i] (1 = the default headline workload; 2 = GPS L5, 4 ants, 12 PRNs, "
                          "5 taps @ 50 MHz; 3 = the per-GPU shard of 16 ants x 32 PRNs @ 50 MHz; 4 = 64 ants x 64 channels, "
@@ -450,6 +452,8 @@ def measure(args, g, torch, dist, world, rank, shape_kw, steps, warmup, settle, 
     for opt in args.option:
         name, _, val = opt.partition("=")
         ctx.set_option(name.strip(), int(val))
+    if args.matrix_core is not None:
+        ctx.set_matrix_core(args.matrix_core)
     fs = N / (shape_kw["block_ms"] * 1e-3)
 
     def barrier():
@@ -714,6 +718,8 @@ def main():
         out.update(provenance())  # "libgat": version + kernel-source commit + build flags, "git": repository commit
         if args.option:
             out["config"]["options"] = list(args.option)
+        if args.matrix_core is not None:
+            out["config"]["options"] = out["config"].get("options", []) + [f"matrix_core={args.matrix_core}"]
         if world > 1:
             out["ranks"] = {"world_size": world, "backend": backend, "ms_per_step_by_rank": rec["ms_per_step_by_rank"],
                             "kernel_ms_median_by_rank": rec["kernel_ms_median_by_rank"], "devices": m["devices"]}

@@ -280,7 +280,8 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
     // (ComplexF32 pairs beyond five taps: the instance drops to two waves per SIMD)
     const bool aw2_rule = fmt != GAT_LAYOUT_INTERLEAVED_I8 && !(fmt == GAT_LAYOUT_INTERLEAVED && max_taps > 5) && K >= 2 && sig->chan_stride == 0 &&
                           pairs_wgs >= 2ll * c->num_cus;
-    const bool aw2 = (c->aw2 == 1 || (c->aw2 < 0 && aw2_rule)) && !plan_out && vec == 4 && MT == 4 && (M / MT) % 4 != 0 && c->max_kt >= 2 &&
+    const bool aw4_tile = (M / MT) % 4 == 0 && c->max_aw >= 4; // sixteen antennas on four waves (with up to four channels per workgroup)
+    const bool aw2 = (c->aw2 == 1 || (c->aw2 < 0 && aw2_rule)) && !plan_out && vec == 4 && MT == 4 && !aw4_tile && c->max_kt >= 2 &&
                      c->max_aw >= 2 && K >= 2 && sig->chan_stride == 0 && dc_has_instance(2, max_taps, 4, 2, 2);
     if (aw2) MT = 2;
     const int AT = M / MT;

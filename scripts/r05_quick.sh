@@ -14,6 +14,7 @@ c1) run c1 ;;
 c0) run c0 --num-samples 4000 --num-ants 1 --blocks 16384 ;;
 c2) run c2 --baseline-config 2 ;;
 c3) run c3 --baseline-config 3 ;;
+c3k32) run c3k32 --num-samples 50000 --num-ants 16 --num-taps 3 --channels 32 --blocks 512 ;;     # configs[3] as a whole on one GPU: 16 antennas x 32 PRNs
 c2l1) run c2l1 --gnss GPSL1 --num-samples 50000 --num-ants 4 --num-taps 5 --channels 12 --blocks 1024 ;;  # configs[2]'s shape on 1 KB chip tables
 c1k8) run c1k8 --channels 8 --blocks 1024 ;;  # configs[1]'s tile with eight channels
 c1k2) run c1k2 --channels 2 --blocks 2048 ;;
