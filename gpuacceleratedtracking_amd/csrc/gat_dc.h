@@ -194,7 +194,7 @@ struct SampleIO {
 // The compiler sinks every kernel-argument load to its first use, so a kernel with several hundred bytes of arguments
 // pays one scalar-cache miss per 64-byte line, one after the other, each a full trip to the runtime's argument buffer
 // (set-up, replica, steps, tail: in a single-block call these serial trips were a third of the kernel's time,
-// scripts/history/r03/r03_latency_cuts.sh; HIP_FORCE_DEV_KERNARG=1 changes nothing).  Touching every line at the kernel's first
+// r03_latency_cuts.sh of an earlier round: git history; HIP_FORCE_DEV_KERNARG=1 changes nothing).  Touching every line at the kernel's first
 // instruction overlaps them into one.
 template <int BYTES>
 __device__ __forceinline__ void kernarg_prefetch()
@@ -233,7 +233,7 @@ __device__ __forceinline__ void completion_flag(unsigned *done_counter, unsigned
     }
 }
 
-// Diagnostic builds (-DGAT_DC_LAT_CUT=n, scripts/history/r03/r03_latency_cuts.sh): the kernel ends at cut point n -- 1 entry, 2 block
+// Diagnostic builds (-DGAT_DC_LAT_CUT=n, r03_latency_cuts.sh of an earlier round: git history): the kernel ends at cut point n -- 1 entry, 2 block
 // set-up + chip tables, 3 first replica segment + carrier anchors, 4 step loop -- so that the single-block latency can be
 // attributed to its phases (5: + reduction up to its barrier, 6: everything but the result stores).  Results are wrong by
 // construction; never part of the product build.

@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         if (!have_item) return;
         if (!c.valid) return;
         const bool anchor = first || ((st - s_begin) % kReanchor) == 0; // wave-uniform
-#if defined(GAT_ABLATE) && (GAT_ABLATE & 1) // diagnostic builds (scripts/history/r01/ablate_mfma_bf16.sh; results wrong on purpose): no replica
+#if defined(GAT_ABLATE) && (GAT_ABLATE & 1) // diagnostic builds (ablate_mfma_bf16.sh of an earlier round: git history; results wrong on purpose): no replica
         if (first)
 #endif
         gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, nb, span + item_s0, OS, span + T,

@@ -103,7 +103,7 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
         int nct = nct_total >= 4 ? 4 : (nct_total >= 2 ? 2 : 1);
         while (nct > 1 && nct * CT > 20) nct >>= 1; // both kernels keep at most 20 channel slots per workgroup
         // kernel choice: 3 / 1 (auto) -> split-bf16 when its tile fits in LDS, 2 -> f32 MFMA.  GAT_MC_AUTO picks a matrix
-        // kernel only where it measured faster than the vector kernel (scripts/history/r02/r02_planner_scan.sh, profiles/r02/
+        // kernel only where it measured faster than the vector kernel (r02_planner_scan.sh of an earlier round: git history, profiles/r02/
         // r02h_planner_scan.txt; N = 50 000, 3 taps): with float samples the round-2 vector kernel (16 antennas per
         // workgroup, channel loop over register-resident samples, lean step loop) wins or ties up to 24 channels at 64
         // antennas, 32 at 32 and 16 at 128, so the split-bf16 kernel takes M >= 32 with K >= 32 and M * K >= 2048
