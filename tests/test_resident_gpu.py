@@ -378,3 +378,101 @@ def test_resident_call_is_faster_than_launch_and_wait(gat):
         print(f"single block N={N} M={M}: ordinary call + sync {mo:.1f} us, resident call {mr:.1f} us (Python host layer)")
     for N, M, mo, mr in rows:
         assert mr < mo, rows
+
+
+# ---- round 5: housekeeping around device-wide waits, room on the device, buffer bounds, bound code tables ---------------------
+def test_park_all_lets_a_device_wide_wait_return_at_once(gat):
+    """A resident kernel with a long idle limit would make torch.cuda.synchronize() sit that limit out;
+    ctx.device_synchronize() (gat_resident_park_all first) returns at once, and the next call starts the kernel again."""
+    g = gat
+    import torch
+    case = make_case(21, N=4096, M=4, L=3, K=2, B=1)
+    ctx, res = _open(g, case, idle_us=400000, life_ms=20000)
+    with res:
+        prm = _params(g, case, 0)
+        r0 = np.array(res.correlate(prm)[0], copy=True)
+        assert res.info()["running"] == 1
+        t0 = time.perf_counter()
+        ctx.device_synchronize()
+        dt = time.perf_counter() - t0
+        assert dt < 0.1, f"device-wide wait took {dt * 1e3:.1f} ms behind a parked resident kernel"
+        info = res.info()
+        assert info["running"] == 0 and info["last_exit"] == 1  # asked to leave
+        r1 = res.correlate(prm)[0]  # starts it again
+        assert np.array_equal(r0, r1) and res.info()["launches"] == 2
+
+
+def test_open_refuses_what_the_device_cannot_hold_at_once(gat):
+    """Every workgroup of every open resident correlator has to be ON the device for a call to complete: an open beyond that
+    answers GAT_ERR_UNSUPPORTED at once (it used to loop until the call's 3 s deadline), and room comes back with a close."""
+    g = gat
+    import torch
+    ctx = g.Context(0, "own")
+    try:
+        case = make_case(22, N=262144, M=4, L=3, K=1, B=1)
+        ctx.set_codes(case["codes"])
+        re = torch.from_numpy(case["re"]).to(ctx.device)
+        im = torch.from_numpy(case["im"]).to(ctx.device)
+        torch.cuda.synchronize()
+        desc = g._lib.SignalDesc(re.data_ptr(), im.data_ptr(), g.GAT_LAYOUT_PLANAR, 4, 262144, 262144, 262144, 0)
+        cus = ctx.device_info()["num_cus"]
+        opened, refused = [], None
+        for _ in range(2 * cus // 100 + 8):  # each asks for up to 200 workgroups
+            try:
+                opened.append(ctx.open_resident(desc, 1, case["shifts"], case["fs"], max_workgroups=200, idle_us=200000))
+            except g.GatError as e:
+                refused = e
+                break
+        assert refused is not None and refused.status == 4, (len(opened), refused)
+        assert 1 <= len(opened) and sum(r.info()["workgroups"] for r in opened) <= 8 * cus
+        ref = oracle_result(case)
+        r, i = opened[0].correlate(_params(g, case, 0))  # the ones that were admitted answer
+        check_close((r + 1j * i)[None], ref)
+        opened.pop().close()
+        opened.append(ctx.open_resident(desc, 1, case["shifts"], case["fs"], max_workgroups=200, idle_us=200000))  # room again
+        r, i = opened[-1].correlate(_params(g, case, 0))
+        check_close((r + 1j * i)[None], ref)
+    finally:
+        ctx.close()
+
+
+def test_python_layer_refuses_blocks_outside_the_buffer(gat):
+    g = gat
+    import torch
+    case = make_case(23, N=2048, M=2, L=3, K=1, B=3)
+    ctx = g.get_context()
+    ctx.set_codes(case["codes"])
+    re = torch.from_numpy(case["re"]).to(ctx.device)
+    im = torch.from_numpy(case["im"]).to(ctx.device)
+    torch.cuda.synchronize()
+    desc = g._lib.SignalDesc(re.data_ptr(), im.data_ptr(), g.GAT_LAYOUT_PLANAR, 2, 2048, 3 * 2048, 2048, 0)
+    with ctx.open_resident(desc, 1, case["shifts"], case["fs"], buffer_samples=3 * 2048) as res:
+        res.correlate(_params(g, case, 2), block_offset=2 * 2048)  # the last block: fine
+        with pytest.raises(ValueError):
+            res.correlate(_params(g, case, 2), block_offset=3 * 2048)  # one block past the allocation
+    system = g.GPSL1(use_gpu=True)
+    loop = g.ResidentTrackingLoop(system, np.array([1]), 2048, 2, case["fs"], case["shifts"], np.array([0.0]), np.array([0.0]), re=re, im=im)
+    with loop:
+        loop.run(3)
+        with pytest.raises(ValueError):
+            loop.run(2, start=2 * 2048)  # the second of them would end behind the buffer
+
+
+def test_bound_code_table_cannot_be_edited_in_place(gat):
+    """The context remembers the bound table by identity: an in-place edit must raise instead of silently keeping the old chips
+    on the device; invalidate_codes() is the explicit way."""
+    g = gat
+    ctx = g.Context(0, "own")
+    try:
+        codes = np.array(g.GPSL1(use_gpu=True).codes, copy=True)
+        ctx.set_codes(codes)
+        assert codes.flags.writeable is False
+        with pytest.raises(ValueError):
+            codes[0, 0] = -codes[0, 0]
+        codes.flags.writeable = True
+        codes[0, :] = -codes[0, :]
+        ctx.invalidate_codes()
+        ctx.set_codes(codes)  # hashed again, uploaded
+        assert ctx._codes_obj is codes
+    finally:
+        ctx.close()
