@@ -192,6 +192,7 @@ void key_put_ctx(std::vector<unsigned char> &key, const gat_ctx *c)
 {
     key_put(key, c->mc_mode); key_put(key, c->max_aw); key_put(key, c->max_kt); key_put(key, c->max_bpw); key_put(key, c->force_bpw);
     key_put(key, c->wgs_per_cu); key_put(key, c->max_depth); key_put(key, c->one_wave); key_put(key, c->keep_l2); key_put(key, c->align_head);
+    key_put(key, c->aw2); key_put(key, c->quads); key_put(key, c->bit_tables); key_put(key, c->seg_cap);
     key_put(key, c->d_codes); key_put(key, c->d_code_bits); key_put(key, c->Lc); key_put(key, c->P);
     key_put(key, c->d_partial); key_put(key, c->partial_bytes);
 }
