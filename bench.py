@@ -338,7 +338,7 @@ def step_stats(laps_ms) -> dict:
             "sigma": round(float(t.std(ddof=1)) if t.size > 1 else 0.0, 6), "max": round(float(t.max()), 6), "n": int(t.size)}
 
 
-def roofline(shape, launch_s, matrix_core, stored, mean_s=None, ceiling=None):
+def roofline(shape, launch_s, matrix_core, stored, mean_s=None, ceiling=None, bf16_terms=3):
     """max(bytes / HBM peak, flops / compute peak) vs the measured launch duration (the MEDIAN step; `mean_s`: the mean of
     the same steps beside it); names the winning term.  `stored`: (HBM bytes per launch, vector instructions per launch,
     where they come from) of the committed PMC passes; `ceiling`: the in-run read-ceiling record."""
@@ -373,9 +373,13 @@ def roofline(shape, launch_s, matrix_core, stored, mean_s=None, ceiling=None):
         out.update(bound="mfma" if matrix_core else "vector-f32", achieved=round(ach, 2), peak=F32_PEAK_TFLOPS,
                    unit="TFLOP/s", frac=round(ach / F32_PEAK_TFLOPS, 4))
         if matrix_core == 2:
-            out["bf16_issue"] = {"executed_tflops": round(8 * 2.0 * 2 * M * 2 * K * L * N * B / launch_s / 1e12, 1),
-                                 "peak": BF16_PEAK_TFLOPS,
-                                 "note": "split-bf16: 8 bf16 products per f32 product, 2M x 2KL x N real GEMM"}
+            # k-slots the kernel issues per f32 product: float samples 3 terms x 3 terms less the lo x lo product = 8; int16
+            # samples 2 exact terms: {a h, a m, a l, b h, b m} = 5; int8 samples 1 term: 3 + one zero slot = 4
+            slots = {1: 4, 2: 5}.get(bf16_terms, 8)
+            out["bf16_issue"] = {"executed_tflops": round(slots * 2.0 * 2 * M * 2 * K * L * N * B / launch_s / 1e12, 1),
+                                 "peak": BF16_PEAK_TFLOPS, "slots_per_product": slots, "terms_per_sample": bf16_terms or 3,
+                                 "frac": round(slots * 2.0 * 2 * M * 2 * K * L * N * B / launch_s / 1e12 / BF16_PEAK_TFLOPS, 4),
+                                 "note": "split-bf16: `slots` bf16 products per f32 product, 2M x 2KL x N real GEMM"}
     out["hbm_frac"] = round(alg_bytes / launch_s / 1e9 / HBM_PEAK_GBS, 4)
     if mean_s:
         out["frac_mean"] = round(out["frac"] * launch_s / mean_s, 4)
@@ -514,7 +518,7 @@ def leg_record(g, m, gnss, layout_name, args, backend, want_ceiling):
     err, h_re, h_im = parity_check(g, m)
     ceiling = read_ceiling(m["ctx"], m["sig"], layout_name == "planar") if want_ceiling else None
     rec = {"launch": info, "step_ms": step_stats(m["laps_ms"]),
-           "roofline": roofline(m["shape"], m["median_s"], info.get("matrix_core", 0), stored_traffic([gnss, N, M, L, K, B, layout_name]),
+           "roofline": roofline(m["shape"], m["median_s"], info.get("matrix_core", 0), stored_traffic([gnss, N, M, L, K, B, layout_name]), bf16_terms=info.get("bf16_terms", 3),
                                 mean_s=m["launch_s"], ceiling=ceiling),
            "parity_max_rel_err_vs_f64_oracle": err}
     if m["world"] > 1:

@@ -93,7 +93,7 @@ LOOP_STATE_DTYPE = np.dtype([(n, "<f8") for n in (
 class LaunchInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("workgroups", "threads", "splits", "ant_tile", "vec",
                                           "lds_bytes", "finalize_launched", "matrix_core", "channels_per_wg",
-                                          "blocks_per_wg", "prefetch_depth")]
+                                          "blocks_per_wg", "prefetch_depth", "bf16_terms")]
 
 
 class ResidentConfig(C.Structure):

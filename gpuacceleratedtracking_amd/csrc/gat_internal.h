@@ -294,6 +294,7 @@ struct MfArgs {
     int max_abs_shift, rep_span, rep_stride;
     int code_bits_stride; // dwords per sign-bit row (multiple of 4)
     int codes_in_lds;    // 1: the workgroup's chip tables are staged in LDS (they fit)
+    int mb_mode;         // split-bf16 kernel: MbMode of this launch (the host's choice: mb_mode(), or kMbThree on request for int16)
     unsigned long long *dbg; // diagnostic builds only (GAT_MFMA_STAMPS): per-wave cycle sums
     unsigned flags;
     int shifts[kMfmaMaxTaps];    // ascending
@@ -322,13 +323,32 @@ constexpr int mb_slots(int nct, int L, int K)
     const int s = (32 * nct + 2 * L - 1) / (2 * L) + 1;
     return s < K ? s : K;
 }
-constexpr size_t mb_lds_bytes(int rt, int nct, int fmt, int nslots, int rep_stride, int code_bits_stride)
+// How the split-bf16 kernel lays the cross products along the MFMA's 16 reduction slots (per 32-lane half: 8 slots):
+//   kMbThree  float / int16 samples: x = hi + mid + lo, w = hi + mid + lo, 8 products per sample  -> 1 sample per half and MFMA
+//   kMbOne    int8 samples: exact in ONE bf16 term, 3 products + a zero slot per sample          -> 2 samples per half and MFMA
+//   kMbTwo    int16 samples, round 5: exact in TWO bf16 terms (x = 256 * floor(x / 256) + (x mod 256), both <= 8 significant
+//             bits), 5 products per sample {a h, a m, a l, b h, b m} (b * lo(w) is 2^-24 of the product: below f32), laid as a
+//             STREAM of slots across consecutive MFMAs: 8 samples per half every 5 MFMAs -- 1.6 samples per half and MFMA.
+//             Needs the half's sample count per step (T / consumer waves per tile / 2) to be a multiple of 8.
+enum MbMode : int { kMbThree = 0, kMbOne = 1, kMbTwo = 2 };
+constexpr int mb_mode(int rt, int nct, int fmt, bool force_three = false)
 {
-    const bool x1 = fmt == GAT_LAYOUT_INTERLEAVED_I8;
+    if (fmt == GAT_LAYOUT_INTERLEAVED_I8) return kMbOne;
+    const int wpt = mb_consumer_waves(rt, nct) / nct, hs = mb_tile_samples(rt, nct) / (wpt > 0 ? wpt : 1) / 2;
+    return fmt == GAT_LAYOUT_INTERLEAVED_I16 && !force_three && wpt > 0 && hs >= 8 && hs % 8 == 0 ? kMbTwo : kMbThree;
+}
+// two-term path: bytes of one LDS row of slot-ordered bf16 terms (10 bytes per sample), an odd multiple of 16 (rows of one
+// 16-lane group of a 16-byte read then start on distinct bank quads)
+constexpr int mb_two_row_bytes(int T) { return ((10 * T + 15) / 16 * 16) | 16; }
+constexpr size_t mb_lds_bytes(int rt, int nct, int fmt, int nslots, int rep_stride, int code_bits_stride, int mode = -1)
+{
+    if (mode < 0) mode = mb_mode(rt, nct, fmt);
+    const bool x1 = mode == kMbOne;
     const int T = mb_tile_samples(rt, nct);
     const int xs = x1 ? T + 2 : T + 1, wbytes = x1 ? 8 : 16;
-    return (size_t)kMbHeader + (size_t)2 * rt * 32 * xs * 8 + (size_t)2 * (2 * nslots + 1) * xs * wbytes +
-           (size_t)((2 * nslots * rep_stride + 3) & ~3) * 4 + (size_t)nslots * code_bits_stride * 4;
+    const size_t xw = mode == kMbTwo ? (size_t)2 * rt * 32 * mb_two_row_bytes(T) + (size_t)2 * (2 * nslots + 1) * mb_two_row_bytes(T)
+                                     : (size_t)2 * rt * 32 * xs * 8 + (size_t)2 * (2 * nslots + 1) * xs * wbytes;
+    return (size_t)kMbHeader + xw + (size_t)((2 * nslots * rep_stride + 3) & ~3) * 4 + (size_t)nslots * code_bits_stride * 4;
 }
 // f32-MFMA kernel: 256-sample tiles, 32 planes per row tile
 constexpr int kMfTile = 256;
@@ -342,7 +362,8 @@ hipError_t launch_mfma(const MfArgs &a, int nct, unsigned grid, unsigned lds_byt
 size_t mfma_lds_bytes(int nct, int ct, int rep_stride, int code_row_stride, int codes_in_lds);
 // split-bf16 matrix-core kernel (gat_mfma_bf16.hip): rt = 16-antenna row tiles per workgroup (1, 2, 4)
 hipError_t launch_mfma_bf16(const MfArgs &a, int rt, int nct, int fmt, unsigned grid, unsigned lds_bytes, hipStream_t s);
-size_t mfma_bf16_lds_bytes(int rt, int nct, int fmt, int nslots, int rep_stride, int code_bits_stride);
+size_t mfma_bf16_lds_bytes(int rt, int nct, int fmt, int nslots, int rep_stride, int code_bits_stride, int mode);
+int mfma_bf16_mode(int rt, int nct, int fmt, bool force_three);
 int mfma_bf16_slots(int nct, int L, int K); // channel slots per workgroup (flat column packing)
 int mfma_bf16_max_slots();
 int mfma_bf16_tile_samples(int rt, int nct);

@@ -93,6 +93,7 @@ __device__ __forceinline__ void wait_loads(f32x4_ (&xv)[XI])
 }
 // __builtin_amdgcn_perm(a, b, sel): result byte i = byte sel[i] of {b: 0-3, a: 4-7}
 #define GAT_PERM(a, b, sel) __builtin_amdgcn_perm((a), (b), (sel))
+#define GAT_P2(hi_, lo_) GAT_PERM(hi_, lo_, 0x07060302u) // two bf16: {low half: top half of lo_, high half: top half of hi_}
 
 // ---- consumer fragment fetches -------------------------------------------------------------------
 // All LDS reads of the MFMA loop are inline assembly, issued D = 2..4 k-slices ahead of their use into a
@@ -106,7 +107,13 @@ __device__ __forceinline__ void wait_loads(f32x4_ (&xv)[XI])
 // {x*hi, x*mid, x*lo, 0}, a slice covers 4 samples (two adjacent ones per 32-lane half) -- half the MFMAs, and
 // the fragments come ready-made from LDS: X = {x|x, x|0} per sample, W = {hi|mid, lo|0} per sample, one 16-byte read
 // fetches a sample pair; the chip signs of the two samples come as two mask dwords.
-template <int RT, bool X1>
+// XM = kMbTwo (int16 samples, two exact bf16 terms; gat_internal.h MbMode): the k-slots of a 32-lane half are a STREAM -- 5 products
+// per sample {a h, a m, a l, b h, b m} -- cut into slices of 8: a slice's X and W fragments are 16 consecutive bytes of the
+// slot-ordered rows the producers write (no assembly here), 8 samples per half every 5 slices.  Slice j (mod 5) of a period that
+// starts at sample sb covers the samples {sb, sb+1}, {sb+1, sb+2, sb+3}, {sb+3, sb+4}, {sb+4, sb+5, sb+6}, {sb+6, sb+7}: it
+// fetches their chip-sign words (two with one ds_read2_b32, a third with a ds_read_b32 for j = 1, 3) and lays them onto the
+// fragment's four dwords (mfma_apply).
+template <int RT, int XM>
 struct FragSet {
     u32x4 w;
     unsigned m;
@@ -116,7 +123,7 @@ struct FragSet {
 #endif
 };
 template <int RT>
-struct FragSet<RT, true> {
+struct FragSet<RT, kMbOne> {
     u32x4 w;
     u32x2 m;
     u32x4 xa[RT];
@@ -124,15 +131,41 @@ struct FragSet<RT, true> {
     u32x2 wl;
 #endif
 };
-template <int J, int RT, bool X1>
-__device__ __forceinline__ void frag_issue(FragSet<RT, X1> &s, unsigned w_addr, unsigned r_addr, const unsigned (&x_addr)[RT])
+template <int RT>
+struct FragSet<RT, kMbTwo> {
+    u32x4 w;
+    u32x2 m;
+    unsigned m3;
+    u32x4 xa[RT];
+};
+// LDS reads of slice J (they count in lgkmcnt)
+template <int RT, int XM>
+constexpr int frag_reads(int J) { return XM == kMbTwo ? 2 + RT + ((J % 5 == 1 || J % 5 == 3) ? 1 : 0) : 2 + RT; }
+// ... of the n slices issued after slice J (slice numbers wrap at NM: the cross-step pipeline runs into the next step)
+template <int RT, int XM>
+constexpr int frag_newer(int J, int n, int NM)
+{
+    int c = 0;
+    for (int i = 1; i <= n; ++i) c += frag_reads<RT, XM>((J + i) % NM);
+    return c;
+}
+template <int J, int RT, int XM>
+__device__ __forceinline__ void frag_issue(FragSet<RT, XM> &s, unsigned w_addr, unsigned r_addr, const unsigned (&x_addr)[RT])
 {
 #if defined(GAT_ABLATE) && (GAT_ABLATE & 64) // diagnostic: half the W fragment bytes (results wrong)
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(s.wl) : "v"(w_addr), "n"(J * 16));
 #else
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(s.w) : "v"(w_addr), "n"(J * 16));
 #endif
-    if constexpr (X1) {
+    if constexpr (XM == kMbTwo) {
+        constexpr int j = J % 5, sb = 8 * (J / 5);
+        constexpr int o0 = sb + (j == 0 ? 0 : j == 1 ? 1 : j == 2 ? 3 : j == 3 ? 4 : 6); // first sample of the slice
+        asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(s.m) : "v"(r_addr), "n"(o0), "n"(o0 + 1));
+        if constexpr (j == 1 || j == 3) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(s.m3) : "v"(r_addr), "n"((o0 + 2) * 4));
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(s.xa[t]) : "v"(x_addr[t]), "n"(J * 16));
+    } else if constexpr (XM == kMbOne) {
         asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(s.m) : "v"(r_addr), "n"(2 * J), "n"(2 * J + 1));
 #pragma unroll
         for (int t = 0; t < RT; ++t)
@@ -144,12 +177,21 @@ __device__ __forceinline__ void frag_issue(FragSet<RT, X1> &s, unsigned w_addr, 
             asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(s.xa[t]) : "v"(x_addr[t]), "n"(J * 8));
     }
 }
-template <int RT, bool X1, int NEWER> // NEWER: reads issued after this set's that may stay in flight
-__device__ __forceinline__ void frag_wait(FragSet<RT, X1> &s)
+template <int RT, int XM, int NEWER> // NEWER: reads issued after this set's that may stay in flight
+__device__ __forceinline__ void frag_wait(FragSet<RT, XM> &s)
 {
     static_assert(RT == 1 || RT == 2 || RT == 4, "row tiles");
     static_assert(NEWER <= 15, "lgkmcnt is a 4-bit counter");
-    if constexpr (RT == 1)
+    if constexpr (XM == kMbTwo) {
+        if constexpr (RT == 1)
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(s.w), "+v"(s.m), "+v"(s.m3), "+v"(s.xa[0]) : "n"(NEWER));
+        else if constexpr (RT == 2)
+            asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(s.w), "+v"(s.m), "+v"(s.m3), "+v"(s.xa[0]), "+v"(s.xa[1]) : "n"(NEWER));
+        else
+            asm volatile("s_waitcnt lgkmcnt(%7)"
+                         : "+v"(s.w), "+v"(s.m), "+v"(s.m3), "+v"(s.xa[0]), "+v"(s.xa[1]), "+v"(s.xa[2]), "+v"(s.xa[3])
+                         : "n"(NEWER));
+    } else if constexpr (RT == 1)
         asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(s.w), "+v"(s.m), "+v"(s.xa[0]) : "n"(NEWER));
     else if constexpr (RT == 2)
         asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(s.w), "+v"(s.m), "+v"(s.xa[0]), "+v"(s.xa[1]) : "n"(NEWER));
@@ -158,37 +200,61 @@ __device__ __forceinline__ void frag_wait(FragSet<RT, X1> &s)
                      : "+v"(s.w), "+v"(s.m), "+v"(s.xa[0]), "+v"(s.xa[1]), "+v"(s.xa[2]), "+v"(s.xa[3])
                      : "n"(NEWER));
 }
-// fetch distance in slices: as deep as the 4-bit lgkmcnt allows (2 + RT reads per slice), at most 4
-template <int RT>
-constexpr int frag_depth() { return (15 / (2 + RT)) < 4 ? (15 / (2 + RT)) : 4; }
+// fetch distance in slices: as deep as the 4-bit lgkmcnt allows (2 + RT reads per slice, 3 + RT at most on the two-term path), at most 4
+template <int RT, int XM = kMbThree>
+constexpr int frag_depth()
+{
+    constexpr int per = XM == kMbTwo ? 3 + RT : 2 + RT;
+    return (15 / per) < 4 ? (15 / per) : 4;
+}
 
-template <int J, int RT, bool X1>
-__device__ __forceinline__ void mfma_apply(f32x16 (&acc)[RT == 1 ? 2 : RT], FragSet<RT, X1> &cur);
+template <int RT, int XM>
+using FragRing = FragSet<RT, XM>[frag_depth<RT, XM>() + 1]; // fragment sets in rotation
 
-template <int J, int NM, int RT, bool X1>
-__device__ __forceinline__ void mfma_slice(f32x16 (&acc)[RT == 1 ? 2 : RT], FragSet<RT, X1> (&fs)[frag_depth<RT>() + 1], unsigned w_addr,
+template <int J, int RT, int XM>
+__device__ __forceinline__ void mfma_apply(f32x16 (&acc)[RT == 1 ? 2 : RT], FragSet<RT, XM> &cur);
+
+template <int J, int NM, int RT, int XM>
+__device__ __forceinline__ void mfma_slice(f32x16 (&acc)[RT == 1 ? 2 : RT], FragRing<RT, XM> &fs, unsigned w_addr,
                                            unsigned r_addr, const unsigned (&x_addr)[RT])
 {
-    constexpr int D = frag_depth<RT>();
-    FragSet<RT, X1> &cur = fs[J % (D + 1)];
+    constexpr int D = frag_depth<RT, XM>();
+    FragSet<RT, XM> &cur = fs[J % (D + 1)];
     // slices J+1 .. J+D-1 (those that exist) were issued after this one and may stay in flight
     constexpr int newer = (NM - 1 - J) < (D - 1) ? (NM - 1 - J) : (D - 1);
-    frag_wait<RT, X1, newer *(2 + RT)>(cur);
-    if constexpr (J + D < NM) frag_issue<J + D, RT, X1>(fs[(J + D) % (D + 1)], w_addr, r_addr, x_addr);
-    mfma_apply<J, RT, X1>(acc, cur);
+    frag_wait<RT, XM, frag_newer<RT, XM>(J, newer, NM)>(cur);
+    if constexpr (J + D < NM) frag_issue<J + D, RT, XM>(fs[(J + D) % (D + 1)], w_addr, r_addr, x_addr);
+    mfma_apply<J, RT, XM>(acc, cur);
 }
 // the arithmetic of one k-slice: chip signs onto W, the {a, a} halves of the X fragments, RT MFMAs
-template <int J, int RT, bool X1>
-__device__ __forceinline__ void mfma_apply(f32x16 (&acc)[RT == 1 ? 2 : RT], FragSet<RT, X1> &cur)
+template <int J, int RT, int XM>
+__device__ __forceinline__ void mfma_apply(f32x16 (&acc)[RT == 1 ? 2 : RT], FragSet<RT, XM> &cur)
 {
+    constexpr bool X1 = XM == kMbOne;
 #if defined(GAT_ABLATE) && (GAT_ABLATE & 128) // diagnostic (results wrong): the arithmetic of two k-slices out of three -- what a
-    if constexpr (!X1 && J % 3 == 2) return;   // 2-term split of the SAMPLE operand (5 products, 3 samples per MFMA) would issue
+    if constexpr (XM == kMbThree && J % 3 == 2) return;   // 2-term split of the SAMPLE operand (5 products, 3 samples per MFMA) would issue
 #endif
     u32x4 w = cur.w;
 #if defined(GAT_ABLATE) && (GAT_ABLATE & 64)
-    if constexpr (!X1) w = u32x4{cur.wl[0], cur.wl[1], cur.wl[0], cur.wl[1]};
+    if constexpr (XM == kMbThree) w = u32x4{cur.wl[0], cur.wl[1], cur.wl[0], cur.wl[1]};
 #endif
-    if constexpr (X1) { // chip signs of the lane's two samples
+    if constexpr (XM == kMbTwo) {
+        // chip signs of the slice's two or three samples onto the dwords (= slot pairs) of the W fragment; LH(a, b) = low half of
+        // a | high half of b, where a sample ends inside a dword
+        const unsigned A = cur.m[0], B = cur.m[1], C = cur.m3;
+        constexpr int j = J % 5;
+        auto LH = [](unsigned a_, unsigned b_) { return GAT_PERM(b_, a_, 0x07060100u); };
+        if constexpr (j == 0) { w[0] ^= A; w[1] ^= A; w[2] ^= LH(A, B); w[3] ^= B; }          // samples 0 0 0 0 0 1 1 1
+        else if constexpr (j == 1) { w[0] ^= A; w[1] ^= B; w[2] ^= B; w[3] ^= LH(B, C); }      // 1 1 2 2 2 2 2 3
+        else if constexpr (j == 2) { w[0] ^= A; w[1] ^= A; w[2] ^= B; w[3] ^= B; }             // 3 3 3 3 4 4 4 4
+        else if constexpr (j == 3) { w[0] ^= LH(A, B); w[1] ^= B; w[2] ^= B; w[3] ^= C; }      // 4 5 5 5 5 5 6 6
+        else { w[0] ^= A; w[1] ^= LH(A, B); w[2] ^= B; w[3] ^= B; }                            // 6 6 6 7 7 7 7 7
+        const bf16x8 bw = __builtin_bit_cast(bf16x8, w);
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+            acc[RT == 1 ? (J & 1) : t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.xa[t]), bw,
+                                                                             acc[RT == 1 ? (J & 1) : t], 0, 0, 0);
+    } else if constexpr (X1) { // chip signs of the lane's two samples
         const unsigned m0 = cur.m[0], m1 = cur.m[1];
         w[0] ^= m0;
         w[1] ^= m0;
@@ -231,17 +297,17 @@ __device__ __forceinline__ void mfma_apply(f32x16 (&acc)[RT == 1 ? 2 : RT], Frag
         }
     }
 }
-template <int NM, int RT, bool X1, int... J>
+template <int NM, int RT, int XM, int... J>
 __device__ __forceinline__ void mfma_step(f32x16 (&acc)[RT == 1 ? 2 : RT], unsigned w_addr, unsigned r_addr, const unsigned (&x_addr)[RT],
                                           std::integer_sequence<int, J...>)
 {
-    constexpr int D = frag_depth<RT>();
-    FragSet<RT, X1> fs[D + 1];
-    frag_issue<0, RT, X1>(fs[0], w_addr, r_addr, x_addr);
-    if constexpr (NM > 1 && D > 1) frag_issue<1, RT, X1>(fs[1], w_addr, r_addr, x_addr);
-    if constexpr (NM > 2 && D > 2) frag_issue<2, RT, X1>(fs[2], w_addr, r_addr, x_addr);
-    if constexpr (NM > 3 && D > 3) frag_issue<3, RT, X1>(fs[3], w_addr, r_addr, x_addr);
-    (mfma_slice<J, NM, RT, X1>(acc, fs, w_addr, r_addr, x_addr), ...);
+    constexpr int D = frag_depth<RT, XM>();
+    FragSet<RT, XM> fs[D + 1];
+    frag_issue<0, RT, XM>(fs[0], w_addr, r_addr, x_addr);
+    if constexpr (NM > 1 && D > 1) frag_issue<1, RT, XM>(fs[1], w_addr, r_addr, x_addr);
+    if constexpr (NM > 2 && D > 2) frag_issue<2, RT, XM>(fs[2], w_addr, r_addr, x_addr);
+    if constexpr (NM > 3 && D > 3) frag_issue<3, RT, XM>(fs[3], w_addr, r_addr, x_addr);
+    (mfma_slice<J, NM, RT, XM>(acc, fs, w_addr, r_addr, x_addr), ...);
 }
 
 // ---- k-slices pipelined ACROSS the step barrier (round 3) ---------------------------------------------------------
@@ -252,15 +318,15 @@ __device__ __forceinline__ void mfma_step(f32x16 (&acc)[RT == 1 ? 2 : RT], unsig
 // the next step -- from the other buffer, complete at the barrier -- are already on their way.  R = ring position of the
 // step's slice 0 (the ring has D + 1 sets and a step NM slices: R advances by NM mod (D + 1) per step).  There are always
 // exactly D - 1 newer slices in flight at a wait (after the last step too: its "next step" reads fetch stale data nobody uses).
-template <int J, int NM, int RT, bool X1, int R>
-__device__ __forceinline__ void xstep_slice(f32x16 (&acc)[RT == 1 ? 2 : RT], FragSet<RT, X1> (&fs)[frag_depth<RT>() + 1], unsigned w_addr,
+template <int J, int NM, int RT, int XM, int R>
+__device__ __forceinline__ void xstep_slice(f32x16 (&acc)[RT == 1 ? 2 : RT], FragRing<RT, XM> &fs, unsigned w_addr,
                                             unsigned r_addr, const unsigned (&x_addr)[RT], int dw, int dr, int dx)
 {
-    constexpr int D = frag_depth<RT>(), RING = D + 1;
-    FragSet<RT, X1> &cur = fs[(R + J) % RING];
-    frag_wait<RT, X1, (D - 1) * (2 + RT)>(cur);
+    constexpr int D = frag_depth<RT, XM>(), RING = D + 1;
+    FragSet<RT, XM> &cur = fs[(R + J) % RING];
+    frag_wait<RT, XM, frag_newer<RT, XM>(J, D - 1, NM)>(cur);
     if constexpr (J + D < NM) {
-        frag_issue<J + D, RT, X1>(fs[(R + J + D) % RING], w_addr, r_addr, x_addr);
+        frag_issue<J + D, RT, XM>(fs[(R + J + D) % RING], w_addr, r_addr, x_addr);
     } else {
         if constexpr (J + D == NM) { // the first fetch that belongs to the next step: this step's reads are home, then the barrier
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -269,15 +335,15 @@ __device__ __forceinline__ void xstep_slice(f32x16 (&acc)[RT == 1 ? 2 : RT], Fra
         unsigned x_next[RT]; // the other buffer: a wave-uniform distance away
 #pragma unroll
         for (int t = 0; t < RT; ++t) x_next[t] = x_addr[t] + (unsigned)dx;
-        frag_issue<J + D - NM, RT, X1>(fs[(R + J + D) % RING], w_addr + (unsigned)dw, r_addr + (unsigned)dr, x_next);
+        frag_issue<J + D - NM, RT, XM>(fs[(R + J + D) % RING], w_addr + (unsigned)dw, r_addr + (unsigned)dr, x_next);
     }
-    mfma_apply<J, RT, X1>(acc, cur);
+    mfma_apply<J, RT, XM>(acc, cur);
 }
-template <int NM, int RT, bool X1, int R, int... J>
-__device__ __forceinline__ void xstep(f32x16 (&acc)[RT == 1 ? 2 : RT], FragSet<RT, X1> (&fs)[frag_depth<RT>() + 1], unsigned w_addr,
+template <int NM, int RT, int XM, int R, int... J>
+__device__ __forceinline__ void xstep(f32x16 (&acc)[RT == 1 ? 2 : RT], FragRing<RT, XM> &fs, unsigned w_addr,
                                       unsigned r_addr, const unsigned (&x_addr)[RT], int dw, int dr, int dx, std::integer_sequence<int, J...>)
 {
-    (xstep_slice<J, NM, RT, X1, R>(acc, fs, w_addr, r_addr, x_addr, dw, dr, dx), ...);
+    (xstep_slice<J, NM, RT, XM, R>(acc, fs, w_addr, r_addr, x_addr, dw, dr, dx), ...);
 }
 
 struct ChanInfoB { // per channel slot of the workgroup, in LDS
@@ -298,23 +364,30 @@ constexpr int tile_samples(int RT, int NCT) { return mb_tile_samples(RT, NCT); }
 // producers (HBM loads two steps ahead, bf16 splits, carriers, code replica) -- their long dependent
 // chains (FP64 code phase, sincos, split) hide behind each other and behind the matrix pipe.
 // Double-buffered LDS, one s_barrier per step of T samples.
-template <int RT, int NCT, int FMT>
+template <int RT, int NCT, int FMT, int XM>
 __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const MfArgs a)
 {
+    static_assert((XM == kMbOne) == (FMT == GAT_LAYOUT_INTERLEAVED_I8), "one term: int8 samples, and only they");
+    static_assert(XM != kMbTwo || FMT == GAT_LAYOUT_INTERLEAVED_I16, "two terms: int16 samples");
     constexpr int kMbThreads = mb_threads(RT, NCT);
     constexpr int T = tile_samples(RT, NCT);
     constexpr int NCW = consumer_waves(RT, NCT);
     constexpr int WPT = NCW / NCT; // consumer waves per channel tile (they split the step's samples)
     constexpr int SW = T / WPT;    // samples per consumer wave and step
-    constexpr bool X1 = FMT == GAT_LAYOUT_INTERLEAVED_I8; // samples exact in one bf16 term: 4 samples per MFMA
+    constexpr bool X1 = XM == kMbOne; // samples exact in one bf16 term: 4 samples per MFMA
+    constexpr bool X2 = XM == kMbTwo; // ... in two: 16 samples per 5 MFMAs (the slot stream, FragSet above)
     constexpr int SPS = X1 ? 4 : 2; // samples per k-slice
-    constexpr int NM = SW / SPS;   // MFMA k-slices per consumer wave and step (two sample streams)
+    constexpr int NM = X2 ? 5 * (SW / 2) / 8 : SW / SPS; // MFMA k-slices per consumer wave and step (two sample streams)
+    static_assert(!X2 || (SW / 2) % 8 == 0, "two-term stream: 8 samples per half and period");
     // A producer item = one channel slot x TWO samples OS apart.  3-term path: samples q and q + T/2, so that the 64 lanes
     // of a wave (consecutive q) store CONSECUTIVE 16-byte W entries and consecutive replica words (round 2 owned the
     // adjacent samples 2q, 2q + 1: every W store 32 bytes from its neighbour's -- every other bank group, 2-way conflicts,
     // SQ_LDS_BANK_CONFLICT 24.6 % of SQ_LDS_IDX_ACTIVE at configs[4]; 18.3 % now, profiles/r03).  1-term path (int8): the
-    // consumers read adjacent sample pairs as one 16-byte entry, the item keeps 2q, 2q + 1.
-    constexpr int OS = X1 ? 1 : T / 2;
+    // consumers read adjacent sample pairs as one 16-byte entry, the item keeps 2q, 2q + 1.  2-term path: an item is FOUR
+    // adjacent samples 4q .. 4q + 3 (40 bytes of a slot-ordered row, five 8-byte stores), rotated one sample at a time.
+    constexpr int OS = XM == kMbThree ? T / 2 : 1;
+    constexpr int IS = X2 ? 4 : 2;    // samples per producer item
+    constexpr int RB = mb_two_row_bytes(T); // 2-term path: bytes per X / W row (10 per sample, slot order)
     // LDS row strides in entries.  3-term: X 8 B / W 16 B per sample, odd (32 planes x one sample = 32 distinct
     // bank pairs).  1-term: X 8 B / W 8 B per sample, read in 16-byte pairs: even, rows 4 banks apart.
     constexpr int XS = X1 ? T + 2 : T + 1;
@@ -338,9 +411,9 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     const int wrows = 2 * nslots + 1; // + one row of zeros for dead columns
     const int RS = a.rep_stride;
     ChanInfoB *s_chan = reinterpret_cast<ChanInfoB *>(smem);
-    u32x2 *s_x = reinterpret_cast<u32x2 *>(smem + kHeader);                 // [2][RT*32][XS]
-    u32x2 *s_w = s_x + 2 * RT * 32 * XS;                                    // [2][wrows][WS] entries of WE u32x2
-    unsigned *s_rep = reinterpret_cast<unsigned *>(s_w + 2 * wrows * WS * WE); // [2][nslots][RS]
+    u32x2 *s_x = reinterpret_cast<u32x2 *>(smem + kHeader);                 // [2][RT*32][XS]   (2-term: [2][RT*32] rows of RB bytes)
+    u32x2 *s_w = X2 ? s_x + 2 * RT * 32 * (RB / 8) : s_x + 2 * RT * 32 * XS; // [2][wrows][WS] entries of WE u32x2 (2-term: [2][wrows] rows of RB bytes)
+    unsigned *s_rep = reinterpret_cast<unsigned *>(X2 ? s_w + 2 * wrows * (RB / 8) : s_w + 2 * wrows * WS * WE); // [2][nslots][RS]
     unsigned *s_code = s_rep + ((2 * nslots * RS + 3) & ~3); // [nslots][code_bits_stride] sign-bit tables
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -387,8 +460,13 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         s_chan[tid] = ci;
     }
     // the zero rows of both carrier buffers (read by dead columns, never written again)
-    for (int e = tid; e < 2 * WS * WE; e += kMbThreads)
-        s_w[((e / (WS * WE)) * wrows * WS + 2 * nslots * WS) * WE + e % (WS * WE)] = u32x2{0u, 0u};
+    if constexpr (X2) {
+        for (int e = tid; e < 2 * (RB / 8); e += kMbThreads)
+            s_w[((e / (RB / 8)) * wrows + 2 * nslots) * (RB / 8) + e % (RB / 8)] = u32x2{0u, 0u};
+    } else {
+        for (int e = tid; e < 2 * WS * WE; e += kMbThreads)
+            s_w[((e / (WS * WE)) * wrows * WS + 2 * nslots * WS) * WE + e % (WS * WE)] = u32x2{0u, 0u};
+    }
     __syncthreads();
     { // sign-bit tables of this workgroup's channels (the producers must not touch global memory for chips:
       // vector-memory returns are in order, a table gather would wait for the sample prefetch in flight)
@@ -417,7 +495,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     const char *re_base = reinterpret_cast<const char *>(a.re) + (PLANAR ? 4ll : (long long)BYTES) * (long long)base;
     // Groups per thread are weighted by role so that all producer waves finish together: the waves that
     // own a carrier / replica item (the first item_waves ones) take few sample groups, the others up to 4.
-    const int n_items = nslots * (T / 2);
+    const int n_items = nslots * (T / IS);
     const int item_waves = (n_items + 63) >> 6;
     const int niw = item_waves * 64, tn = PT - niw;            // item / non-item producer threads
     const int xi_other = tn > 0 ? min(4, (NG + tn - 1) / tn) : 0;
@@ -454,12 +532,37 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         if (st >= s_begin + 2) return;
 #endif
         const int nb = st * T;
-        u32x2 *xb = s_x + buf * RT * 32 * XS;
+        u32x2 *xb = X2 ? s_x + buf * RT * 32 * (RB / 8) : s_x + buf * RT * 32 * XS;
 #pragma unroll
         for (int it = 0; it < XI; ++it) {
             const int id = g_first + it * g_stride;
             if (id >= NG) continue;
             const int row = id / QPR, q = id % QPR;
+            if constexpr (X2) {
+                // int16 v = a + b exactly, a = v & ~255 (a multiple of 256 in [-32768, 32512]: 8 significant bits), b = v & 255
+                // (0 .. 255): both exact in bf16, the top halves of their float patterns.  Slot order of a sample: a a a b b.
+                unsigned ar[4], br[4], ai[4], bi[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int w = (int)__float_as_uint(xv[it][u]); // {re: low half, im: high half}
+                    const int re = (int)(short)(w & 0xffff), im = w >> 16;
+                    ar[u] = __float_as_uint((float)(re & ~0xff));
+                    br[u] = __float_as_uint((float)(re & 0xff));
+                    ai[u] = __float_as_uint((float)(im & ~0xff));
+                    bi[u] = __float_as_uint((float)(im & 0xff));
+                }
+                auto put4 = [&](int plane, const unsigned (&A)[4], const unsigned (&B)[4]) {
+                    u32x2 *d = reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned char *>(xb) + plane * RB + 40 * q);
+                    d[0] = u32x2{GAT_P2(A[0], A[0]), GAT_P2(B[0], A[0])};
+                    d[1] = u32x2{GAT_P2(A[1], B[0]), GAT_P2(A[1], A[1])};
+                    d[2] = u32x2{GAT_P2(B[1], B[1]), GAT_P2(A[2], A[2])};
+                    d[3] = u32x2{GAT_P2(B[2], A[2]), GAT_P2(A[3], B[2])};
+                    d[4] = u32x2{GAT_P2(A[3], A[3]), GAT_P2(B[3], B[3])};
+                };
+                put4(2 * row, ar, br);
+                put4(2 * row + 1, ai, bi);
+                continue;
+            }
             // {a = hi | mid << 16, b = lo | lo << 16} of one value into the LDS row of its plane
             auto put = [&](int plane, int rel, float v) {
                 if constexpr (X1) { // an int8 value is exact in bf16: {x|x, x|0}
@@ -539,13 +642,13 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     // carries its phasor and code index from step to step: one complex rotation by e^{j 2 pi T step}
     // instead of an FP64 range reduction + sincos; re-anchored in FP64 every kReanchor steps.
     float car_r = 0.f, car_i = 0.f;
-    int rep_ip = 0, rep_t = 0;
-    const int item_slot = ptid / (T / 2), item_q = ptid % (T / 2);
-    const int item_s0 = X1 ? 2 * item_q : item_q; // the item's first sample (step-relative); its second one is OS further
+    int rep_ip = 0, rep_t = 0, rep_ip2 = 0, rep_t2 = 0;
+    const int item_slot = ptid / (T / IS), item_q = ptid % (T / IS);
+    const int item_s0 = X2 ? 4 * item_q : X1 ? 2 * item_q : item_q; // the item's first sample (step-relative); its second one is OS further
     const bool have_item = producer && item_slot < nslots;
     auto produce = [&](int st, int buf, bool first) { // everything of step st except the samples
         const int nb = st * T;
-        u32x2 *wb = s_w + buf * wrows * WS * WE;
+        u32x2 *wb = X2 ? s_w + buf * wrows * (RB / 8) : s_w + buf * wrows * WS * WE;
         unsigned *rb = s_rep + buf * nslots * RS;
         const unsigned *rprev = s_rep + (buf ^ 1) * nslots * RS;
         const ChanInfoB c = s_chan[have_item ? item_slot : 0]; // fetched first: in flight behind the overlap copy below
@@ -571,6 +674,9 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
 #endif
         gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, nb, span + item_s0, OS, span + T,
                  anchor || !c.inc_ok, rep_ip, rep_t);
+        if constexpr (X2)
+            gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, nb, span + item_s0 + 2, 1, span + T,
+                     anchor || !c.inc_ok, rep_ip2, rep_t2);
 #if defined(GAT_ABLATE) && (GAT_ABLATE & 2) // diagnostic: carrier fragments only in the first step
         if (!first) return;
 #endif
@@ -584,6 +690,31 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         }
         car_r = cr;
         car_i = ci;
+        if constexpr (X2) { // slot order of a sample: h m l h m  (against a a a b b)
+            unsigned ch[4], cm[4], cl[4], sh[4], sm[4], sl[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const Split3 sc = split3(cr), ss = split3(-ci);
+                ch[u] = sc.v; cm[u] = sc.r; cl[u] = sc.r2;
+                sh[u] = ss.v; sm[u] = ss.r; sl[u] = ss.r2;
+                if (u < 3) {
+                    const float tr = __builtin_fmaf(cr, c.wr, -(ci * c.wi));
+                    ci = __builtin_fmaf(cr, c.wi, ci * c.wr);
+                    cr = tr;
+                }
+            }
+            auto put4 = [&](int wrow, const unsigned (&H)[4], const unsigned (&M)[4], const unsigned (&Lo)[4]) {
+                u32x2 *d = reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned char *>(wb) + wrow * RB + 40 * item_q);
+                d[0] = u32x2{GAT_P2(M[0], H[0]), GAT_P2(H[0], Lo[0])};
+                d[1] = u32x2{GAT_P2(H[1], M[0]), GAT_P2(Lo[1], M[1])};
+                d[2] = u32x2{GAT_P2(M[1], H[1]), GAT_P2(M[2], H[2])};
+                d[3] = u32x2{GAT_P2(H[2], Lo[2]), GAT_P2(H[3], M[2])};
+                d[4] = u32x2{GAT_P2(Lo[3], M[3]), GAT_P2(M[3], H[3])};
+            };
+            put4(2 * item_slot, ch, cm, cl);
+            put4(2 * item_slot + 1, sh, sm, sl);
+            return;
+        }
         u32x2 *w_re = wb + ((2 * item_slot) * WS + item_s0) * WE;
         u32x2 *w_im = w_re + WS * WE;
 #pragma unroll
@@ -621,9 +752,13 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     const ChanInfoB my = s_chan[slot_c];
     const bool live_col = in_range && my.valid;
     const int col0 = sub * SW + h * (SW / 2); // first sample (step-relative) of this lane's stream
-    const int w_off = (live_col ? 2 * slot_c + comp : 2 * nslots) * WS + col0;
+    // (2-term: w_off / x_off in BYTES; else in entries)
+    const int w_off = X2 ? (live_col ? 2 * slot_c + comp : 2 * nslots) * RB + 10 * col0 : (live_col ? 2 * slot_c + comp : 2 * nslots) * WS + col0;
     const int r_off = slot_c * RS + (a.shifts[l] - a.shifts[0]) + col0;
-    const int x_off = r * XS + col0;
+    const int x_off = X2 ? r * RB + 10 * col0 : r * XS + col0;
+    // bytes of one buffer's X rows / W rows
+    constexpr int XBUF = X2 ? RT * 32 * RB : 8 * RT * 32 * XS, XTILE = X2 ? 32 * RB : 8 * 32 * XS, XU = X2 ? 1 : 8;
+    const int WBUF = X2 ? wrows * RB : 8 * WE * wrows * WS, WU = X2 ? 1 : 8 * WE;
 
     // the consumers' few vector instructions per slice must not queue behind the producers' streams
     if (!producer) __builtin_amdgcn_s_setprio(3);
@@ -643,10 +778,10 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
 #endif
         unsigned x_addr[RT];
 #pragma unroll
-        for (int t = 0; t < RT; ++t) x_addr[t] = lds_x + 8u * (unsigned)((buf * RT * 32 + t * 32) * XS + x_off);
-        const unsigned w_addr = lds_w + 8u * WE * (unsigned)(buf * wrows * WS + w_off);
+        for (int t = 0; t < RT; ++t) x_addr[t] = lds_x + (unsigned)(buf * XBUF + t * XTILE + XU * x_off);
+        const unsigned w_addr = lds_w + (unsigned)(buf * WBUF + WU * w_off);
         const unsigned r_addr = lds_r + 4u * (unsigned)(buf * nslots * RS + r_off);
-        mfma_step<NM, RT, X1>(acc, w_addr, r_addr, x_addr, std::make_integer_sequence<int, NM>{});
+        mfma_step<NM, RT, XM>(acc, w_addr, r_addr, x_addr, std::make_integer_sequence<int, NM>{});
     };
 
     // ---- pipeline ----------------------------------------------------------------------------------
@@ -748,28 +883,28 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         // unrolled (each with its position as a constant: no run-time choice between code copies -- a merge of copies
         // would make the register allocator move fragment registers that are still being loaded); what is left over at the
         // end (fewer than RING steps) runs unpipelined.
-        constexpr int D = frag_depth<RT>(), RING = D + 1;
+        constexpr int D = frag_depth<RT, XM>(), RING = D + 1;
         static_assert(NM >= D, "a step holds at least as many slices as the fetch distance");
         const int nsteps = s_end - s_begin, groups = nsteps > 0 ? nsteps / RING : 0;
         // this lane's stream addresses in the CURRENT buffer only; the other buffer is a wave-uniform distance away (its
         // addresses are formed when the look-ahead fetches are issued: six persistent registers less)
         unsigned xa_c[RT];
 #pragma unroll
-        for (int t = 0; t < RT; ++t) xa_c[t] = lds_x + 8u * (unsigned)((t * 32) * XS + x_off);
-        unsigned wa_c = lds_w + 8u * WE * (unsigned)w_off;
+        for (int t = 0; t < RT; ++t) xa_c[t] = lds_x + (unsigned)(t * XTILE + XU * x_off);
+        unsigned wa_c = lds_w + (unsigned)(WU * w_off);
         unsigned ra_c = lds_r + 4u * (unsigned)r_off;
-        int dx = 8 * (RT * 32 * XS), dw = __builtin_amdgcn_readfirstlane(8 * WE * (wrows * WS)),
+        int dx = XBUF, dw = __builtin_amdgcn_readfirstlane(WBUF),
             dr = __builtin_amdgcn_readfirstlane(4 * (nslots * RS)); // bytes from the current buffer to the other one (sign flips per step)
         __syncthreads(); // the first step's buffer is complete
         if (groups > 0) {
-            FragSet<RT, X1> fs[RING];
-            frag_issue<0, RT, X1>(fs[0], wa_c, ra_c, xa_c);
-            if constexpr (D > 1) frag_issue<1, RT, X1>(fs[1], wa_c, ra_c, xa_c);
-            if constexpr (D > 2) frag_issue<2, RT, X1>(fs[2], wa_c, ra_c, xa_c);
-            if constexpr (D > 3) frag_issue<3, RT, X1>(fs[3], wa_c, ra_c, xa_c);
+            FragSet<RT, XM> fs[RING];
+            frag_issue<0, RT, XM>(fs[0], wa_c, ra_c, xa_c);
+            if constexpr (D > 1) frag_issue<1, RT, XM>(fs[1], wa_c, ra_c, xa_c);
+            if constexpr (D > 2) frag_issue<2, RT, XM>(fs[2], wa_c, ra_c, xa_c);
+            if constexpr (D > 3) frag_issue<3, RT, XM>(fs[3], wa_c, ra_c, xa_c);
             auto one = [&](auto r_c) {
                 constexpr int R = decltype(r_c)::value;
-                xstep<NM, RT, X1, R>(acc, fs, wa_c, ra_c, xa_c, dw, dr, dx, std::make_integer_sequence<int, NM>{});
+                xstep<NM, RT, XM, R>(acc, fs, wa_c, ra_c, xa_c, dw, dr, dx, std::make_integer_sequence<int, NM>{});
                 wa_c += (unsigned)dw; // the buffers change roles
                 ra_c += (unsigned)dr;
 #pragma unroll
@@ -863,17 +998,37 @@ int mfma_bf16_producer_threads(int rt, int nct) { return mb_threads(rt, nct) - 6
 
 int mfma_bf16_slots(int nct, int L, int K) { return mb_slots(nct, L, K); }
 
-size_t mfma_bf16_lds_bytes(int rt, int nct, int fmt, int nslots, int rep_stride, int code_bits_stride)
+size_t mfma_bf16_lds_bytes(int rt, int nct, int fmt, int nslots, int rep_stride, int code_bits_stride, int mode)
 {
     static_assert(sizeof(ChanInfoB) * kMbMaxSlots <= kHeader, "channel table must fit the header");
-    return mb_lds_bytes(rt, nct, fmt, nslots, rep_stride, code_bits_stride);
+    return mb_lds_bytes(rt, nct, fmt, nslots, rep_stride, code_bits_stride, mode);
 }
+int mfma_bf16_mode(int rt, int nct, int fmt, bool force_three) { return mb_mode(rt, nct, fmt, force_three); }
+
+namespace {
+// the operand split of the launch: the host's a.mb_mode, which for int16 may be the three-term path on request
+template <int RT, int NCT, int F>
+hipError_t launch_one(const MfArgs &a, dim3 g, dim3 blk, unsigned lds_bytes, hipStream_t s)
+{
+    constexpr int natural = F == GAT_LAYOUT_INTERLEAVED_I8 ? kMbOne : kMbThree;
+    if constexpr (mb_mode(RT, NCT, F) == kMbTwo) {
+        if (a.mb_mode == kMbTwo) {
+            hipLaunchKernelGGL((mfma_bf16_kernel<RT, NCT, F, kMbTwo>), g, blk, lds_bytes, s, a);
+            return hipSuccess;
+        }
+    }
+    if (a.mb_mode != natural) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((mfma_bf16_kernel<RT, NCT, F, natural>), g, blk, lds_bytes, s, a);
+    return hipSuccess;
+}
+} // namespace
 
 hipError_t launch_mfma_bf16(const MfArgs &a, int rt, int nct, int fmt, unsigned grid, unsigned lds_bytes, hipStream_t s)
 {
     const dim3 g(grid), blk(mb_threads(rt, nct));
+    hipError_t e = hipSuccess;
 #define GAT_MB1(RT_, NCT_, F_) \
-    case (F_ * 8 + RT_) * 8 + NCT_: hipLaunchKernelGGL((mfma_bf16_kernel<RT_, NCT_, F_>), g, blk, lds_bytes, s, a); break;
+    case (F_ * 8 + RT_) * 8 + NCT_: e = launch_one<RT_, NCT_, F_>(a, g, blk, lds_bytes, s); break;
 #define GAT_MB(F_)                                                                                                    \
     GAT_MB1(1, 1, F_) GAT_MB1(1, 2, F_) GAT_MB1(1, 4, F_) GAT_MB1(2, 1, F_) GAT_MB1(2, 2, F_) GAT_MB1(2, 4, F_) GAT_MB1(4, 2, F_) \
         GAT_MB1(4, 4, F_)
@@ -886,7 +1041,7 @@ hipError_t launch_mfma_bf16(const MfArgs &a, int rt, int nct, int fmt, unsigned 
     }
 #undef GAT_MB
 #undef GAT_MB1
-    return hipGetLastError();
+    return e != hipSuccess ? e : hipGetLastError();
 }
 
 } // namespace gat

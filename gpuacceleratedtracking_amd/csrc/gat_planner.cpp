@@ -129,7 +129,7 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
                 const int ns = mfma_bf16_slots(n, L, K);
                 // at most one (slot, sample pair) item per producer thread
                 if (ns * T / 2 > mfma_bf16_producer_threads(rt, n) || ns > mfma_bf16_max_slots()) continue;
-                if (mfma_bf16_lds_bytes(rt, n, fmt, ns, rs, c->code_bits_stride) <= 160 * 1024) {
+                if (mfma_bf16_lds_bytes(rt, n, fmt, ns, rs, c->code_bits_stride, mfma_bf16_mode(rt, n, fmt, c->mc_i16_terms == 3)) <= 160 * 1024) {
                     kind = 2;
                     nct_b = n;
                     nslots_b = ns;
@@ -228,7 +228,9 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
                 m.code_bits = c->d_code_bits;
                 m.zeros = c->d_zeros;
                 m.code_bits_stride = c->code_bits_stride;
-                lds = (unsigned)mfma_bf16_lds_bytes(rt, nct, fmt, m.nslots, m.rep_stride, c->code_bits_stride);
+                // int16 samples: two exact bf16 terms per value (5 products per sample), or the float path's three on request
+                m.mb_mode = mfma_bf16_mode(rt, nct, fmt, c->mc_i16_terms == 3);
+                lds = (unsigned)mfma_bf16_lds_bytes(rt, nct, fmt, m.nslots, m.rep_stride, c->code_bits_stride, m.mb_mode);
                 GAT_HIP(c, launch_mfma_bf16(m, rt, nct, fmt, (unsigned)grid_m, lds, c->stream));
             } else {
                 m.codes_in_lds = mfma_lds_bytes(nct, CT, m.rep_stride, c->code_row_stride, 1) <= 160 * 1024;
@@ -249,6 +251,7 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
             c->last.channels_per_wg = kind == 2 ? m.nslots : nct * CT;
             c->last.blocks_per_wg = 1;
             c->last.prefetch_depth = 0;
+            c->last.bf16_terms = kind == 2 ? (m.mb_mode == kMbOne ? 1 : m.mb_mode == kMbTwo ? 2 : 3) : 0;
             return GAT_OK;
         }
     }
@@ -562,6 +565,7 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
     c->last.channels_per_wg = kt;
     c->last.blocks_per_wg = (int32_t)bpw;
     c->last.prefetch_depth = cfg.depth;
+    c->last.bf16_terms = 0;
     return GAT_OK;
 }
 

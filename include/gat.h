@@ -391,6 +391,7 @@ typedef struct gat_launch_info {
     int32_t channels_per_wg; /* channels one workgroup loops over (signal held in registers / LDS meanwhile)  */
     int32_t blocks_per_wg;   /* consecutive integration blocks one workgroup loops over                       */
     int32_t prefetch_depth;  /* vector kernel: register sets of samples per wave (steps in flight); else 0      */
+    int32_t bf16_terms;      /* split-bf16 kernel: bf16 terms per sample value (1: int8, 2: int16, 3: float); else 0 */
 } gat_launch_info;
 /* struct_size = sizeof(gat_launch_info) of the CALLER's header: the struct grows at its end between versions and the
  * library copies no more than the caller has room for. */

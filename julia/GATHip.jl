@@ -85,7 +85,7 @@ struct LoopState
     prompt_power::Float64
 end
 
-# struct gat_launch_info (44 bytes): geometry of the last correlate call
+# struct gat_launch_info (48 bytes): geometry of the last correlate call
 struct LaunchInfo
     workgroups::Int32
     threads::Int32
@@ -98,6 +98,7 @@ struct LaunchInfo
     channels_per_wg::Int32
     blocks_per_wg::Int32
     prefetch_depth::Int32
+    bf16_terms::Int32
 end
 
 # struct gat_resident_config (28 bytes) / gat_resident_info (32 bytes): the resident correlator (single-block calls
@@ -174,7 +175,7 @@ set_vector_tiling(ctx::Context, max_antenna_tiles::Integer, max_channels::Intege
 set_option(ctx::Context, name::AbstractString, value::Integer) =
     check(ctx, ccall((:gat_set_option, libgat), Int32, (Ptr{Cvoid}, Cstring, Int64), ctx.handle, name, Int64(value)))
 function last_launch_info(ctx::Context)
-    info = Ref(LaunchInfo(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
+    info = Ref(LaunchInfo(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
     check(ctx, ccall((:gat_last_launch_info, libgat), Int32, (Ptr{Cvoid}, Ref{LaunchInfo}, Csize_t), ctx.handle, info,
                      sizeof(LaunchInfo)))
     info[]

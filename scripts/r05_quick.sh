@@ -31,6 +31,9 @@ lat12) run lat12 --channels 12 --blocks 1 --steps 400 ;;   # one 20 MHz block, 1
 lat4) run lat4 --channels 4 --blocks 4 --steps 400 ;;
 i8k8) run i8k8 --layout i8 --channels 8 --blocks 1024 ;;
 c4) run c4 --baseline-config 4 ;;
+c4i16) run c4i16 --baseline-config 4 --layout i16 ;;
+c4k32i16) run c4k32i16 --num-samples 2000000 --num-ants 64 --channels 32 --blocks 1 --block-ms 20 --layout i16 --matrix-core 3 ;;
+m32k32i16) run m32k32i16 --num-samples 2000000 --num-ants 32 --channels 32 --blocks 1 --block-ms 20 --layout i16 --matrix-core 3 ;;
 i8) run i8 --layout i8 ;;
 i16) run i16 --layout i16 ;;
 il) run il --layout interleaved ;;

@@ -120,7 +120,8 @@ hipError_t launch_dc_tail(const DcTailArgs &a, hipStream_t)
 // matrix-core kernels: the planner's helpers are the kernels' own (gat_internal.h); every launch is checked against what
 // the kernels assume
 size_t mfma_lds_bytes(int nct, int ct, int rep_stride, int code_row_stride, int codes_in_lds) { return mf_lds_bytes(nct, ct, rep_stride, code_row_stride, codes_in_lds); }
-size_t mfma_bf16_lds_bytes(int rt, int nct, int fmt, int nslots, int rep_stride, int code_bits_stride) { return mb_lds_bytes(rt, nct, fmt, nslots, rep_stride, code_bits_stride); }
+size_t mfma_bf16_lds_bytes(int rt, int nct, int fmt, int nslots, int rep_stride, int code_bits_stride, int mode) { return mb_lds_bytes(rt, nct, fmt, nslots, rep_stride, code_bits_stride, mode); }
+int mfma_bf16_mode(int rt, int nct, int fmt, bool force_three) { return mb_mode(rt, nct, fmt, force_three); }
 int mfma_bf16_slots(int nct, int L, int K) { return mb_slots(nct, L, K); }
 int mfma_bf16_max_slots() { return kMbMaxSlots; }
 int mfma_bf16_tile_samples(int rt, int nct) { return mb_tile_samples(rt, nct); }
@@ -167,7 +168,9 @@ hipError_t launch_mfma_bf16(const MfArgs &a, int rt, int nct, int fmt, unsigned 
             "bf16 mfma: %d slots x %d samples for %d producers", a.nslots, T, mb_threads(rt, nct) - 64 * mb_consumer_waves(rt, nct));
     REQUIRE((long long)a.steps_per_split * T <= kMbMaxChain || a.steps_per_split == 1, "bf16 mfma: chain of %d x %d samples", a.steps_per_split, T);
     REQUIRE(a.code_bits && a.zeros && a.code_bits_stride % 4 == 0 && a.code_bits_stride * 32 >= a.Lc, "bf16 mfma: sign-bit tables");
-    REQUIRE(lds_bytes == mb_lds_bytes(rt, nct, fmt, a.nslots, a.rep_stride, a.code_bits_stride) && lds_bytes <= 160 * 1024, "bf16 mfma: LDS %u", lds_bytes);
+    REQUIRE(a.mb_mode == mb_mode(rt, nct, fmt) || (fmt == GAT_LAYOUT_INTERLEAVED_I16 && a.mb_mode == kMbThree), "bf16 mfma: operand split %d for layout %d", a.mb_mode, fmt);
+    REQUIRE(a.mb_mode != kMbTwo || a.nslots * T / 4 <= mb_threads(rt, nct) - 64 * mb_consumer_waves(rt, nct), "bf16 mfma: two-term items");
+    REQUIRE(lds_bytes == mb_lds_bytes(rt, nct, fmt, a.nslots, a.rep_stride, a.code_bits_stride, a.mb_mode) && lds_bytes <= 160 * 1024, "bf16 mfma: LDS %u", lds_bytes);
     check_mf_common(a, grid, T, "bf16 mfma");
     return hipSuccess;
 }

@@ -71,8 +71,8 @@ int main(int argc, char **argv)
 
     // ---- 1. random correlate calls ---------------------------------------------------------------------------------------
     const char *opts[] = {"sync_flag_wgs", "max_ant_tile", "dc_aw", "dc_kt", "dc_bpw", "dc_bpw_force", "dc_wgs_per_cu", "dc_one_wave",
-                          "dc_one_wave_min", "dc_ow_seg", "dc_depth", "dc_keep_l2", "dc_align", "dc_aw2", "dc_seg", "dc_bits", "dc_quads"};
-    const long long opt_lo[] = {0, 1, 1, 1, 1, 0, 0, 0, -1, 1, 1, -1, 0, 0, 0, 0, -1}, opt_hi[] = {2048, 4, 4, 4, 64, 8, 16, 1, 64, 8, 2, 1, 1, 1, 8, 2, 1};
+                          "dc_one_wave_min", "dc_ow_seg", "dc_depth", "dc_keep_l2", "dc_align", "dc_aw2", "dc_seg", "dc_bits", "dc_quads", "mc_i16_terms"};
+    const long long opt_lo[] = {0, 1, 1, 1, 1, 0, 0, 0, -1, 1, 1, -1, 0, 0, 0, 0, -1, 2}, opt_hi[] = {2048, 4, 4, 4, 64, 8, 16, 1, 64, 8, 2, 1, 1, 1, 8, 2, 1, 3};
     EXPECT(gat_set_option(ctx, "no_such_option", 1) == GAT_ERR_ARG && gat_set_option(ctx, "dc_depth", 7) == GAT_ERR_RANGE, "option errors");
     EXPECT(gat_set_matrix_core(ctx, 7) != GAT_OK, "kernel selection: bad mode");
     long ok_calls = 0, rejected = 0;
@@ -148,7 +148,7 @@ int main(int argc, char **argv)
     EXPECT(ok_calls > calls / 2 && hostsim::counters.tail_launches > 0 && hostsim::counters.finalize_launches > 0 && (calls < 500 || hostsim::counters.mfma_launches > 0),
            "the sweep covers second stages, tails and the matrix-core kernels");
     EXPECT(gat_set_matrix_core(ctx, 1) == GAT_OK, "kernel selection back to auto");
-    for (int o = 0; o < 17; ++o) gat_set_option(ctx, opts[o], o == 0 ? 1024 : o == 1 ? 4 : o == 2 ? 4 : o == 3 ? 4 : o == 4 ? 16 : o == 5 ? 0 : o == 6 ? 0 : o == 7 ? 1 : o == 8 ? -1 : o == 9 ? 4 : o == 10 ? 2 : o == 11 ? -1 : o == 12 ? 1 : o == 15 ? 1 : o == 16 ? -1 : 0);
+    for (int o = 0; o < 18; ++o) gat_set_option(ctx, opts[o], o == 17 ? 2 : o == 0 ? 1024 : o == 1 ? 4 : o == 2 ? 4 : o == 3 ? 4 : o == 4 ? 16 : o == 5 ? 0 : o == 6 ? 0 : o == 7 ? 1 : o == 8 ? -1 : o == 9 ? 4 : o == 10 ? 2 : o == 11 ? -1 : o == 12 ? 1 : o == 15 ? 1 : o == 16 ? -1 : 0);
     EXPECT(gat_set_codes(ctx, codes.data(), lc, 32) == GAT_OK, "rebind L1");
 
     // ---- 2. closed loop, stand-alone operators, groups ---------------------------------------------------------------------

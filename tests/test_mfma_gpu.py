@@ -229,3 +229,53 @@ def test_split_bf16_extreme_dynamic_range(g):
     scale = np.abs(ref).max(axis=(2,), keepdims=True)  # per (block, channel, antenna): max over taps
     assert (np.abs(got - ref) / scale).max() <= 1e-5
     assert (np.abs(vec - ref) / scale).max() <= 1e-5
+
+
+# (M, K, L, N): one shape per instance <row tiles, channel tiles> of the split-bf16 kernel -- rt = M / 16 capped at 4 (2 when
+# there is a single column tile), nct = column tiles (2 L K / 32) capped at 4
+TWO_TERM_SHAPES = [(16, 2, 3, 6000), (16, 6, 3, 6000), (16, 16, 3, 4100), (32, 3, 3, 6000), (32, 8, 3, 4100), (32, 16, 3, 3000),
+                   (64, 2, 3, 3000), (64, 9, 3, 3000), (64, 32, 3, 2600), (64, 12, 5, 2600)]
+
+
+@pytest.mark.parametrize("shape", TWO_TERM_SHAPES, ids=lambda s: f"M{s[0]}-K{s[1]}-L{s[2]}-N{s[3]}")
+def test_int16_two_term_split(g, shape):
+    """int16 samples on the split-bf16 kernel (round 5): v = (v & ~255) + (v & 255), both exact in bf16 -- 5 products per
+    sample instead of the float path's 8.  FULL-SCALE data with the corner values (-32768, 32767, -1, -256, 255, 0) placed
+    at the tile edges: parity with the FP64 oracle, agreement with the three-term path (option mc_i16_terms = 3) on the
+    same device buffer far inside the tolerance, and the launch info names the split that ran."""
+    import torch
+    M, K, L, N = shape
+    system = "GPSL5" if L == 5 else "GPSL1"
+    case = make_case(zlib.crc32(repr(shape).encode()), system=system, N=N, M=M, L=L, K=K, B=2, fs=10e6, if_hz=2e5)
+    rng = np.random.default_rng(N + M)
+    q = rng.integers(-32768, 32768, size=(2,) + case["re"].shape, dtype=np.int64).astype(np.int16)
+    corners = np.array([-32768, 32767, -1, -256, 255, 0, 256, -255, -257, 1], dtype=np.int16)
+    for comp in range(2):
+        flat = q[comp].reshape(M, -1)
+        flat[:, :10] = corners
+        flat[:, 27:37] = corners[::-1]
+        flat[:, -10:] = corners
+        flat[M - 1, 60:70] = -32768
+    case["re"], case["im"] = q[0].astype(np.float32), q[1].astype(np.float32)
+    ref = oracle_result(case)
+    ctx = g.get_context()
+    sysobj = g.GNSSDICT[system](use_gpu=True)
+    p = case["prm"]
+    prm = g.make_params(p["prn0"], p["code_freq_hz"], p["carrier_freq_hz"], p["code_phase_chips"], p["carrier_phase_cycles"])
+    xd = torch.from_numpy(np.stack([q[0], q[1]], axis=-1)).to(ctx.device)
+    res = {}
+    try:
+        ctx.set_matrix_core(g.GAT_MC_BF16_SPLIT)
+        for terms in (2, 3):
+            ctx.set_option("mc_i16_terms", terms)
+            op = g.StreamCorrelator(sysobj, N, M, 2, K, case["shifts"], case["fs"])
+            op.set_params(prm)
+            op(xd, None)
+            info = ctx.last_launch_info()
+            assert info["matrix_core"] == 2 and info["bf16_terms"] == terms, info
+            res[terms] = op.result()
+            check_close(res[terms], ref, what=f"int16, {terms} bf16 terms per sample, {shape}")
+    finally:
+        ctx.set_option("mc_i16_terms", 2)
+        ctx.set_matrix_core(1)
+    assert np.abs(res[2] - res[3]).max() <= 3e-6 * np.abs(ref).max()
