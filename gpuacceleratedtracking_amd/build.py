@@ -108,6 +108,8 @@ def build_libgat(force: bool = False, verbose: bool = False, extra_flags: tuple[
     hdr_t = max(os.path.getmtime(h) for h in HEADERS + [os.path.abspath(__file__)])
     jobs, objs = [], []
     dc_only = bool(extra_flags) and all(f.startswith("-DGAT_DC_") or f == "-DGAT_DEV" for f in extra_flags)
+    # ... and flags that only touch the split-bf16 matrix-core kernel (-DGAT_ABLATE=, -DGAT_MB_*)
+    mb_only = bool(extra_flags) and all(f.startswith("-DGAT_ABLATE") or f.startswith("-DGAT_MB_") or f == "-DGAT_DEV" for f in extra_flags)
     base_objdir = os.path.join(ROOT, "build", "obj")
     os.makedirs(base_objdir, exist_ok=True)
     for src in SOURCES:
@@ -115,6 +117,7 @@ def build_libgat(force: bool = False, verbose: bool = False, extra_flags: tuple[
         # flags that only touch the fused vector kernel (-DGAT_DC_*): every other object is shared with the main build
         vector_tu = src.startswith("gat_dc_f") or src.startswith("gat_resident_f")  # both are made of gat_dc_body.inc
         shared = dc_only and not vector_tu and src not in ("gat_api.cpp", "gat_planner.cpp", "gat_resident_api.cpp")  # the planner shares gat_internal.h
+        shared = shared or (mb_only and src not in ("gat_mfma_bf16.hip", "gat_api.cpp", "gat_planner.cpp"))
         obj = os.path.join(base_objdir if shared else objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if shared:

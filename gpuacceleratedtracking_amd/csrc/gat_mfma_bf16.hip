@@ -505,13 +505,17 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     const int my_xi = __builtin_amdgcn_readfirstlane(item_wave ? xi_item : xi_other); // wave-uniform, in an SGPR
     const int g_first = item_wave ? xi_other * tn + ptid : ptid - niw;
     const int g_stride = item_wave ? niw : tn;
+    // 2-term path: a ds_write_b64 is served 16 consecutive lanes at a time = the 8 sample groups of TWO rows; the banks one row's
+    // 40-byte items cover and those of the row 4 planes (2 antennas) on are complementary, those of the next antenna overlap
+    // (RB = 84 dwords: 4 planes = 16 banks on): consecutive group rows are antennas 0 2 1 3 of every four
+    auto x_row = [&](int row) { return X2 ? ((row & ~3) | ((row & 1) << 1) | ((row >> 1) & 1)) : row; };
     auto load_x = [&](auto &xv, int st) {
         constexpr int XI = sizeof(xv) / sizeof(xv[0]);
         const int nb = st * T;
 #pragma unroll
         for (int it = 0; it < XI; ++it) {
             const int id = g_first + it * g_stride;
-            const int row = id / QPR, q = id % QPR; // planar: plane 2*m_local + comp; interleaved: antenna m_local
+            const int row = x_row(id / QPR), q = id % QPR; // planar: plane 2*m_local + comp; interleaved: antenna m_local
             const int n = nb + GS * q;
             const bool ok = id < NG && st < s_end && n < N;
             const long long off = PLANAR ? ((row & 1) ? im_delta : 0ll) + 4ll * ((long long)(row >> 1) * a.ant_stride + n)
@@ -537,7 +541,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         for (int it = 0; it < XI; ++it) {
             const int id = g_first + it * g_stride;
             if (id >= NG) continue;
-            const int row = id / QPR, q = id % QPR;
+            const int row = x_row(id / QPR), q = id % QPR;
             if constexpr (X2) {
                 // int16 v = a + b exactly, a = v & ~255 (a multiple of 256 in [-32768, 32512]: 8 significant bits), b = v & 255
                 // (0 .. 255): both exact in bf16, the top halves of their float patterns.  Slot order of a sample: a a a b b.
@@ -643,7 +647,9 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     // instead of an FP64 range reduction + sincos; re-anchored in FP64 every kReanchor steps.
     float car_r = 0.f, car_i = 0.f;
     int rep_ip = 0, rep_t = 0, rep_ip2 = 0, rep_t2 = 0;
-    const int item_slot = ptid / (T / IS), item_q = ptid % (T / IS);
+    // (2-term path: the items of 16 consecutive lanes are two slots 2 apart -- rows 4 apart, complementary banks, as for X)
+    const int item_i = ptid / (T / IS), item_q = ptid % (T / IS);
+    const int item_slot = X2 ? ((item_i & ~3) | ((item_i & 1) << 1) | ((item_i >> 1) & 1)) : item_i;
     const int item_s0 = X2 ? 4 * item_q : X1 ? 2 * item_q : item_q; // the item's first sample (step-relative); its second one is OS further
     const bool have_item = producer && item_slot < nslots;
     auto produce = [&](int st, int buf, bool first) { // everything of step st except the samples
@@ -672,11 +678,13 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
 #if defined(GAT_ABLATE) && (GAT_ABLATE & 1) // diagnostic builds (ablate_mfma_bf16.sh of an earlier round: git history; results wrong on purpose): no replica
         if (first)
 #endif
-        gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, nb, span + item_s0, OS, span + T,
-                 anchor || !c.inc_ok, rep_ip, rep_t);
-        if constexpr (X2)
-            gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, nb, span + item_s0 + 2, 1, span + T,
-                     anchor || !c.inc_ok, rep_ip2, rep_t2);
+        {
+            gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, nb, span + item_s0, OS, span + T,
+                     anchor || !c.inc_ok, rep_ip, rep_t);
+            if constexpr (X2) // the item's samples 2 and 3
+                gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, nb, span + item_s0 + 2, 1, span + T,
+                         anchor || !c.inc_ok, rep_ip2, rep_t2);
+        }
 #if defined(GAT_ABLATE) && (GAT_ABLATE & 2) // diagnostic: carrier fragments only in the first step
         if (!first) return;
 #endif

@@ -87,6 +87,33 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
         MT = next;
     }
 
+    // split-bf16 kernel: a consumer lane reads the chip-sign word of its column's (channel slot, tap) -- dword slot * rs + shift
+    // + const -- 32 lanes (columns of one tile) per LDS access, 32 banks: choose the row stride rs (odd, in [base, base + 32))
+    // under which the fewest of a tile's distinct words share a bank (rows 1 apart at taps -49 / 0 / +49: slot s + 2's early
+    // tap sits on slot s's late tap's bank, every read a 2-way conflict)
+    auto pick_rep_stride = [&](int base, int tiles, const int *order_) {
+        int best_rs = base + 1;
+        long long best_cost = -1;
+        for (int rs = base + 1; rs < base + 32; rs += 2) {
+            long long cost = 0;
+            for (int t = 0; t < tiles; ++t) {
+                int words[32], nw = 0; // distinct words of the tile
+                for (int r = 0; r < 32; r += 2) { // columns (k, l, re / im): the pair reads one word
+                    const int col = 32 * t + r, k = col / (2 * L), l = (col - 2 * L * k) >> 1;
+                    if (k >= K) break;
+                    words[nw++] = k * rs + (shifts[order_[l]] - shifts[order_[0]]);
+                }
+                for (int i = 0; i < nw; ++i)
+                    for (int j = 0; j < i; ++j) cost += ((words[i] - words[j]) & 31) == 0 && words[i] != words[j];
+            }
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                best_rs = rs;
+            }
+        }
+        return best_rs;
+    };
+
     // ---- matrix-core paths: antenna-rich shapes whose (channel, tap) columns fill a useful part of
     // a 32-column tile run on the matrix cores -- the split-bf16 kernel (gat_mfma_bf16.hip) by default,
     // the f32-MFMA kernel (gat_mfma.hip) on request; everything else takes the vector kernel below.
@@ -125,11 +152,15 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
             for (int n = tiles_b >= 4 ? 4 : (tiles_b >= 2 ? 2 : 1); n >= 1 && !kind; n >>= 1) {
                 rt = (rt_max == 4 && n == 1) ? 2 : rt_max; // <4,1> does not fit the VGPR budget of a 12-wave workgroup
                 const int T = mfma_bf16_tile_samples(rt, n);
-                const int rs = ((T + (int)span + 31) / 32) * 32 + 1; // odd: channel rows land on different banks
+                int rs = ((T + (int)span + 31) / 32) * 32 + 1; // odd: channel rows land on different banks
                 const int ns = mfma_bf16_slots(n, L, K);
                 // at most one (slot, sample pair) item per producer thread
                 if (ns * T / 2 > mfma_bf16_producer_threads(rt, n) || ns > mfma_bf16_max_slots()) continue;
-                if (mfma_bf16_lds_bytes(rt, n, fmt, ns, rs, c->code_bits_stride, mfma_bf16_mode(rt, n, fmt, c->mc_i16_terms == 3)) <= 160 * 1024) {
+                const int mode_n = mfma_bf16_mode(rt, n, fmt, c->mc_i16_terms == 3);
+                // ... and the taps of neighbouring channels too, where the longer rows still fit
+                const int rs_tuned = pick_rep_stride(rs - 1, tiles_b, order);
+                if (mfma_bf16_lds_bytes(rt, n, fmt, ns, rs_tuned, c->code_bits_stride, mode_n) <= 160 * 1024) rs = rs_tuned;
+                if (mfma_bf16_lds_bytes(rt, n, fmt, ns, rs, c->code_bits_stride, mode_n) <= 160 * 1024) {
                     kind = 2;
                     nct_b = n;
                     nslots_b = ns;

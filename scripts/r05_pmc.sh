@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5: PMC passes of one bench shape (separate rocprofv3 --pmc runs, --kernel-trace only beside them):
-#   scripts/r05_pmc.sh tag [sets] -- bench-args...      sets: any of "fetch write sq1 sq2 clk sq3 sq4 lds" (default: all but lds)
+#   scripts/r05_pmc.sh tag [sets] -- bench-args...      sets: any of "fetch write sq1 sq2 clk sq3 sq4 lds lds2 mfma" (default: all but lds)
 # GAT_LIBRARY=... selects a variant build.  Output: gpurun_out/r05/pmc_<tag>.txt (one dict per pass, averaged over the
 # last launches of the dominant kernel) + the raw csv under gpurun_out/r05/pmc_<tag>_<set>/
 set -o pipefail
@@ -36,5 +36,7 @@ for s in $sets; do case $s in
   clk) pmc clk "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_SMEM SQ_IFETCH" "$@";;
   sq3) pmc sq3 "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_WAVE_CYCLES" "$@";;
   sq4) pmc sq4 "SQ_INST_CYCLES_VMEM SQ_INSTS_VALU SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_IFETCH SQ_INSTS_SMEM" "$@";;
+  mfma) pmc mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES" "$@";;
+  lds2) pmc lds2 "SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_BUSY_CU_CYCLES SQ_WAIT_INST_LDS SQ_WAVE_CYCLES" "$@";;
   lds) pmc lds "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES" "$@";;
 esac; done
