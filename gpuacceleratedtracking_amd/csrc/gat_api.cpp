@@ -190,7 +190,7 @@ int32_t graph_replay_or_record(gat_ctx *c, MakeKey make_key, Enqueue enqueue)
 // the part of a graph key every recorded launch sequence shares: kernel-selection knobs and library-owned buffers
 void key_put_ctx(std::vector<unsigned char> &key, const gat_ctx *c)
 {
-    key_put(key, c->mc_mode); key_put(key, c->mc_i16_terms); key_put(key, c->max_aw); key_put(key, c->max_kt); key_put(key, c->max_bpw); key_put(key, c->force_bpw);
+    key_put(key, c->mc_mode); key_put(key, c->mc_i16_terms); key_put(key, c->mc_nct); key_put(key, c->max_aw); key_put(key, c->max_kt); key_put(key, c->max_bpw); key_put(key, c->force_bpw);
     key_put(key, c->wgs_per_cu); key_put(key, c->max_depth); key_put(key, c->one_wave); key_put(key, c->keep_l2); key_put(key, c->align_head);
     key_put(key, c->aw2); key_put(key, c->quads); key_put(key, c->bit_tables); key_put(key, c->seg_cap);
     key_put(key, c->d_codes); key_put(key, c->d_code_bits); key_put(key, c->Lc); key_put(key, c->P);
@@ -224,6 +224,7 @@ constexpr OptionDesc kOptions[] = {
     {"dc_bits", 0, 2},               // chip tables in LDS as sign bits: 0 never, 1 long codes (> 2 KB per PRN), 2 whenever every chip is +-1
     {"dc_aw2", -1, 1},               // the two-channel 2 x 2 tile (two waves of two antennas, two channels each): -1 by rule, 0 never, 1 wherever an instance exists
     {"dc_seg", 0, kUcarSteps},       // cap of the steps per replica segment of a four-wave workgroup (0: by instance)
+    {"mc_nct", 0, 4},                // split-bf16 kernel: 32-column channel tiles per workgroup to try first (1, 2, 4; 0 = by rule)
     {"mc_i16_terms", 2, 3},          // split-bf16 kernel, int16 samples: 2 = the exact two-term split (5 products per sample), 3 = the float path's three terms (8)
     {"dc_align", 0, 1},              // blocks walked from the 128-byte line their first sample lies in (1) or from the sample itself (0)
 };
@@ -254,6 +255,7 @@ int32_t set_option(gat_ctx *c, const char *name, long long v)
     else if (n == "dc_seg") c->seg_cap = (int)v;
     else if (n == "dc_align") c->align_head = (int)v;
     else if (n == "mc_i16_terms") c->mc_i16_terms = (int)v;
+    else if (n == "mc_nct") c->mc_nct = v == 3 ? 2 : (int)v;
     return GAT_OK;
 }
 

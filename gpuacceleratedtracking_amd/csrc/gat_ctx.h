@@ -93,6 +93,7 @@ struct gat_ctx {
     int seg_cap = 0;                          // option dc_seg: cap of the steps per replica segment (0: by instance)
     int align_head = 1;                       // option dc_align: line-aligned virtual block starts where blocks start off a line
     int mc_mode = 1; // GAT_MC_* kernel selection (gat_set_matrix_core)
+    int mc_nct = 0;       // option mc_nct: column tiles per workgroup of the split-bf16 kernel to try first (0: by rule; A/B runs)
     int mc_i16_terms = 2; // option mc_i16_terms: bf16 terms per int16 sample on the split-bf16 kernel (2: exact two-term split; 3: the float path's split)
     std::string err;
     gat_launch_info last{};

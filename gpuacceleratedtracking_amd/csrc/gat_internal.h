@@ -326,8 +326,8 @@ constexpr int mb_slots(int nct, int L, int K)
 // How the split-bf16 kernel lays the cross products along the MFMA's 16 reduction slots (per 32-lane half: 8 slots):
 //   kMbThree  float / int16 samples: x = hi + mid + lo, w = hi + mid + lo, 8 products per sample  -> 1 sample per half and MFMA
 //   kMbOne    int8 samples: exact in ONE bf16 term, 3 products + a zero slot per sample          -> 2 samples per half and MFMA
-//   kMbTwo    int16 samples, round 5: exact in TWO bf16 terms (x = 256 * floor(x / 256) + (x mod 256), both <= 8 significant
-//             bits), 5 products per sample {a h, a m, a l, b h, b m} (b * lo(w) is 2^-24 of the product: below f32), laid as a
+//   kMbTwo    int16 samples, round 5: exact in TWO bf16 terms (a = x rounded to 8 significant bits, b = x - a: at most 7 bits,
+//             |b| <= 2^-8 |a|), 5 products per sample {a h, a m, a l, b h, b m} (b * lo(w) is 2^-24 of the product: below f32), laid as a
 //             STREAM of slots across consecutive MFMAs: 8 samples per half every 5 MFMAs -- 1.6 samples per half and MFMA.
 //             Needs the half's sample count per step (T / consumer waves per tile / 2) to be a multiple of 8.
 enum MbMode : int { kMbThree = 0, kMbOne = 1, kMbTwo = 2 };

@@ -543,17 +543,22 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
             if (id >= NG) continue;
             const int row = x_row(id / QPR), q = id % QPR;
             if constexpr (X2) {
-                // int16 v = a + b exactly, a = v & ~255 (a multiple of 256 in [-32768, 32512]: 8 significant bits), b = v & 255
-                // (0 .. 255): both exact in bf16, the top halves of their float patterns.  Slot order of a sample: a a a b b.
+                // int16 v = a + b exactly: a = v rounded to bf16's 8 significant bits (to nearest: the magnitude's bit pattern
+                // + half an ulp, truncated), b = v - a -- at most 7 significant bits, |b| <= 2^-8 |a|: both exact in bf16 (the top
+                // halves of their float patterns), and the product the slot stream leaves out, b * lo(w), is below 2^-24 of
+                // a * w WHATEVER the sample's magnitude (a fixed cut at bit 8 would leave small samples -- an 8-bit ADC in an
+                // int16 container -- with the two-term carrier only: 2^-17).  Slot order of a sample: a a a b b.
                 unsigned ar[4], br[4], ai[4], bi[4];
+                auto two_terms = [](int v, unsigned &a_, unsigned &b_) {
+                    const float f = (float)v;
+                    a_ = (__float_as_uint(f) + 0x8000u) & 0xffff0000u;
+                    b_ = __float_as_uint(f - __uint_as_float(a_));
+                };
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int w = (int)__float_as_uint(xv[it][u]); // {re: low half, im: high half}
-                    const int re = (int)(short)(w & 0xffff), im = w >> 16;
-                    ar[u] = __float_as_uint((float)(re & ~0xff));
-                    br[u] = __float_as_uint((float)(re & 0xff));
-                    ai[u] = __float_as_uint((float)(im & ~0xff));
-                    bi[u] = __float_as_uint((float)(im & 0xff));
+                    two_terms((int)(short)(w & 0xffff), ar[u], br[u]);
+                    two_terms(w >> 16, ai[u], bi[u]);
                 }
                 auto put4 = [&](int plane, const unsigned (&A)[4], const unsigned (&B)[4]) {
                     u32x2 *d = reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned char *>(xb) + plane * RB + 40 * q);

@@ -129,27 +129,47 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
         const int nct_total = shape_ok ? (K + CT - 1) / CT : 1;
         int nct = nct_total >= 4 ? 4 : (nct_total >= 2 ? 2 : 1);
         while (nct > 1 && nct * CT > 20) nct >>= 1; // both kernels keep at most 20 channel slots per workgroup
-        // kernel choice: 3 / 1 (auto) -> split-bf16 when its tile fits in LDS, 2 -> f32 MFMA.  GAT_MC_AUTO picks a matrix
-        // kernel only where it measured faster than the vector kernel (r02_planner_scan.sh of an earlier round: git history, profiles/r02/
-        // r02h_planner_scan.txt; N = 50 000, 3 taps): with float samples the round-2 vector kernel (16 antennas per
-        // workgroup, channel loop over register-resident samples, lean step loop) wins or ties up to 24 channels at 64
-        // antennas, 32 at 32 and 16 at 128, so the split-bf16 kernel takes M >= 32 with K >= 32 and M * K >= 2048
-        // (64 x 32: 0.53 vs 0.58 ms, 32 x 64: 0.84 vs 0.99, 64 x 64: 0.75 vs 1.03); from int8 pairs (single-term
-        // path, half the MFMAs) it wins from 24 (channel, tap, re/im) columns on at every M.  The f32-MFMA kernel is
-        // never chosen by itself any more: the round-2 vector kernel is faster everywhere (configs[4]: 2.45 vs 4.19 ms,
-        // 64 antennas x 32 channels: 0.58 vs 0.92 ms); it runs on request (GAT_MC_F32).
+        // split-bf16 kernel: columns packed flat (2 L per channel), 32 per tile; rt_max 16-antenna row tiles per workgroup.
+        // Column tiles per workgroup: a workgroup of nct tiles costs the same whether its last tiles are live or dead, so
+        // the launch costs (groups x nct) tile SLOTS -- at two tiles per workgroup a slot costs w2 x what it costs at four
+        // (more sample splitting per column, the 12-wave instance at 64 antennas; profiles/r05/mfma_nct_scan_*.txt:
+        // 1.13-1.41 by layout and row tiles).  Three tiles: 4 slots either way -> one workgroup of four (0.55 vs 0.74 ms
+        // at 64 antennas x 16 channels of int16); five or six: 6 x w2 slots vs 8 -> mostly two per workgroup (0.62 vs
+        // 0.75 ms at 32 x 32 int16, 0.86 vs 0.93 float); nine or more: four.
         const bool int8_in = fmt == GAT_LAYOUT_INTERLEAVED_I8;
-        const bool auto_bf16 = 2ll * L * K >= 24 && (int8_in || (M >= 32 && K >= 32 && (long long)M * K >= 2048));
+        const bool two_term = fmt == GAT_LAYOUT_INTERLEAVED_I16 && c->mc_i16_terms != 3;
+        const int tiles_b = (2 * L * K + 31) / 32;
+        const int rt_max = (M / 16) % 4 == 0 ? 4 : ((M / 16) % 2 == 0 ? 2 : 1);
+        int n_first = tiles_b >= 4 ? 4 : (tiles_b >= 2 ? 2 : 1);
+        const double w2 = int8_in ? (rt_max == 4 ? 1.41 : 1.22) : two_term ? (rt_max == 4 ? 1.30 : 1.13) : (rt_max == 4 ? 1.26 : 1.235);
+        if (tiles_b >= 3) n_first = ((tiles_b + 1) / 2 * 2) * w2 < (tiles_b + 3) / 4 * 4 ? 2 : 4;
+        // kernel choice: 3 / 1 (auto) -> split-bf16 when its tile fits in LDS, 2 -> f32 MFMA.  GAT_MC_AUTO picks a matrix
+        // kernel only where it measured faster than the vector kernel (scripts/r05_i16_planner_scan.sh, profiles/r05/
+        // mfma_planner_scan_*.txt: N = 50 000, 3 taps, 16-64 antennas x 4-32 channels; round 2's scan: profiles/r02/).  What
+        // decides is the share of the launch's tile slots that carry live columns, u = 2 L K / (32 x slots x slot cost): the
+        // vector kernel's time grows with K, the matrix kernel's with the slots.  Float samples (three bf16 terms): the
+        // matrix kernel wins from u = 0.70 on at four row tiles (64 x 16: 0.76 vs 0.90 ms, 64 x 32: 1.48 vs 1.69; 64 x 24
+        // at u = 0.60: 1.48 vs 1.30) and only with nearly full slots at two (32 x 32, u = 0.81: 0.88 vs 0.85; 32 x 64 wins);
+        // int16 samples (two exact terms, 5/8 of the MFMAs): from u = 0.5 on (32 x 8: 0.22 vs 0.27 ms, 64 x 12: 0.55 vs
+        // 0.74, 64 x 32: 1.12 vs 1.81; a single tile -- 4 channels -- loses); one row tile (M = 16, 48) never wins; tap
+        // counts beyond three were not scanned again: round 2's rule (M >= 32, K >= 32, M K >= 2048) stays for them.
+        // From int8 pairs (single-term path) it wins from 24 (channel, tap, re/im) columns on at every M.  The f32-MFMA
+        // kernel is never chosen by itself any more: the round-2 vector kernel is faster everywhere (configs[4]: 2.45 vs
+        // 4.19 ms, 64 antennas x 32 channels: 0.58 vs 0.92 ms); it runs on request (GAT_MC_F32).
+        const int slots_first = (tiles_b + n_first - 1) / n_first * n_first;
+        const double slot_cost = n_first == 4 ? 1.0 : n_first == 2 ? w2 : 1.8;
+        const double util = 2.0 * L * K / (32.0 * slots_first * slot_cost);
+        const double util_min = rt_max == 1 ? 2.0 : two_term ? (rt_max == 4 ? 0.50 : 0.53) : (rt_max == 4 ? 0.70 : 0.90);
+        const bool round2_rule = M >= 32 && K >= 32 && (long long)M * K >= 2048;
+        const bool auto_bf16 = 2ll * L * K >= 24 && (int8_in || (L <= 3 ? util >= util_min : round2_rule));
         const bool auto_f32 = false;
         const bool want_bf16 = c->mc_mode == 3 || (c->mc_mode == 1 && auto_bf16);
         const bool want_f32 = c->mc_mode == 2 || (c->mc_mode == 1 && auto_f32);
         int kind = 0, rt = 1, rep_stride_m = 0;
-        int nslots_b = 0, tiles_b = 0, nct_b = 1;
+        int nslots_b = 0, nct_b = 1;
         if (shape_any && want_bf16 && c->d_code_bits && c->d_zeros && N % spv == 0 && spv <= 8) {
-            // split-bf16 kernel: columns packed flat (2 L per channel), 32 per tile
-            tiles_b = (2 * L * K + 31) / 32;
-            const int rt_max = (M / 16) % 4 == 0 ? 4 : ((M / 16) % 2 == 0 ? 2 : 1);
-            for (int n = tiles_b >= 4 ? 4 : (tiles_b >= 2 ? 2 : 1); n >= 1 && !kind; n >>= 1) {
+            if (c->mc_nct > 0) n_first = c->mc_nct; // A/B runs
+            for (int n = n_first; n >= 1 && !kind; n >>= 1) {
                 rt = (rt_max == 4 && n == 1) ? 2 : rt_max; // <4,1> does not fit the VGPR budget of a 12-wave workgroup
                 const int T = mfma_bf16_tile_samples(rt, n);
                 int rs = ((T + (int)span + 31) / 32) * 32 + 1; // odd: channel rows land on different banks

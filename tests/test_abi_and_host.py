@@ -75,7 +75,7 @@ def test_struct_layouts_match_header(g):
     from gpuacceleratedtracking_amd import _lib
     assert C.sizeof(_lib.ChannelParams) == 40 and _lib.PARAMS_DTYPE.itemsize == 40
     assert C.sizeof(_lib.SignalDesc) == 56
-    assert C.sizeof(_lib.LaunchInfo) == 44
+    assert C.sizeof(_lib.LaunchInfo) == 48
     # the oracle's params struct has the same layout (prn0/pad == prn/reserved)
     assert oracle.PARAMS_DTYPE.itemsize == 40
 

@@ -36,13 +36,35 @@ def run(g, case, matrix_core=1, flags=0):
         ctx.set_matrix_core(1)
 
 
+def planner_auto_kind(M, K, L, layout="f32"):
+    """Mirror of the planner's GAT_MC_AUTO rule for M % 16 == 0 (gat_planner.cpp, round 5): column tiles per workgroup by
+    slot count x slot cost, then the split-bf16 kernel iff the live share of its slots reaches the layout's threshold
+    (profiles/r05/mfma_planner_scan_*.txt); tap counts beyond three keep round 2's rule."""
+    tiles = (2 * L * K + 31) // 32
+    rt = 4 if (M // 16) % 4 == 0 else 2 if (M // 16) % 2 == 0 else 1
+    w2 = {"i8": (1.41, 1.22), "i16": (1.30, 1.13), "f32": (1.26, 1.235)}[layout][0 if rt == 4 else 1]
+    n = 4 if tiles >= 4 else 2 if tiles >= 2 else 1
+    if tiles >= 3:
+        n = 2 if ((tiles + 1) // 2 * 2) * w2 < (tiles + 3) // 4 * 4 else 4
+    slots = -(-tiles // n) * n
+    util = 2 * L * K / (32 * slots * (1.0 if n == 4 else w2 if n == 2 else 1.8))
+    util_min = 2.0 if rt == 1 else {"i16": (0.50, 0.53), "f32": (0.70, 0.90)}.get(layout, (0, 0))[0 if rt == 4 else 1]
+    if 2 * L * K < 24:
+        return 0
+    if layout == "i8":
+        return 2
+    if L > 3:
+        return 2 if (M >= 32 and K >= 32 and M * K >= 2048) else 0
+    return 2 if util >= util_min else 0
+
+
 GRID = [
     # system, N, M, L, K, B
     ("GPSL1", 50000, 16, 3, 4, 2),    # BASELINE config 4 per-GPU shape
     ("GPSL1", 20000, 64, 3, 12, 1),   # config-5-like: 64 antennas, 3 channel tiles
     ("GPSL1", 5000, 16, 3, 5, 3),     # exactly one full channel tile
     ("GPSL1", 5000, 16, 3, 6, 1),     # CT + 1 channels: second tile nearly empty
-    ("GPSL1", 3004, 32, 3, 21, 1),    # 5 channel tiles -> two channel groups, ragged tile
+    ("GPSL1", 3004, 32, 3, 21, 1),    # 4 column tiles, nearly full: the split-bf16 kernel by default (round 5)
     ("GPSL5", 8192, 16, 5, 7, 2),     # L = 5 -> CT = 3
     ("GPSL1", 776, 16, 1, 16, 2, 0),  # L = 1: the split-bf16 tile does not fit, M x K is small for the f32 kernel -> auto: vector
     ("GPSL1", 260, 16, 16, 2, 1),     # L = 16: one channel per tile
@@ -52,16 +74,17 @@ GRID = [
     ("GPSL1", 9000, 64, 3, 3, 1, 0),  # 4 row tiles, 18 of 32 columns: below the auto threshold (vector kernel faster)
     ("GPSL1", 70004, 48, 3, 10, 1),   # 3 antenna tiles of one row tile each, ragged last step
     ("GPSL5", 30000, 64, 5, 12, 1),   # L5: 12 channels x 5 taps = 4 channel tiles of CT = 3
-    ("GPSL1", 12000, 64, 3, 32, 1),   # above the auto threshold (M >= 32, K >= 32, M * K >= 2048): split-bf16 by default
+    ("GPSL1", 12000, 64, 3, 32, 1),   # 6 column tiles in 3 workgroups of two: split-bf16 by default
+    ("GPSL1", 12000, 64, 3, 16, 1),   # 3 tiles in one workgroup of four (a dead tile): split-bf16 by default at 64 antennas ...
+    ("GPSL1", 12000, 32, 3, 16, 1),   # ... not at 32
 ]
 
 
 @pytest.mark.parametrize("cfg", GRID, ids=lambda c: f"{c[0]}-N{c[1]}-M{c[2]}-L{c[3]}-K{c[4]}-B{c[5]}")
 def test_mfma_parity(g, cfg):
     system, N, M, L, K, B = cfg[:6]
-    # GAT_MC_AUTO (float samples): the split-bf16 kernel when M >= 32, K >= 32 and M * K >= 2048; below that the
-    # round-2 vector kernel measured as fast or faster (profiles/r02/r02h_planner_scan.txt)
-    auto_kind = cfg[6] if len(cfg) > 6 else (2 if (2 * L * K >= 24 and M >= 32 and K >= 32 and M * K >= 2048) else 0)
+    # GAT_MC_AUTO: the split-bf16 kernel where enough of its tile slots carry live columns (planner_auto_kind below)
+    auto_kind = cfg[6] if len(cfg) > 6 else planner_auto_kind(M, K, L)
     forced = 2 if not (L == 1 and K == 16) else 1  # GAT_MC_BF16_SPLIT takes every shape whose tile fits
     fs = {"GPSL1": 8e6, "GPSL5": 25e6}[system] if L <= 5 else 2.5e6
     case = make_case(zlib.crc32(repr(cfg).encode()), system=system, N=N, M=M, L=L, K=K, B=B, fs=fs, if_hz=1.1e6)
@@ -237,18 +260,21 @@ TWO_TERM_SHAPES = [(16, 2, 3, 6000), (16, 6, 3, 6000), (16, 16, 3, 4100), (32, 3
                    (64, 2, 3, 3000), (64, 9, 3, 3000), (64, 32, 3, 2600), (64, 12, 5, 2600)]
 
 
+@pytest.mark.parametrize("bits", [16, 8, 3], ids=lambda b: f"{b}bit")
 @pytest.mark.parametrize("shape", TWO_TERM_SHAPES, ids=lambda s: f"M{s[0]}-K{s[1]}-L{s[2]}-N{s[3]}")
-def test_int16_two_term_split(g, shape):
-    """int16 samples on the split-bf16 kernel (round 5): v = (v & ~255) + (v & 255), both exact in bf16 -- 5 products per
-    sample instead of the float path's 8.  FULL-SCALE data with the corner values (-32768, 32767, -1, -256, 255, 0) placed
-    at the tile edges: parity with the FP64 oracle, agreement with the three-term path (option mc_i16_terms = 3) on the
-    same device buffer far inside the tolerance, and the launch info names the split that ran."""
+def test_int16_two_term_split(g, shape, bits):
+    """int16 samples on the split-bf16 kernel (round 5): v = a + b with a = v rounded to bf16's 8 significant bits and
+    b = v - a, both exact in bf16 -- 5 products per sample instead of the float path's 8.  FULL-SCALE data, and the
+    output of an 8-bit or 3-bit converter in the same container (there a cut at a FIXED bit would leave the whole sample
+    in the term that meets only two of the carrier's three terms), with the corner values (-32768, 32767, -1, -256, 255,
+    0) placed at the tile edges: parity with the FP64 oracle, agreement with the three-term path (option mc_i16_terms = 3)
+    on the same device buffer far inside the tolerance, and the launch info names the split that ran."""
     import torch
     M, K, L, N = shape
     system = "GPSL5" if L == 5 else "GPSL1"
     case = make_case(zlib.crc32(repr(shape).encode()), system=system, N=N, M=M, L=L, K=K, B=2, fs=10e6, if_hz=2e5)
     rng = np.random.default_rng(N + M)
-    q = rng.integers(-32768, 32768, size=(2,) + case["re"].shape, dtype=np.int64).astype(np.int16)
+    q = rng.integers(-(1 << (bits - 1)), 1 << (bits - 1), size=(2,) + case["re"].shape, dtype=np.int64).astype(np.int16)
     corners = np.array([-32768, 32767, -1, -256, 255, 0, 256, -255, -257, 1], dtype=np.int16)
     for comp in range(2):
         flat = q[comp].reshape(M, -1)
@@ -279,3 +305,26 @@ def test_int16_two_term_split(g, shape):
         ctx.set_option("mc_i16_terms", 2)
         ctx.set_matrix_core(1)
     assert np.abs(res[2] - res[3]).max() <= 3e-6 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("shape", [(32, 8), (32, 4), (16, 16), (48, 16), (64, 12), (64, 24), (64, 4)], ids=lambda s: f"M{s[0]}-K{s[1]}")
+def test_planner_auto_rule_for_int16_samples(g, shape):
+    """int16 pairs need 5/8 of the float path's MFMAs: GAT_MC_AUTO hands them to the split-bf16 kernel from two column tiles
+    on when the antennas fill two or four row tiles (scripts/r05_i16_planner_scan.sh), never at one row tile or one column
+    tile -- and whichever kernel runs, the result is the oracle's."""
+    import torch
+    M, K = shape
+    N, L = 4000, 3
+    case = make_case(M * 131 + K, N=N, M=M, L=L, K=K, B=1, fs=8e6, if_hz=1e5)
+    q = np.clip(np.rint(np.stack([case["re"], case["im"]], axis=-1) * (2000.0 / K)), -32768, 32767).astype(np.int16)
+    case["re"], case["im"] = q[..., 0].astype(np.float32), q[..., 1].astype(np.float32)
+    ctx = g.get_context()
+    ctx.set_matrix_core(g.GAT_MC_AUTO)
+    op = g.StreamCorrelator(g.GPSL1(use_gpu=True), N, M, 1, K, case["shifts"], case["fs"])
+    p = case["prm"]
+    op.set_params(g.make_params(p["prn0"], p["code_freq_hz"], p["carrier_freq_hz"], p["code_phase_chips"], p["carrier_phase_cycles"]))
+    op(torch.from_numpy(q).to(ctx.device), None)
+    info = ctx.last_launch_info()
+    assert info["matrix_core"] == planner_auto_kind(M, K, L, "i16"), info
+    assert info["bf16_terms"] == (2 if info["matrix_core"] == 2 else 0)
+    check_close(op.result(), oracle_result(case), what=f"int16 auto {shape}")
