@@ -76,7 +76,11 @@ __device__ __forceinline__ Split3 split3(float v)
 // around the wait makes the register allocator COPY the registers before it, i.e. before the data is there.
 __device__ __forceinline__ void gload_nt(f32x4_ &dst, const void *p)
 {
+#ifdef GAT_MB_NT_LOADS // A/B build: non-temporal sample loads, as up to round 4
     asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+#else
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+#endif
 }
 template <int XI> // XI loads per register set; the two other sets' 2 * XI loads are newer and may stay in flight
 __device__ __forceinline__ void wait_loads(f32x4_ (&xv)[XI])
