@@ -156,6 +156,14 @@ constexpr int frag_newer(int J, int n, int NM)
 template <int J, int RT, int XM>
 __device__ __forceinline__ void frag_issue(FragSet<RT, XM> &s, unsigned w_addr, unsigned r_addr, const unsigned (&x_addr)[RT])
 {
+#if defined(GAT_ABLATE) && (GAT_ABLATE & 256) // diagnostic: no fragment fetches (one LDS read keeps the counted waits meaningful)
+    {
+        unsigned one;
+        asm volatile("ds_read_b32 %0, %1" : "=v"(one) : "v"(r_addr));
+        if constexpr (XM == kMbThree) s.m = one; else s.m[0] = one;
+        return;
+    }
+#endif
 #if defined(GAT_ABLATE) && (GAT_ABLATE & 64) // diagnostic: half the W fragment bytes (results wrong)
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(s.wl) : "v"(w_addr), "n"(J * 16));
 #else
@@ -237,6 +245,16 @@ __device__ __forceinline__ void mfma_apply(f32x16 (&acc)[RT == 1 ? 2 : RT], Frag
     constexpr bool X1 = XM == kMbOne;
 #if defined(GAT_ABLATE) && (GAT_ABLATE & 128) // diagnostic (results wrong): the arithmetic of two k-slices out of three -- what a
     if constexpr (XM == kMbThree && J % 3 == 2) return;   // 2-term split of the SAMPLE operand (5 products, 3 samples per MFMA) would issue
+#endif
+#if defined(GAT_ABLATE) && (GAT_ABLATE & 512) // diagnostic: no vector preparation of the operands (3-term path)
+    if constexpr (XM == kMbThree) {
+        const bf16x8 bw0 = __builtin_bit_cast(bf16x8, cur.w);
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+            acc[RT == 1 ? (J & 1) : t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, u32x4{cur.xa[t][0], cur.xa[t][1], cur.xa[t][0], cur.xa[t][1]}), bw0, acc[RT == 1 ? (J & 1) : t], 0, 0, 0);
+        return;
+    }
 #endif
     u32x4 w = cur.w;
 #if defined(GAT_ABLATE) && (GAT_ABLATE & 64)
@@ -334,7 +352,9 @@ __device__ __forceinline__ void xstep_slice(f32x16 (&acc)[RT == 1 ? 2 : RT], Fra
     } else {
         if constexpr (J + D == NM) { // the first fetch that belongs to the next step: this step's reads are home, then the barrier
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !(defined(GAT_ABLATE) && (GAT_ABLATE & 32)) // diagnostic: no step barrier (both roles)
             __syncthreads();
+#endif
         }
         unsigned x_next[RT]; // the other buffer: a wave-uniform distance away
 #pragma unroll
@@ -845,7 +865,9 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
                 GAT_ACC(t_st, t2_, t1_);
             }
             GAT_STAMP(t1_);
+#if !(defined(GAT_ABLATE) && (GAT_ABLATE & 32))
             __syncthreads();
+#endif
             GAT_STAMP(t2_);
             GAT_ACC(t_work, t0_, t1_);
             GAT_ACC(t_wait, t1_, t2_);

@@ -357,8 +357,10 @@ GAT_API int32_t gat_debug_read_stream(gat_ctx *ctx, const void *dev, size_t byte
 
 /* Kernel selection.  By default (GAT_MC_AUTO) the library runs the split-bf16 matrix-core kernel (gat_mfma_bf16.hip:
  * both operands as hi+mid+lo bf16 terms, f32-equivalent accuracy; every sample format) where it measured faster than
- * the vector kernel -- M % 16 == 0 and at least 24 (channel, tap, re/im) columns, then: float / int16 samples from 32
- * antennas x 32 channels on (antennas x channels >= 2048), int8 pairs always --, everything else on the vector kernel.
+ * the vector kernel -- M % 16 == 0 and at least 24 (channel, tap, re/im) columns, then by the share of the kernel's
+ * 32-column tile slots that carry live columns: float samples (three bf16 terms per value) from 0.70 on at M % 64 == 0
+ * (64 antennas x 16 or 32 channels) and 0.90 at M % 32 == 0; int16 pairs (two exact terms, 5/8 of the matrix work: round 5)
+ * from 0.5 on at M % 32 == 0 (32 antennas x 8 channels); int8 pairs always --, everything else on the vector kernel.
  * GAT_MC_VECTOR forces the vector kernel (A/B measurements, bit-comparisons), GAT_MC_F32 the
  * f32-MFMA kernel (gat_mfma.hip), GAT_MC_BF16_SPLIT the split-bf16 kernel only (shapes neither
  * matrix kernel takes fall through to the vector kernel in every mode). */
@@ -380,7 +382,10 @@ GAT_API int32_t gat_set_vector_tiling(gat_ctx *ctx, int32_t max_antenna_tiles, i
  * result beyond summation order.  The library reads NO environment variable that selects kernels or geometry (development
  * builds, -DGAT_DEV, map GAT_<NAME> onto these).  Names: "sync_flag_wgs" (largest launch in workgroups that carries the
  * completion flag; 0: never), "max_ant_tile", "dc_aw", "dc_kt", "dc_bpw" (the caps of gat_set_vector_tiling),
- * "dc_bpw_force", "dc_wgs_per_cu", "dc_one_wave", "dc_one_wave_min", "dc_ow_seg", "dc_depth", "dc_keep_l2", "dc_align".
+ * "dc_bpw_force", "dc_wgs_per_cu", "dc_one_wave", "dc_one_wave_min", "dc_ow_seg", "dc_depth", "dc_keep_l2", "dc_align",
+ * "dc_aw2", "dc_quads", "dc_bits", "dc_seg" (round 5: the two-channel tile and its replica fill), "mc_i16_terms" (split-bf16
+ * kernel, int16 samples: 2 = the exact two-term split, the default; 3 = the float path's three terms: bit-comparisons),
+ * "mc_nct" (32-column tiles per workgroup of the split-bf16 kernel to try first; 0 = by rule).
  * GAT_ERR_ARG: unknown name; GAT_ERR_RANGE: value outside the option's range. */
 GAT_API int32_t gat_set_option(gat_ctx *ctx, const char *name, int64_t value);
 

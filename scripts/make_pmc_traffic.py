@@ -18,6 +18,7 @@ WORK = {  # tag -> (workload key of bench.py's stored_traffic, bytes per complex
     "c3": (["GPSL5", 50000, 4, 5, 12, 1024, "planar"], 8),
     "c4": (["GPSL1", 50000, 16, 3, 4, 512, "planar"], 8),
     "c5": (["GPSL1", 2000000, 64, 3, 64, 1, "planar"], 8),
+    "c5_i16": (["GPSL1", 2000000, 64, 3, 64, 1, "i16"], 4),  # configs[4] from int16 pairs: the two-term split
     "c1shape": (["GPSL1", 4000, 1, 3, 1, 16384, "planar"], 8),
     "c2_i16": (["GPSL1", 20000, 4, 3, 1, 4096, "i16"], 4),
     "c2_i8": (["GPSL1", 20000, 4, 3, 1, 4096, "i8"], 2),

@@ -30,13 +30,14 @@ stats c1shape --no-single-block  --num-samples 4000 --num-ants 1 --blocks 16384
 stats c3 --no-single-block --baseline-config 2
 stats c4 --no-single-block --baseline-config 3
 stats c5 --no-single-block --baseline-config 4
+stats c5_i16 --no-single-block --baseline-config 4 --layout i16
 stats c2_i16 --no-single-block  --layout i16
 stats c2_i8 --no-single-block  --layout i8
 stats c4x32 --num-samples 50000 --num-ants 16 --num-taps 3 --channels 32 --blocks 512 --no-single-block
 fi
 [ "$PART" = "stats" ] && { cat $OUT/summary.txt; exit 0; }
 cd $REPO
-for spec in "c2:" "c1shape:--num-samples 4000 --num-ants 1 --blocks 16384" "c3:--baseline-config 2" "c4:--baseline-config 3" "c5:--baseline-config 4" "c2_i16:--layout i16" "c2_i8:--layout i8" "c4x32:--num-samples 50000 --num-ants 16 --num-taps 3 --channels 32 --blocks 512"; do
+for spec in "c2:" "c1shape:--num-samples 4000 --num-ants 1 --blocks 16384" "c3:--baseline-config 2" "c4:--baseline-config 3" "c5:--baseline-config 4" "c5_i16:--baseline-config 4 --layout i16" "c2_i16:--layout i16" "c2_i8:--layout i8" "c4x32:--num-samples 50000 --num-ants 16 --num-taps 3 --channels 32 --blocks 512"; do
   tag=${spec%%:*}; args=${spec#*:}
   : > gpurun_out/r05/pmc_$tag.txt
   bash scripts/r05_pmc.sh $tag "fetch write sq1 sq2 clk" -- $args > /dev/null 2>&1
