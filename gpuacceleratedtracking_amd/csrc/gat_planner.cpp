@@ -181,6 +181,18 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
                 const int rs_tuned = pick_rep_stride(rs - 1, tiles_b, order);
                 if (mfma_bf16_lds_bytes(rt, n, fmt, ns, rs_tuned, c->code_bits_stride, mode_n) <= 160 * 1024) rs = rs_tuned;
                 if (mfma_bf16_lds_bytes(rt, n, fmt, ns, rs, c->code_bits_stride, mode_n) <= 160 * 1024) {
+                    if (c->mc_mode == 1) {
+                        // GAT_MC_AUTO: the kernel's set-up (sign tables and the first replica into LDS, three sample loads
+                        // ahead) is paid per workgroup, and a launch is cut into ~2 workgroups per CU: with few steps per
+                        // workgroup the vector kernel is faster whatever the shape (ONE 50 MHz block of 64 antennas x 32
+                        // int16 channels: 10 steps each, 0.056 vs 0.050 ms; round 4's rule sent it here).  Crossovers:
+                        // 10-14 steps with int16 pairs, 25-40 with float samples (profiles/r05/mfma_blocks_scan_*.txt).
+                        const long long steps_total = (N + T - 1) / T;
+                        const long long groups = (long long)B * (M / (16 * rt)) * ((tiles_b + n - 1) / n);
+                        const long long cut = std::min<long long>(steps_total, std::max<long long>(1, (2ll * c->num_cus + groups - 1) / groups));
+                        const long long steps_each = (steps_total + cut - 1) / cut;
+                        if (steps_each < (two_term || int8_in ? 16 : 32)) break; // -> the vector kernel
+                    }
                     kind = 2;
                     nct_b = n;
                     nslots_b = ns;

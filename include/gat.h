@@ -360,7 +360,9 @@ GAT_API int32_t gat_debug_read_stream(gat_ctx *ctx, const void *dev, size_t byte
  * the vector kernel -- M % 16 == 0 and at least 24 (channel, tap, re/im) columns, then by the share of the kernel's
  * 32-column tile slots that carry live columns: float samples (three bf16 terms per value) from 0.70 on at M % 64 == 0
  * (64 antennas x 16 or 32 channels) and 0.90 at M % 32 == 0; int16 pairs (two exact terms, 5/8 of the matrix work: round 5)
- * from 0.5 on at M % 32 == 0 (32 antennas x 8 channels); int8 pairs always --, everything else on the vector kernel.
+ * from 0.5 on at M % 32 == 0 (32 antennas x 8 channels); int8 pairs always; and only launches long enough to give each of
+ * the kernel's ~2 workgroups per CU 16 steps (int16, int8) or 32 (float) of 32-128 samples: ONE 1 ms block stays on the
+ * vector kernel whatever its shape --, everything else on the vector kernel.
  * GAT_MC_VECTOR forces the vector kernel (A/B measurements, bit-comparisons), GAT_MC_F32 the
  * f32-MFMA kernel (gat_mfma.hip), GAT_MC_BF16_SPLIT the split-bf16 kernel only (shapes neither
  * matrix kernel takes fall through to the vector kernel in every mode). */

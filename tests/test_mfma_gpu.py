@@ -36,10 +36,11 @@ def run(g, case, matrix_core=1, flags=0):
         ctx.set_matrix_core(1)
 
 
-def planner_auto_kind(M, K, L, layout="f32"):
+def planner_auto_kind(M, K, L, layout="f32", N=None, B=1, num_cus=256):
     """Mirror of the planner's GAT_MC_AUTO rule for M % 16 == 0 (gat_planner.cpp, round 5): column tiles per workgroup by
     slot count x slot cost, then the split-bf16 kernel iff the live share of its slots reaches the layout's threshold
-    (profiles/r05/mfma_planner_scan_*.txt); tap counts beyond three keep round 2's rule."""
+    (profiles/r05/mfma_planner_scan_*.txt; tap counts beyond three keep round 2's rule) AND the launch is long enough to
+    give every workgroup 16 (int16 / int8) or 32 (float) steps (profiles/r05/mfma_blocks_scan_*.txt)."""
     tiles = (2 * L * K + 31) // 32
     rt = 4 if (M // 16) % 4 == 0 else 2 if (M // 16) % 2 == 0 else 1
     w2 = {"i8": (1.41, 1.22), "i16": (1.30, 1.13), "f32": (1.26, 1.235)}[layout][0 if rt == 4 else 1]
@@ -51,11 +52,17 @@ def planner_auto_kind(M, K, L, layout="f32"):
     util_min = 2.0 if rt == 1 else {"i16": (0.50, 0.53), "f32": (0.70, 0.90)}.get(layout, (0, 0))[0 if rt == 4 else 1]
     if 2 * L * K < 24:
         return 0
-    if layout == "i8":
-        return 2
-    if L > 3:
-        return 2 if (M >= 32 and K >= 32 and M * K >= 2048) else 0
-    return 2 if util >= util_min else 0
+    if layout != "i8" and not (util >= util_min if L <= 3 else (M >= 32 and K >= 32 and M * K >= 2048)):
+        return 0
+    if N is not None:
+        rt_i = 2 if (rt == 4 and n == 1) else rt
+        T = min(32 * (4 // n), 128 // rt_i)
+        steps = -(-N // T)
+        groups = B * (M // (16 * rt_i)) * -(-tiles // n)
+        cut = min(steps, max(1, -(-2 * num_cus // groups)))
+        if -(-steps // cut) < (32 if layout == "f32" else 16):
+            return 0
+    return 2
 
 
 GRID = [
@@ -74,9 +81,10 @@ GRID = [
     ("GPSL1", 9000, 64, 3, 3, 1, 0),  # 4 row tiles, 18 of 32 columns: below the auto threshold (vector kernel faster)
     ("GPSL1", 70004, 48, 3, 10, 1),   # 3 antenna tiles of one row tile each, ragged last step
     ("GPSL5", 30000, 64, 5, 12, 1),   # L5: 12 channels x 5 taps = 4 channel tiles of CT = 3
-    ("GPSL1", 12000, 64, 3, 32, 1),   # 6 column tiles in 3 workgroups of two: split-bf16 by default
-    ("GPSL1", 12000, 64, 3, 16, 1),   # 3 tiles in one workgroup of four (a dead tile): split-bf16 by default at 64 antennas ...
-    ("GPSL1", 12000, 32, 3, 16, 1),   # ... not at 32
+    ("GPSL1", 12000, 64, 3, 32, 1),   # 6 column tiles in 3 workgroups of two; ONE short block: 3 steps per workgroup -> vector by default
+    ("GPSL1", 8192, 64, 3, 32, 24),   # the same tiles in a launch of 24 blocks: 32 steps per workgroup -> split-bf16 by default
+    ("GPSL1", 8192, 64, 3, 16, 64),   # 3 tiles in one workgroup of four (a dead tile): split-bf16 by default at 64 antennas ...
+    ("GPSL1", 8192, 32, 3, 16, 64),   # ... not at 32
 ]
 
 
@@ -84,7 +92,7 @@ GRID = [
 def test_mfma_parity(g, cfg):
     system, N, M, L, K, B = cfg[:6]
     # GAT_MC_AUTO: the split-bf16 kernel where enough of its tile slots carry live columns (planner_auto_kind below)
-    auto_kind = cfg[6] if len(cfg) > 6 else planner_auto_kind(M, K, L)
+    auto_kind = cfg[6] if len(cfg) > 6 else planner_auto_kind(M, K, L, "f32", N, B)
     forced = 2 if not (L == 1 and K == 16) else 1  # GAT_MC_BF16_SPLIT takes every shape whose tile fits
     fs = {"GPSL1": 8e6, "GPSL5": 25e6}[system] if L <= 5 else 2.5e6
     case = make_case(zlib.crc32(repr(cfg).encode()), system=system, N=N, M=M, L=L, K=K, B=B, fs=fs, if_hz=1.1e6)
@@ -307,24 +315,26 @@ def test_int16_two_term_split(g, shape, bits):
     assert np.abs(res[2] - res[3]).max() <= 3e-6 * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("shape", [(32, 8), (32, 4), (16, 16), (48, 16), (64, 12), (64, 24), (64, 4)], ids=lambda s: f"M{s[0]}-K{s[1]}")
+@pytest.mark.parametrize("shape", [(32, 8, 64), (32, 8, 4), (32, 4, 64), (16, 16, 64), (48, 16, 64), (64, 12, 32), (64, 12, 1), (64, 4, 32)],
+                         ids=lambda s: f"M{s[0]}-K{s[1]}-B{s[2]}")
 def test_planner_auto_rule_for_int16_samples(g, shape):
     """int16 pairs need 5/8 of the float path's MFMAs: GAT_MC_AUTO hands them to the split-bf16 kernel from two column tiles
     on when the antennas fill two or four row tiles (scripts/r05_i16_planner_scan.sh), never at one row tile or one column
-    tile -- and whichever kernel runs, the result is the oracle's."""
+    tile, and never when the launch is too short to give every workgroup 16 steps (one block, four blocks) -- and
+    whichever kernel runs, the result is the oracle's."""
     import torch
-    M, K = shape
-    N, L = 4000, 3
-    case = make_case(M * 131 + K, N=N, M=M, L=L, K=K, B=1, fs=8e6, if_hz=1e5)
+    M, K, B = shape
+    N, L = 16384, 3
+    case = make_case(M * 131 + K, N=N, M=M, L=L, K=K, B=B, fs=8e6, if_hz=1e5)
     q = np.clip(np.rint(np.stack([case["re"], case["im"]], axis=-1) * (2000.0 / K)), -32768, 32767).astype(np.int16)
     case["re"], case["im"] = q[..., 0].astype(np.float32), q[..., 1].astype(np.float32)
     ctx = g.get_context()
     ctx.set_matrix_core(g.GAT_MC_AUTO)
-    op = g.StreamCorrelator(g.GPSL1(use_gpu=True), N, M, 1, K, case["shifts"], case["fs"])
+    op = g.StreamCorrelator(g.GPSL1(use_gpu=True), N, M, B, K, case["shifts"], case["fs"])
     p = case["prm"]
     op.set_params(g.make_params(p["prn0"], p["code_freq_hz"], p["carrier_freq_hz"], p["code_phase_chips"], p["carrier_phase_cycles"]))
     op(torch.from_numpy(q).to(ctx.device), None)
     info = ctx.last_launch_info()
-    assert info["matrix_core"] == planner_auto_kind(M, K, L, "i16"), info
+    assert info["matrix_core"] == planner_auto_kind(M, K, L, "i16", N, B), info
     assert info["bf16_terms"] == (2 if info["matrix_core"] == 2 else 0)
     check_close(op.result(), oracle_result(case), what=f"int16 auto {shape}")
