@@ -7,7 +7,8 @@ OUT=$REPO/gpurun_out/r05; mkdir -p $OUT
 export TMPDIR=/tmp
 SCR=$(mktemp -d /tmp/r05i.XXXXXX)
 cd /tmp
-for spec in "c5_i16:--baseline-config 4 --layout i16" "c5_i16_three_terms:--baseline-config 4 --layout i16 --option mc_i16_terms=3"; do
+: > $OUT/i16_profile_summary.txt
+for spec in "c5:--baseline-config 4" "c5_i16:--baseline-config 4 --layout i16" "c5_i16_three_terms:--baseline-config 4 --layout i16 --option mc_i16_terms=3"; do
   tag=${spec%%:*}; args=${spec#*:}
   timeout -k 10 280 rocprofv3 --kernel-trace --stats --output-format csv -d $SCR/$tag -- python3 $REPO/bench.py --no-cpu-baseline --no-single-block $args > $OUT/$tag.json 2> $OUT/$tag.log || exit 1
   f=$(find $SCR/$tag -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${tag}_kernel_stats.csv
@@ -20,7 +21,6 @@ print("%-20s %-62s calls %s avg %.1f us | bench: %.4f ms/launch %s frac %.4f bf1
 PY
 done
 cd $REPO
-bash scripts/r05_pmc.sh c5_i16 "fetch write sq1 sq2 clk mfma lds2" -- --baseline-config 4 --layout i16 || exit 1
-bash scripts/r05_pmc.sh c5 "mfma lds2" -- --baseline-config 4 || exit 1
-QARGS="--matrix-core 0" bash scripts/r05_quick.sh i16vec c4i16 c4k32i16 m32k32i16
-cat $OUT/quick_i16vec.txt
+PART=pmc ONLY="c5 c5_i16" bash scripts/r05_profile_configs.sh > /dev/null 2>&1
+cat gpurun_out/r05/pmc_c5.txt gpurun_out/r05/pmc_c5_i16.txt
+bash scripts/r05_pmc.sh c5_i16 "mfma lds2" -- --baseline-config 4 --layout i16 || exit 1

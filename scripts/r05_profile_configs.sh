@@ -39,6 +39,7 @@ fi
 cd $REPO
 for spec in "c2:" "c1shape:--num-samples 4000 --num-ants 1 --blocks 16384" "c3:--baseline-config 2" "c4:--baseline-config 3" "c5:--baseline-config 4" "c5_i16:--baseline-config 4 --layout i16" "c2_i16:--layout i16" "c2_i8:--layout i8" "c4x32:--num-samples 50000 --num-ants 16 --num-taps 3 --channels 32 --blocks 512"; do
   tag=${spec%%:*}; args=${spec#*:}
+  if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $tag "; then continue; fi   # ONLY="c5 c5_i16": a subset (a call is limited to 20 minutes)
   : > gpurun_out/r05/pmc_$tag.txt
   bash scripts/r05_pmc.sh $tag "fetch write sq1 sq2 clk" -- $args > /dev/null 2>&1
   cat gpurun_out/r05/pmc_$tag.txt >> $OUT/summary.txt

@@ -33,6 +33,7 @@ i8k8) run i8k8 --layout i8 --channels 8 --blocks 1024 ;;
 c4) run c4 --baseline-config 4 ;;
 m32k64) run m32k64 --num-samples 2000000 --num-ants 32 --channels 64 --blocks 1 --block-ms 20 ;;   # one column group fewer rows: 3 groups x 2 row tiles
 i8m16k8) run i8m16k8 --num-samples 50000 --num-ants 16 --channels 8 --blocks 64 --layout i8 ;;       # int8 pairs: the matrix kernel by default from 24 columns on
+c4i8) run c4i8 --baseline-config 4 --layout i8 ;;
 c4i16) run c4i16 --baseline-config 4 --layout i16 ;;
 c4k32i16) run c4k32i16 --num-samples 2000000 --num-ants 64 --channels 32 --blocks 1 --block-ms 20 --layout i16 --matrix-core 3 ;;
 m32k32i16) run m32k32i16 --num-samples 2000000 --num-ants 32 --channels 32 --blocks 1 --block-ms 20 --layout i16 --matrix-core 3 ;;
