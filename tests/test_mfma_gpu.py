@@ -338,3 +338,58 @@ def test_planner_auto_rule_for_int16_samples(g, shape):
     assert info["matrix_core"] == planner_auto_kind(M, K, L, "i16", N, B), info
     assert info["bf16_terms"] == (2 if info["matrix_core"] == 2 else 0)
     check_close(op.result(), oracle_result(case), what=f"int16 auto {shape}")
+
+
+# every instance <row tiles, column tiles> of the split-bf16 kernel: (M, K) that the planner maps onto it when mc_nct asks for
+# that many column tiles (3 taps: 6 columns per channel)
+INSTANCES = {(1, 1): (16, 5), (1, 2): (16, 10), (1, 4): (48, 21), (2, 1): (32, 5), (2, 2): (32, 10), (2, 4): (32, 21), (4, 2): (64, 10), (4, 4): (64, 21)}
+INSTANCE_LAYOUTS = ["planar", "interleaved", "int16", "int16-three-terms", "int8"]
+
+
+@pytest.mark.parametrize("layout", INSTANCE_LAYOUTS)
+@pytest.mark.parametrize("inst", list(INSTANCES), ids=lambda i: f"rt{i[0]}-nct{i[1]}")
+def test_every_instance_through_the_pipelined_step_loop(g, inst, layout):
+    """All 40 instances of the split-bf16 kernel with ~13 steps per workgroup: the consumers' fragment fetches are pipelined
+    across the step barrier from (fetch depth + 1) steps on (shorter launches -- most of the other cases here -- run the
+    plain loop), and those fetches are inline-assembly LDS reads whose registers the compiler must not move before the
+    inline-assembly wait: something only the result can tell per instance (scripts/check_async_registers.py looks at the
+    device code for it).  Parity with the oracle at 1e-5."""
+    import torch
+    rt, nct = inst
+    M, K = INSTANCES[inst]
+    T = min(32 * (4 // nct), 128 // rt)
+    B, L = 16, 3
+    N = 13 * 32 * T // (M // (16 * rt))  # ~13 steps for each of the ~512 workgroups the launch is cut into
+    N -= N % 8
+    case = make_case(zlib.crc32(repr((inst, layout)).encode()), N=N, M=M, L=L, K=K, B=B, fs=8e6, if_hz=1e5)
+    ctx = g.get_context()
+    if layout in ("planar", "interleaved"):
+        if layout == "planar":
+            sig = (torch.from_numpy(case["re"]).to(ctx.device), torch.from_numpy(case["im"]).to(ctx.device))
+        else:
+            sig = (torch.from_numpy(np.stack([case["re"], case["im"]], axis=-1)).to(ctx.device), None)
+    else:
+        dt, amp = (np.int8, 25.0 / K) if layout == "int8" else (np.int16, 6000.0 / K)
+        lim = np.iinfo(dt)
+        q = np.clip(np.rint(np.stack([case["re"], case["im"]], axis=-1) * amp), lim.min, lim.max).astype(dt)
+        case["re"], case["im"] = q[..., 0].astype(np.float32), q[..., 1].astype(np.float32)
+        sig = (torch.from_numpy(q).to(ctx.device), None)
+    ref = oracle_result(case)
+    p = case["prm"]
+    prm = g.make_params(p["prn0"], p["code_freq_hz"], p["carrier_freq_hz"], p["code_phase_chips"], p["carrier_phase_cycles"])
+    try:
+        ctx.set_matrix_core(g.GAT_MC_BF16_SPLIT)
+        ctx.set_option("mc_nct", nct)
+        ctx.set_option("mc_i16_terms", 3 if layout == "int16-three-terms" else 2)
+        op = g.StreamCorrelator(g.GPSL1(use_gpu=True), N, M, B, K, case["shifts"], case["fs"])
+        op.set_params(prm)
+        op(*sig)
+        info = ctx.last_launch_info()
+        assert info["matrix_core"] == 2 and info["ant_tile"] == 16 * rt and info["threads"] in (768, 1024), info
+        steps_each = -(-(-(-N // T)) // info["splits"])
+        assert 8 <= steps_each <= 40, (steps_each, info)
+        check_close(op.result(), ref, what=f"instance <{rt}, {nct}> {layout}: {steps_each} steps per workgroup")
+    finally:
+        ctx.set_option("mc_nct", 0)
+        ctx.set_option("mc_i16_terms", 2)
+        ctx.set_matrix_core(1)
