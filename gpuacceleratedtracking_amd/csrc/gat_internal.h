@@ -8,7 +8,7 @@
 
 // Diagnostic code (ablations, latency cuts, cycle stamps: kernels that compute WRONG results on purpose) and the
 // environment knobs of gat_create exist in development builds only; gat_version() names every flag of a build.
-#if (defined(GAT_DC_ABLATE) || defined(GAT_DC_LAT_CUT) || defined(GAT_ABLATE) || defined(GAT_MFMA_STAMPS) || defined(GAT_MB_CW8) || defined(GAT_MB_NT_LOADS) || \
+#if (defined(GAT_DC_ABLATE) || defined(GAT_DC_LAT_CUT) || defined(GAT_ABLATE) || defined(GAT_MFMA_STAMPS) || defined(GAT_MB_CW8) || defined(GAT_MB_NT_LOADS) || defined(GAT_MB_NO_RING) || \
      defined(GAT_RES_STAMPS) || defined(GAT_RES_FENCE)) &&                                                                                                 \
     !defined(GAT_DEV)
 #error "diagnostic builds (-DGAT_DC_ABLATE, -DGAT_DC_LAT_CUT, -DGAT_ABLATE, -DGAT_MFMA_STAMPS, -DGAT_MB_CW8, -DGAT_RES_STAMPS, -DGAT_RES_FENCE) need -DGAT_DEV"
@@ -294,6 +294,7 @@ struct MfArgs {
     int max_abs_shift, rep_span, rep_stride;
     int code_bits_stride; // dwords per sign-bit row (multiple of 4)
     int codes_in_lds;    // 1: the workgroup's chip tables are staged in LDS (they fit)
+    int rep_ring;        // split-bf16 kernel: entries of a channel slot's chip-sign ring (a multiple of the tile, >= rep_span + 2 tiles; rep_stride >= rep_ring + rep_span + tile)
     int mb_mode;         // split-bf16 kernel: MbMode of this launch (the host's choice: mb_mode(), or kMbThree on request for int16)
     unsigned long long *dbg; // diagnostic builds only (GAT_MFMA_STAMPS): per-wave cycle sums
     unsigned flags;
@@ -340,6 +341,15 @@ constexpr int mb_mode(int rt, int nct, int fmt, bool force_three = false)
 // two-term path: bytes of one LDS row of slot-ordered bf16 terms (10 bytes per sample), an odd multiple of 16 (rows of one
 // 16-lane group of a 16-byte read then start on distinct bank quads)
 constexpr int mb_two_row_bytes(int T) { return ((10 * T + 15) / 16 * 16) | 16; }
+// chip-sign ring of the split-bf16 kernel: ring length and the least row length for a tap span (gat_mfma_bf16.hip, s_rep)
+// (instances of two or four row tiles; those of one keep two buffers of span + T entries and copy the overlap)
+#ifdef GAT_MB_NO_RING // A/B build: two buffers and the overlap copy in every instance, as up to round 4
+constexpr bool mb_rep_ring_rows(int) { return false; }
+#else
+constexpr bool mb_rep_ring_rows(int rt) { return rt >= 2; }
+#endif
+constexpr int mb_rep_ring(int rt, int T, int span) { return mb_rep_ring_rows(rt) ? (span + 2 * T + T - 1) / T * T : 0; }
+constexpr int mb_rep_row(int rt, int T, int span) { return mb_rep_ring_rows(rt) ? mb_rep_ring(rt, T, span) + span + T : span + T; }
 constexpr size_t mb_lds_bytes(int rt, int nct, int fmt, int nslots, int rep_stride, int code_bits_stride, int mode = -1)
 {
     if (mode < 0) mode = mb_mode(rt, nct, fmt);
@@ -348,7 +358,7 @@ constexpr size_t mb_lds_bytes(int rt, int nct, int fmt, int nslots, int rep_stri
     const int xs = x1 ? T + 2 : T + 1, wbytes = x1 ? 8 : 16;
     const size_t xw = mode == kMbTwo ? (size_t)2 * rt * 32 * mb_two_row_bytes(T) + (size_t)2 * (2 * nslots + 1) * mb_two_row_bytes(T)
                                      : (size_t)2 * rt * 32 * xs * 8 + (size_t)2 * (2 * nslots + 1) * xs * wbytes;
-    return (size_t)kMbHeader + xw + (size_t)((2 * nslots * rep_stride + 3) & ~3) * 4 + (size_t)nslots * code_bits_stride * 4;
+    return (size_t)kMbHeader + xw + (size_t)(((mb_rep_ring_rows(rt) ? 1 : 2) * nslots * rep_stride + 3) & ~3) * 4 + (size_t)nslots * code_bits_stride * 4;
 }
 // f32-MFMA kernel: 256-sample tiles, 32 planes per row tile
 constexpr int kMfTile = 256;

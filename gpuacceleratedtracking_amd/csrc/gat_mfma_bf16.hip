@@ -437,8 +437,24 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     ChanInfoB *s_chan = reinterpret_cast<ChanInfoB *>(smem);
     u32x2 *s_x = reinterpret_cast<u32x2 *>(smem + kHeader);                 // [2][RT*32][XS]   (2-term: [2][RT*32] rows of RB bytes)
     u32x2 *s_w = X2 ? s_x + 2 * RT * 32 * (RB / 8) : s_x + 2 * RT * 32 * XS; // [2][wrows][WS] entries of WE u32x2 (2-term: [2][wrows] rows of RB bytes)
-    unsigned *s_rep = reinterpret_cast<unsigned *>(X2 ? s_w + 2 * wrows * (RB / 8) : s_w + 2 * wrows * WS * WE); // [2][nslots][RS]
-    unsigned *s_code = s_rep + ((2 * nslots * RS + 3) & ~3); // [nslots][code_bits_stride] sign-bit tables
+    // Chip-sign words: ONE ring of RR entries per channel slot (round 5; up to round 4: two buffers and a copy of the span
+    // overlapping the next step -- 98 entries x 23 slots per step at configs[4], 7 % of the kernel).  Entry e of the step
+    // whose window starts at ring position s (s advances by T per step, modulo RR) sits at (s + e) mod RR; positions below
+    // the window length WIN = span + T are ALSO kept at RR + position, so a window [s, s + WIN) is contiguous wherever it
+    // starts.  RR >= WIN + T: the entries written for the next step never touch the window being read.
+    // Instances of ONE row tile keep the two buffers and the copy (mb_rep_ring_rows): with the ring their consumer loops come out
+    // of the compiler with 40-350 scratch accesses (5 fragment sets in rotation), and no default path runs them on float data.
+    constexpr bool RINGREP = mb_rep_ring_rows(RT);
+    unsigned *s_rep = reinterpret_cast<unsigned *>(X2 ? s_w + 2 * wrows * (RB / 8) : s_w + 2 * wrows * WS * WE); // ring: [nslots][RS], RS >= RR + WIN; else [2][nslots][RS]
+    unsigned *s_code = s_rep + (((RINGREP ? 1 : 2) * nslots * RS + 3) & ~3); // [nslots][code_bits_stride] sign-bit tables
+    const int RR = a.rep_ring, WIN = a.rep_span + tile_samples(RT, NCT);
+    // a window's start one step on: (s + T) mod RR without a select -- a select on a wave-uniform value may be compiled into a
+    // BRANCH, and a control-flow merge inside the step loops makes the register allocator copy registers that inline-assembly
+    // loads still have in flight (the consumers' fragments, the producers' sample sets): wrong results in single instances
+    auto ring_next = [RR](int s_) {
+        const int n = s_ + tile_samples(RT, NCT), m = (n - RR) >> 31; // m = -1 while n < RR
+        return (n & m) | ((n - RR) & ~m);
+    };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool producer = wave >= NCW;
@@ -644,7 +660,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     // full floored modulo only when `anchor`; otherwise it follows from the exact floor differences
     // (chips advance monotonically): ip - ip_prev chips on from the index of T samples ago
     // (c.inc_ok: fewer than Lc chips per step), and the pair's second entry (dist samples on) at most two wraps on.
-    auto gen_rep2 = [&](const ChanInfoB &c, const unsigned *tab, unsigned *row, int nb, int e0, int dist, int e_end, bool anchor,
+    auto gen_rep2 = [&](const ChanInfoB &c, const unsigned *tab, unsigned *row, int win, int nb, int e0, int dist, int e_end, bool anchor,
                         int &ip_state, int &t_state) {
         const int x0 = nb + a.shifts[0] + e0;
         const double p0 = code_phase(c.ratio, c.tau, x0);
@@ -667,8 +683,18 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         const unsigned w0 = tab[t0 >> 5], w1 = tab[t1 >> 5];
         const unsigned m0 = (unsigned)__builtin_amdgcn_sbfe(w0, t0 & 31, 1) & 0x80008000u; // bit set: chip -1
         const unsigned m1 = (unsigned)__builtin_amdgcn_sbfe(w1, t1 & 31, 1) & 0x80008000u;
-        row[e0] = m0;
-        if (e0 + dist < e_end) row[e0 + dist] = m1;
+        auto put = [&](int e, unsigned m) { // window entry e -> ring position (and its copy behind the ring's end)
+            if constexpr (!RINGREP) {
+                row[e] = m;
+                return;
+            }
+            int q = win + e;
+            q -= q >= RR ? RR : 0;
+            row[q] = m;
+            if (q < WIN) row[RR + q] = m;
+        };
+        put(e0, m0);
+        if (e0 + dist < e_end) put(e0 + dist, m1);
     };
     // one item = (slot, 2 consecutive samples): carrier fragments + the 2 new replica entries.  A producer
     // thread owns the same item in every step (at most one: the planner keeps nslots * T / 2 <= PT) and
@@ -681,11 +707,13 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     const int item_slot = X2 ? ((item_i & ~3) | ((item_i & 1) << 1) | ((item_i >> 1) & 1)) : item_i;
     const int item_s0 = X2 ? 4 * item_q : X1 ? 2 * item_q : item_q; // the item's first sample (step-relative); its second one is OS further
     const bool have_item = producer && item_slot < nslots;
+    int p_win = 0; // ring position of the window of the step being produced (wave-uniform)
     auto produce = [&](int st, int buf, bool first) { // everything of step st except the samples
         const int nb = st * T;
+        const int win = p_win;
+        if constexpr (RINGREP) p_win = ring_next(p_win);
         u32x2 *wb = X2 ? s_w + buf * wrows * (RB / 8) : s_w + buf * wrows * WS * WE;
-        unsigned *rb = s_rep + buf * nslots * RS;
-        const unsigned *rprev = s_rep + (buf ^ 1) * nslots * RS;
+        unsigned *rb = RINGREP ? s_rep : s_rep + buf * nslots * RS;
         const ChanInfoB c = s_chan[have_item ? item_slot : 0]; // fetched first: in flight behind the overlap copy below
         if (first) { // entries [0, span): ceil(span / 2) pairs per slot
             const int gps = (span + 1) >> 1;
@@ -694,13 +722,14 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
                 const ChanInfoB cs = s_chan[slot];
                 if (!cs.valid) continue;
                 int ip_unused, t_unused;
-                gen_rep2(cs, s_code + slot * a.code_bits_stride, rb + slot * RS, nb, 2 * g, 1, span, true, ip_unused, t_unused);
+                gen_rep2(cs, s_code + slot * a.code_bits_stride, rb + slot * RS, win, nb, 2 * g, 1, span, true, ip_unused, t_unused);
             }
-        } else { // the overlap with the previous step is already known
+        } else if constexpr (!RINGREP) { // the overlap with the previous step is already known: from the other buffer
+            const unsigned *rprev = s_rep + (buf ^ 1) * nslots * RS;
             const int pw = wave - NCW;
             for (int slot = pw; slot < nslots; slot += PT / 64)
                 for (int e = lane; e < span; e += 64) rb[slot * RS + e] = rprev[slot * RS + e + T];
-        }
+        } // (ring: the overlap with the previous step is in place already)
         if (!have_item) return;
         if (!c.valid) return;
         const bool anchor = first || ((st - s_begin) % kReanchor) == 0; // wave-uniform
@@ -708,10 +737,10 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         if (first)
 #endif
         {
-            gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, nb, span + item_s0, OS, span + T,
+            gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, win, nb, span + item_s0, OS, span + T,
                      anchor || !c.inc_ok, rep_ip, rep_t);
             if constexpr (X2) // the item's samples 2 and 3
-                gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, nb, span + item_s0 + 2, 1, span + T,
+                gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, win, nb, span + item_s0 + 2, 1, span + T,
                          anchor || !c.inc_ok, rep_ip2, rep_t2);
         }
 #if defined(GAT_ABLATE) && (GAT_ABLATE & 2) // diagnostic: carrier fragments only in the first step
@@ -809,6 +838,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
 
     // LDS byte addresses of this lane's streams (the low 32 bits of a flat LDS address are the LDS offset)
     const unsigned lds_x = (unsigned)(uintptr_t)s_x, lds_w = (unsigned)(uintptr_t)s_w, lds_r = (unsigned)(uintptr_t)s_rep;
+    int c_win = 0; // ring position of the window of the step being consumed (wave-uniform)
     auto consume = [&](int buf) {
 #if defined(GAT_ABLATE) && (GAT_ABLATE & 8) // diagnostic: no MFMA work
         return;
@@ -817,7 +847,8 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
 #pragma unroll
         for (int t = 0; t < RT; ++t) x_addr[t] = lds_x + (unsigned)(buf * XBUF + t * XTILE + XU * x_off);
         const unsigned w_addr = lds_w + (unsigned)(buf * WBUF + WU * w_off);
-        const unsigned r_addr = lds_r + 4u * (unsigned)(buf * nslots * RS + r_off);
+        const unsigned r_addr = lds_r + 4u * (unsigned)((RINGREP ? c_win : buf * nslots * RS) + r_off);
+        if constexpr (RINGREP) c_win = ring_next(c_win);
         mfma_step<NM, RT, XM>(acc, w_addr, r_addr, x_addr, std::make_integer_sequence<int, NM>{});
     };
 
@@ -932,8 +963,8 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         for (int t = 0; t < RT; ++t) xa_c[t] = lds_x + (unsigned)(t * XTILE + XU * x_off);
         unsigned wa_c = lds_w + (unsigned)(WU * w_off);
         unsigned ra_c = lds_r + 4u * (unsigned)r_off;
-        int dx = XBUF, dw = __builtin_amdgcn_readfirstlane(WBUF),
-            dr = __builtin_amdgcn_readfirstlane(4 * (nslots * RS)); // bytes from the current buffer to the other one (sign flips per step)
+        int dx = XBUF, dw = __builtin_amdgcn_readfirstlane(WBUF), // bytes from the current buffer to the other one (sign flips per step)
+            dr_flip = __builtin_amdgcn_readfirstlane(4 * (nslots * RS)); // (chip signs in two buffers: one-row-tile instances)
         __syncthreads(); // the first step's buffer is complete
         if (groups > 0) {
             FragSet<RT, XM> fs[RING];
@@ -943,13 +974,21 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
             if constexpr (D > 3) frag_issue<3, RT, XM>(fs[3], wa_c, ra_c, xa_c);
             auto one = [&](auto r_c) {
                 constexpr int R = decltype(r_c)::value;
+                // the chip-sign window moves T entries on along its ring, or back to the ring's start
+                int dr = dr_flip;
+                if constexpr (RINGREP) {
+                    const int c_next = ring_next(c_win);
+                    dr = __builtin_amdgcn_readfirstlane(4 * (c_next - c_win));
+                    c_win = c_next;
+                } else {
+                    dr_flip = -dr_flip;
+                }
                 xstep<NM, RT, XM, R>(acc, fs, wa_c, ra_c, xa_c, dw, dr, dx, std::make_integer_sequence<int, NM>{});
                 wa_c += (unsigned)dw; // the buffers change roles
                 ra_c += (unsigned)dr;
 #pragma unroll
                 for (int t = 0; t < RT; ++t) xa_c[t] += (unsigned)dx;
                 dw = -dw;
-                dr = -dr;
                 dx = -dx;
             };
             for (int g = 0; g < groups; ++g) {

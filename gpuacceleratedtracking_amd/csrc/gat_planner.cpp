@@ -172,7 +172,8 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
             for (int n = n_first; n >= 1 && !kind; n >>= 1) {
                 rt = (rt_max == 4 && n == 1) ? 2 : rt_max; // <4,1> does not fit the VGPR budget of a 12-wave workgroup
                 const int T = mfma_bf16_tile_samples(rt, n);
-                int rs = ((T + (int)span + 31) / 32) * 32 + 1; // odd: channel rows land on different banks
+                // chip-sign rows: a ring + the copy of its first window (gat_mfma_bf16.hip, s_rep); odd: channel rows land on different banks
+                int rs = ((mb_rep_row(rt, T, (int)span) + 31) / 32) * 32 + 1;
                 const int ns = mfma_bf16_slots(n, L, K);
                 // at most one (slot, sample pair) item per producer thread
                 if (ns * T / 2 > mfma_bf16_producer_threads(rt, n) || ns > mfma_bf16_max_slots()) continue;
@@ -260,6 +261,7 @@ int32_t gat::correlate_impl(gat_ctx *c, const gat_signal_desc *sig, const gat_ch
             m.max_abs_shift = (int)max_shift;
             m.rep_span = (int)span;
             m.rep_stride = rep_stride_m;
+            m.rep_ring = kind == 2 ? mb_rep_ring(rt, T, (int)span) : 0;
             m.flags = flags;
             for (int l = 0; l < kMfmaMaxTaps; ++l) {
                 m.shifts[l] = shifts[order[std::min(l, L - 1)]];

@@ -169,6 +169,10 @@ hipError_t launch_mfma_bf16(const MfArgs &a, int rt, int nct, int fmt, unsigned 
     REQUIRE((long long)a.steps_per_split * T <= kMbMaxChain || a.steps_per_split == 1, "bf16 mfma: chain of %d x %d samples", a.steps_per_split, T);
     REQUIRE(a.code_bits && a.zeros && a.code_bits_stride % 4 == 0 && a.code_bits_stride * 32 >= a.Lc, "bf16 mfma: sign-bit tables");
     REQUIRE(a.mb_mode == mb_mode(rt, nct, fmt) || (fmt == GAT_LAYOUT_INTERLEAVED_I16 && a.mb_mode == kMbThree), "bf16 mfma: operand split %d for layout %d", a.mb_mode, fmt);
+    if (mb_rep_ring_rows(rt))
+        REQUIRE(a.rep_ring % T == 0 && a.rep_ring >= a.rep_span + 2 * T && a.rep_stride >= a.rep_ring + a.rep_span + T, "bf16 mfma: chip-sign ring %d in rows of %d for span %d, tile %d", a.rep_ring, a.rep_stride, a.rep_span, T);
+    else
+        REQUIRE(a.rep_ring == 0 && a.rep_stride >= a.rep_span + T, "bf16 mfma: chip-sign rows of %d for span %d, tile %d", a.rep_stride, a.rep_span, T);
     REQUIRE(a.mb_mode != kMbTwo || a.nslots * T / 4 <= mb_threads(rt, nct) - 64 * mb_consumer_waves(rt, nct), "bf16 mfma: two-term items");
     REQUIRE(lds_bytes == mb_lds_bytes(rt, nct, fmt, a.nslots, a.rep_stride, a.code_bits_stride, a.mb_mode) && lds_bytes <= 160 * 1024, "bf16 mfma: LDS %u", lds_bytes);
     check_mf_common(a, grid, T, "bf16 mfma");

@@ -352,8 +352,9 @@ def test_every_instance_through_the_pipelined_step_loop(g, inst, layout):
     """All 40 instances of the split-bf16 kernel with ~13 steps per workgroup: the consumers' fragment fetches are pipelined
     across the step barrier from (fetch depth + 1) steps on (shorter launches -- most of the other cases here -- run the
     plain loop), and those fetches are inline-assembly LDS reads whose registers the compiler must not move before the
-    inline-assembly wait: something only the result can tell per instance (scripts/check_async_registers.py looks at the
-    device code for it).  Parity with the oracle at 1e-5."""
+    inline-assembly wait: something only the result can tell, per instance (round 5: a select on the window position of
+    the chip-sign ring, compiled into a branch, made the allocator copy fragments in flight in two of the 40 instances
+    while the other 38 passed).  Parity with the oracle at 1e-5."""
     import torch
     rt, nct = inst
     M, K = INSTANCES[inst]
