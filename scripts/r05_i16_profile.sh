@@ -21,6 +21,6 @@ print("%-20s %-62s calls %s avg %.1f us | bench: %.4f ms/launch %s frac %.4f bf1
 PY
 done
 cd $REPO
-PART=pmc ONLY="c5 c5_i16" bash scripts/r05_profile_configs.sh > /dev/null 2>&1
+ONLY="c5 c5_i16" bash scripts/r05_profile_configs.sh pmc > /dev/null 2>&1
 cat gpurun_out/r05/pmc_c5.txt gpurun_out/r05/pmc_c5_i16.txt
 bash scripts/r05_pmc.sh c5_i16 "mfma lds2" -- --baseline-config 4 --layout i16 || exit 1

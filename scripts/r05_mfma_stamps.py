@@ -35,5 +35,7 @@ tot = (d[:, :, 0] + d[:, :, 1])
 print("cycles per step and wave (s_memtime ticks: 100 MHz on this part -> x ~23 for shader cycles), mean over workgroups:")
 for name, sl in (("consumers (waves 0-3)", slice(0, 4)), ("producers, item waves (4-9)", slice(4, 10)), ("producers, sample waves (10-15)", slice(10, waves))):
     w = d[:, sl]
-    print(f"  {name:34s} work {w[:, :, 0].mean() / steps:8.2f}  barrier wait {w[:, :, 1].mean() / steps:8.2f}  "
+    print(f"  {name:34s} work {w[:, :, 0].mean() / steps:8.2f} (slowest wave of the role {w[:, :, 0].max(axis=1).mean() / steps:8.2f})  barrier wait {w[:, :, 1].mean() / steps:8.2f}  "
           f"[carriers+replica {w[:, :, 2].mean() / steps:8.2f}  split+store {w[:, :, 3].mean() / steps:8.2f}]  total {tot[:, sl].mean() / steps:8.2f}")
+per_wave = d[:, :, 0].mean(axis=0) / steps
+print("  work per wave:", " ".join(f"{x:.0f}" for x in per_wave))
