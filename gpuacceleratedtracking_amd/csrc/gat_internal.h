@@ -8,7 +8,7 @@
 
 // Diagnostic code (ablations, latency cuts, cycle stamps: kernels that compute WRONG results on purpose) and the
 // environment knobs of gat_create exist in development builds only; gat_version() names every flag of a build.
-#if (defined(GAT_DC_ABLATE) || defined(GAT_DC_LAT_CUT) || defined(GAT_ABLATE) || defined(GAT_MFMA_STAMPS) || defined(GAT_MB_CW8) || defined(GAT_MB_NT_LOADS) || defined(GAT_MB_NO_RING) || \
+#if (defined(GAT_DC_ABLATE) || defined(GAT_DC_LAT_CUT) || defined(GAT_ABLATE) || defined(GAT_MFMA_STAMPS) || defined(GAT_MB_CW8) || defined(GAT_MB_NT_LOADS) || defined(GAT_MB_NO_RING) || defined(GAT_MB_X2_ITEMS4) || defined(GAT_MB_X2_DEPTH2) || \
      defined(GAT_RES_STAMPS) || defined(GAT_RES_FENCE)) &&                                                                                                 \
     !defined(GAT_DEV)
 #error "diagnostic builds (-DGAT_DC_ABLATE, -DGAT_DC_LAT_CUT, -DGAT_ABLATE, -DGAT_MFMA_STAMPS, -DGAT_MB_CW8, -DGAT_RES_STAMPS, -DGAT_RES_FENCE) need -DGAT_DEV"

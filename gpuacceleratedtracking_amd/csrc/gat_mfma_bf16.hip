@@ -217,6 +217,11 @@ template <int RT, int XM = kMbThree>
 constexpr int frag_depth()
 {
     constexpr int per = XM == kMbTwo ? 3 + RT : 2 + RT;
+#ifndef GAT_MB_X2_DEPTH2
+    // (four row tiles on the two-term path: 64 accumulator registers + 23 per fragment set -- three sets do not fit the 128 of a
+    // 16-wave workgroup, and what the allocator then spills are fragments that LDS reads may still have in flight: two sets)
+    if (XM == kMbTwo && RT == 4) return 1;
+#endif
     return (15 / per) < 4 ? (15 / per) : 4;
 }
 
@@ -410,7 +415,11 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     // consumers read adjacent sample pairs as one 16-byte entry, the item keeps 2q, 2q + 1.  2-term path: an item is FOUR
     // adjacent samples 4q .. 4q + 3 (40 bytes of a slot-ordered row, five 8-byte stores), rotated one sample at a time.
     constexpr int OS = XM == kMbThree ? T / 2 : 1;
+#ifdef GAT_MB_X2_ITEMS4 // A/B build: four samples per item of the two-term path (40 bytes, five 8-byte stores)
     constexpr int IS = X2 ? 4 : 2;    // samples per producer item
+#else
+    constexpr int IS = 2;             // samples per producer item (2-term path: 20 bytes of a slot-ordered row, five 4-byte stores)
+#endif
     constexpr int RB = mb_two_row_bytes(T); // 2-term path: bytes per X / W row (10 per sample, slot order)
     // LDS row strides in entries.  3-term: X 8 B / W 16 B per sample, odd (32 planes x one sample = 32 distinct
     // bank pairs).  1-term: X 8 B / W 8 B per sample, read in 16-byte pairs: even, rows 4 banks apart.
@@ -705,7 +714,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
     // (2-term path: the items of 16 consecutive lanes are two slots 2 apart -- rows 4 apart, complementary banks, as for X)
     const int item_i = ptid / (T / IS), item_q = ptid % (T / IS);
     const int item_slot = X2 ? ((item_i & ~3) | ((item_i & 1) << 1) | ((item_i >> 1) & 1)) : item_i;
-    const int item_s0 = X2 ? 4 * item_q : X1 ? 2 * item_q : item_q; // the item's first sample (step-relative); its second one is OS further
+    const int item_s0 = X2 ? IS * item_q : X1 ? 2 * item_q : item_q; // the item's first sample (step-relative); its second one is OS further
     const bool have_item = producer && item_slot < nslots;
     int p_win = 0; // ring position of the window of the step being produced (wave-uniform)
     auto produce = [&](int st, int buf, bool first) { // everything of step st except the samples
@@ -739,7 +748,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         {
             gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, win, nb, span + item_s0, OS, span + T,
                      anchor || !c.inc_ok, rep_ip, rep_t);
-            if constexpr (X2) // the item's samples 2 and 3
+            if constexpr (X2 && IS == 4) // the item's samples 2 and 3
                 gen_rep2(c, s_code + item_slot * a.code_bits_stride, rb + item_slot * RS, win, nb, span + item_s0 + 2, 1, span + T,
                          anchor || !c.inc_ok, rep_ip2, rep_t2);
         }
@@ -756,7 +765,18 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         }
         car_r = cr;
         car_i = ci;
-        if constexpr (X2) { // slot order of a sample: h m l h m  (against a a a b b)
+        if constexpr (X2 && IS == 2) { // slot order of a sample: h m l h m  (against a a a b b); two samples = five dwords
+            const Split3 c0 = split3(cr), s0 = split3(-ci);
+            const float tr = __builtin_fmaf(cr, c.wr, -(ci * c.wi));
+            ci = __builtin_fmaf(cr, c.wi, ci * c.wr);
+            cr = tr;
+            const Split3 c1 = split3(cr), s1 = split3(-ci);
+            unsigned *dre = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(wb) + (2 * item_slot) * RB + 20 * item_q);
+            unsigned *dim = reinterpret_cast<unsigned *>(reinterpret_cast<unsigned char *>(dre) + RB);
+            dre[0] = GAT_P2(c0.r, c0.v); dre[1] = GAT_P2(c0.v, c0.r2); dre[2] = GAT_P2(c1.v, c0.r); dre[3] = GAT_P2(c1.r2, c1.r); dre[4] = GAT_P2(c1.r, c1.v);
+            dim[0] = GAT_P2(s0.r, s0.v); dim[1] = GAT_P2(s0.v, s0.r2); dim[2] = GAT_P2(s1.v, s0.r); dim[3] = GAT_P2(s1.r2, s1.r); dim[4] = GAT_P2(s1.r, s1.v);
+            return;
+        } else if constexpr (X2) {
             unsigned ch[4], cm[4], cl[4], sh[4], sm[4], sl[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
