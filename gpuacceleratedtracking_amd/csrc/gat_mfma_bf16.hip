@@ -218,9 +218,9 @@ constexpr int frag_depth()
 {
     constexpr int per = XM == kMbTwo ? 3 + RT : 2 + RT;
 #ifndef GAT_MB_X2_DEPTH2
-    // (four row tiles on the two-term path: 64 accumulator registers + 23 per fragment set -- three sets do not fit the 128 of a
+    // (four row tiles on the two-term and one-term paths: 64 accumulator registers + 23 per fragment set -- three sets do not fit the 128 of a
     // 16-wave workgroup, and what the allocator then spills are fragments that LDS reads may still have in flight: two sets)
-    if (XM == kMbTwo && RT == 4) return 1;
+    if ((XM == kMbTwo || XM == kMbOne) && RT == 4) return 1; // (one term: 22 registers per set, the same arithmetic)
 #endif
     return (15 / per) < 4 ? (15 / per) : 4;
 }
