@@ -22,13 +22,16 @@
 // signs: the consumer XORs the fragment with a 0x80008000 / 0 mask from the LDS code replica -- the
 // three taps and the 16*RT antennas of a tile all reuse one carrier split.
 // Code replica: exactly the reference's FP64 expression, unfused (src/algorithms.jl:179), as in the
-// other kernels; per step only the T new entries are evaluated, the tap-span overlap is copied
-// from the previous step's buffer.
+// other kernels; per step only the T new entries are evaluated: the chip-sign words of a channel slot live in a ring in
+// LDS that the step's window moves along (round 5, s_rep below; instances of one row tile: two buffers and a copy of
+// the tap-span overlap).
 // Sample formats: planar / interleaved ComplexF32, int16 and int8 pairs (template FMT).  int8 samples are exact in
 // ONE bf16 term: 3 products {x*hi, x*mid, x*lo} = 4 slots per sample, a slice covers 4 samples (half the MFMAs) and
-// both fragments come ready-made from LDS (X = {x|x, x|0}, W = {hi|mid, lo|0} per sample; see X1 below).
-// What bounds the kernel (profiles/r01c_mfma_bf16_ablation.txt): the vector issue port -- the
-// producers' splits / permutes / FP64 code phases do not fit into the issue cycles the MFMAs leave free.
+// both fragments come ready-made from LDS (X = {x|x, x|0}, W = {hi|mid, lo|0} per sample; see X1 below).  int16 samples are
+// exact in TWO terms: 5 products per sample laid as a stream over consecutive MFMAs (round 5, FragSet<RT, kMbTwo> below).
+// What bounds the kernel (profiles/r05/mfma_cycle_stamps_*.txt, mfma_bf16_ablation_*.txt): float samples --
+// the consumers (matrix pipe + fragment fetches + operand preparation) at the power cap's clock; int16 / int8 -- the producer
+// waves' chains and the consumers about level, coupled through LDS and the issue ports.
 // One accumulation chain covers at most kMaxChain samples (the planner splits longer blocks over
 // workgroups, finalize_kernel adds the partials in a fixed order), so the f32 rounding of a running
 // sum of millions of samples stays far inside 1e-5.
@@ -723,7 +726,7 @@ __global__ void __launch_bounds__(mb_threads(RT, NCT)) mfma_bf16_kernel(const Mf
         if constexpr (RINGREP) p_win = ring_next(p_win);
         u32x2 *wb = X2 ? s_w + buf * wrows * (RB / 8) : s_w + buf * wrows * WS * WE;
         unsigned *rb = RINGREP ? s_rep : s_rep + buf * nslots * RS;
-        const ChanInfoB c = s_chan[have_item ? item_slot : 0]; // fetched first: in flight behind the overlap copy below
+        const ChanInfoB c = s_chan[have_item ? item_slot : 0]; // fetched first: in flight behind what follows
         if (first) { // entries [0, span): ceil(span / 2) pairs per slot
             const int gps = (span + 1) >> 1;
             for (int id = ptid; id < nslots * gps; id += PT) {
