@@ -64,13 +64,17 @@ EXPECTED = {
     "configs[2]": (("GPSL5", 50000, 4, 5, 12, 256), dict(matrix_core=0, threads=256, ant_tile=4, vec=4, channels_per_wg=2, splits=1, prefetch_depth=1)),
     "configs[3] shard": (("GPSL1", 50000, 16, 3, 4, 512), dict(matrix_core=0, threads=256, ant_tile=16, vec=4, channels_per_wg=4, splits=1, prefetch_depth=1)),
     "configs[3] whole": (("GPSL1", 50000, 16, 3, 32, 128), dict(matrix_core=0, threads=256, ant_tile=16, vec=4, channels_per_wg=4, splits=1, prefetch_depth=1)),
+    # (round 5: the split-bf16 kernel's <4 row tiles, 4 column tiles> instance, 3 column groups x 256 splits = 3 rounds of the chip)
+    "configs[4]": (("GPSL1", 2000000, 64, 3, 64, 1), dict(matrix_core=2, threads=1024, ant_tile=64, workgroups=768, splits=256, bf16_terms=3), dict(block_seconds=20e-3)),
+    "configs[4] from int16 pairs": (("GPSL1", 2000000, 64, 3, 64, 1), dict(matrix_core=2, threads=1024, ant_tile=64, workgroups=768, splits=256, bf16_terms=2),
+                                    dict(block_seconds=20e-3, layout=2)),
 }
 
 
 @pytest.mark.parametrize("name", list(EXPECTED))
 def test_planner_picks_the_expected_instance(g, name):
-    args, want = EXPECTED[name]
-    op, desc, sig, prm = g.build_stream(*args)
+    args, want = EXPECTED[name][:2]
+    op, desc, sig, prm = g.build_stream(*args, **(EXPECTED[name][2] if len(EXPECTED[name]) > 2 else {}))
     op.launch(desc)
     op.ctx.sync()
     info = op.ctx.last_launch_info()
